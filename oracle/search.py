@@ -1,0 +1,22 @@
+"""Oracle a7: exact inner-product top-k (faiss IndexFlatIP.search semantics as used at
+reference database.py:121: k largest q.x per query row, scores descending, labels int64,
+-1 labels when fewer than k rows exist).  faiss is un-vendored; exact flat IP is
+definitional, so this is a restatement of the definition, not of faiss code."""
+import numpy as np
+
+
+def flat_ip_topk(query, db, k):
+    query = np.ascontiguousarray(query, dtype=np.float32)
+    db = np.ascontiguousarray(db, dtype=np.float32).reshape(-1, query.shape[1])
+    nq, n = query.shape[0], db.shape[0]
+    D = np.full((nq, k), -np.finfo(np.float32).max, dtype=np.float32)
+    I = np.full((nq, k), -1, dtype=np.int64)
+    if n == 0:
+        return D, I
+    s = query @ db.T
+    kk = min(k, n)
+    # stable: ties broken by smaller label
+    order = np.argsort(-s, axis=1, kind="stable")[:, :kk]
+    D[:, :kk] = np.take_along_axis(s, order, axis=1)
+    I[:, :kk] = order
+    return D, I

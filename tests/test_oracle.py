@@ -1,0 +1,143 @@
+"""The oracle (oracle/) against the golden vectors generated from the reference's own code
+(tests/golden/make_golden.py) and against the probed outputs SURVEY.md §8c records."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import make_golden as mg
+from oracle import encoder, melspec, native, search, segmenter, seqscore
+from pfann_amd import synth
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("name", ["default", "seg", "n640d64", "tiny", "nafstyle"])
+def test_encoder_matches_reference(name):
+    z = np.load(os.path.join(G, "encoder_%s.npz" % name))
+    params = json.loads(str(z["params"]))
+    _, _, _, F, T = synth.model_dims(params)
+    sd = synth.make_state_dict(params, seed=123)
+    x = mg.encoder_inputs(F, T)
+    taps = []
+    emb = encoder.encode(x, sd, params, norm=True, taps=taps)
+    raw = encoder.encode(x, sd, params, norm=False)
+    assert np.abs(emb - z["emb"]).max() < 2e-6
+    assert np.abs(raw - z["raw"]).max() < 2e-5 * max(1.0, np.abs(z["raw"]).max())
+    sums = np.array([[t.astype(np.float64).sum(), np.abs(t.astype(np.float64)).sum()] for t in taps])
+    assert np.allclose(sums, z["tap_sums"], rtol=1e-5, atol=1e-2)
+
+
+def test_segmenter_matches_reference(tmp_path):
+    z = np.load(os.path.join(G, "segmenter.npz"))
+    params = json.load(open(os.path.join(os.path.dirname(G), "..", "configs", "default.json")))
+    inputs = mg.segmenter_inputs()
+    for name, pcm in inputs.items():
+        synth.write_wav(str(tmp_path / (name + ".wav")), pcm)
+    (tmp_path / "notwav.wav").write_bytes(b"this is not a wave file")
+    for fsm in (1, 2):
+        p = json.loads(json.dumps(params))
+        p["indexer"]["frame_shift_mul"] = fsm
+        for name in list(inputs) + ["missing", "notwav"]:
+            w = segmenter.load_segments(str(tmp_path / (name + ".wav")), p)
+            key = "%s_fsm%d" % (name, fsm)
+            assert tuple(z[key + "_shape"]) == w.shape, key
+            if w.shape[0]:
+                # bit-identical rows, and checksums over every row
+                assert np.array_equal(w[z[key + "_rows"]], z[key + "_vals"]), key
+                sums = np.stack([w.astype(np.float64).sum(1), np.abs(w.astype(np.float64)).sum(1)], 1)
+                assert np.allclose(sums, z[key + "_sums"], rtol=0, atol=1e-9), key
+
+
+DB_CASES = ["clean_hit", "negative_offset", "past_end", "k_gt_ntotal", "duplicate_songs",
+            "nonpositive_best", "no_candidates", "frame_shift_mul2", "empty_db", "random_noisy"]
+
+
+@pytest.mark.parametrize("name", DB_CASES)
+def test_seqscore_python_path_matches_reference(name):
+    z = np.load(os.path.join(G, "database.npz"))
+    db, q, labels = z[name + "_db"], z[name + "_q"], z[name + "_labels"]
+    pos = seqscore.song_pos_from_key(z[name + "_key"])
+    fsm = int(z[name + "_fsm"])
+    score, (song, sec), ss = seqscore.query_embeddings_base(q, labels, db, pos, 0.5, fsm)
+    assert song == int(z[name + "_song"])
+    assert sec == float(z[name + "_sec"])
+    assert score == float(z[name + "_score"]) or abs(score - float(z[name + "_score"])) < 1e-6
+    assert np.allclose(ss, z[name + "_song_score"], atol=1e-6)
+    # the labels the reference searched with are the exact flat top-k
+    if name not in ("no_candidates", "nonpositive_best") and db.shape[0]:
+        D, I = search.flat_ip_topk(q, db, labels.shape[1])
+        assert np.array_equal(I, labels)
+        D2, I2 = native.flat_ip_topk(q, db, labels.shape[1])
+        assert np.array_equal(I2, labels)
+        assert np.abs(D - D2).max() < 1e-6
+
+
+@pytest.mark.parametrize("name", DB_CASES)
+def test_seqscore_c_path(name):
+    """C restatement of cpp/seqscore.cpp: agrees with the Python path wherever SURVEY.md
+    §8c says the two reference paths agree, and shows the documented divergences."""
+    z = np.load(os.path.join(G, "database.npz"))
+    db, q, labels = z[name + "_db"], z[name + "_q"], z[name + "_labels"]
+    if db.shape[0] == 0:
+        pytest.skip("cpp path has no empty-db branch (database.py:126-127 is python-only)")
+    pos = seqscore.song_pos_from_key(z[name + "_key"])
+    fsm = int(z[name + "_fsm"])
+    best, ss = native.seq_score(db, pos, q, labels, fsm, 0.0)
+    hop = 0.5
+    if name == "no_candidates":
+        assert best == -1 and not ss.any()
+        return
+    assert best == int(z[name + "_song"])
+    if name == "nonpositive_best":
+        # song_scores never records a non-positive score; caller reads back 0.0 / 0.0
+        assert not ss.any()
+        return
+    # caller-side scaling of database.py:190-193
+    assert abs(ss[best, 0] - float(z[name + "_score"])) < 1e-6
+    assert ss[best, 1] * hop / fsm == float(z[name + "_sec"])
+    ss2 = ss.copy()
+    ss2[:, 1] *= hop / fsm
+    assert np.allclose(ss2, z[name + "_song_score"], atol=1e-6)
+
+
+def test_seqscore_c_probed_values():
+    """Known answers recorded from the compiled reference in SURVEY.md §8c:
+    4 of 6 rows match with divisor 6 -> 0.6666666269 in fp32."""
+    z = np.load(os.path.join(G, "database.npz"))
+    n = "negative_offset"
+    pos = seqscore.song_pos_from_key(z[n + "_key"])
+    best, ss = native.seq_score(z[n + "_db"], pos, z[n + "_q"], z[n + "_labels"], 1, 0.0)
+    assert best == 1 and ss[1, 1] == -2.0
+    assert abs(float(ss[1, 0]) - 0.6666666269) < 1e-7
+
+
+def test_seqscore_c_alpha():
+    z = np.load(os.path.join(G, "database.npz"))
+    n = "random_noisy"
+    pos = seqscore.song_pos_from_key(z[n + "_key"])
+    db, q, lab = z[n + "_db"], z[n + "_q"], z[n + "_labels"]
+    best, ss = native.seq_score(db, pos, q, lab, 1, 2.0)
+    assert best == 17
+    off = int(ss[17, 1])
+    ips = np.array([db[pos[17] + off + i] @ q[i] for i in range(19)], np.float32)
+    assert abs(ss[17, 0] - np.exp(-2.0 * (1 - ips) ** 2).mean()) < 1e-5
+
+
+def test_melspec_restatement_self_consistency():
+    """a2 is parity-unpinned (torchaudio absent); check the fp32 torch.stft restatement
+    against the independent float64 gather+rfft form and the documented bank shape."""
+    params = json.load(open(os.path.join(os.path.dirname(G), "..", "configs", "default.json")))
+    fb = melspec.mel_filterbank(8000, 1024, 256, 300, 4000).numpy()
+    nz = fb > 0
+    assert nz.sum() == 942 and nz.sum(0).max() == 7 and nz.sum(0).min() >= 1
+    rows = np.nonzero(nz.sum(1))[0]
+    assert rows[0] == 39 and rows[-1] == 511
+    pcm = synth.make_song(3, seconds=3.0)
+    segs = segmenter.segment(segmenter.pcm_to_mono(pcm[:, None]), 8000, 4000)
+    m32 = melspec.melspec(segs, params)
+    m64 = melspec.melspec_f64(segs, params)
+    assert m32.shape == (5, 256, 32)
+    assert np.abs(m32 - m64).max() < 5e-3
+    assert np.abs(m32 - m64).mean() < 1e-4
