@@ -1,0 +1,177 @@
+/* pfann_amd C ABI -- the drop-in boundary of the MI355X hot path.
+ *
+ * Plain C: pointers, sizes, opaque handles.  No torch / C++ types cross this boundary.
+ * Every function returns 0 (or a value documented below) on success and a negative code
+ * on failure; pfann_last_error() returns the message of the last failure on this thread.
+ * No exception ever crosses the boundary.  Pointers named *_dev are device (HBM)
+ * pointers, e.g. torch.Tensor.data_ptr(); *_host are host pointers; `stream` is a
+ * hipStream_t passed as void* (0 = the null stream).
+ *
+ * Reference interfaces these entry points replace (paths relative to the reference repo):
+ *   version, seq_score      cpp/seqscore.cpp:27-43 (bound by ctypes at database.py:15-32,
+ *                           called at database.py:178-189)
+ *   pfann_melspec           datautil/melspec.py:33-50  MelSpec.forward
+ *   pfann_encode            model.py:148-153           FpNetwork.forward(x, norm)
+ *   pfann_segment_embed     builder.py:88-100 / matcher.py:110-128 emit loops fused with
+ *                           datautil/musicdata.py:82-88 (pad, unfold, mean removal)
+ *   pfann_pcm16_to_mono     datautil/musicdata.py:48,72-80
+ *   pfann_db_*              database.py:75-109 Database.__init__ (index + song_pos)
+ *   pfann_search_topk       database.py:121  index.search(query, top_k)  (exact flat IP)
+ *   pfann_match             database.py:117-166 query_embeddings_base (search + rerank)
+ */
+#ifndef PFANN_AMD_H
+#define PFANN_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PFANN_SEQSCORE_VERSION 20220625002LL
+
+/* ---- the reference's native seam, byte-identical signatures ------------------------ */
+
+/* cpp/seqscore.cpp:27-30.  database.py:30 exits unless this equals 20220625002. */
+long long version(void);
+
+/* cpp/seqscore.cpp:32-43.  `index` is a pfann_db* (the reference passes a faiss::Index*;
+ * only d + row fetch are used there).  All other pointers are HOST pointers, exactly as
+ * database.py:178-189 passes them.  song_scores must arrive zeroed (database.py:176);
+ * offsets are written in frames.  Returns the best song id, or -1 with no candidate. */
+int seq_score(void *index, const int64_t *song_pos, int n_songs, const float *query,
+              int query_len, const int64_t *labels, int top_k, float *song_scores,
+              int frame_shift_mul, float score_alpha);
+
+/* ---- errors ------------------------------------------------------------------------- */
+const char *pfann_last_error(void);
+
+/* ---- front-end + encoder ------------------------------------------------------------- */
+typedef struct pfann_ctx pfann_ctx;
+
+typedef struct pfann_config {
+    /* front-end (config keys sample_rate, stft_n, stft_hop, n_mels, segment_size)        */
+    int32_t segment_len;    /* samples per segment = int(sample_rate * segment_size)      */
+    int32_t stft_n;         /* FFT size, power of two, 64..4096                            */
+    int32_t stft_hop;
+    int32_t n_mels;
+    int32_t power;          /* 2 (default) or 1 (naf_mode), melspec.py:27                  */
+    int32_t pad_reflect;    /* 1 reflect (default) / 0 constant zeros, melspec.py:28       */
+    int32_t log_mode;       /* 1 natural log (default), 2 log10, 0 none, melspec.py:43-46  */
+    int32_t spec_norm_max;  /* 0: L2 normalise (default); 1: 'max' mode, melspec.py:35,48  */
+    float   log_eps;        /* 1e-8 (default) or 0.06 (naf_mode), melspec.py:38-41         */
+    /* encoder (config key "model") */
+    int32_t d, h, u;
+    int32_t fuller;         /* 1: full conv2, 0: depthwise, model.py:26-29                 */
+    int32_t activation;     /* 0 ReLU, 1 ELU, model.py:7-12                                */
+    int32_t relu_after_bn;  /* model.py:58-72                                              */
+    int32_t stride_t[8];    /* conv1 stride along T per block (default 2), model.py:83-85  */
+    int32_t stride_f[8];    /* conv2 stride along F per block (default 2)                  */
+    int32_t max_batch;      /* segments processed per internal pass (workspace size)       */
+} pfann_config;
+
+/* Creates a context on HIP device `device`; NULL on failure (see pfann_last_error). */
+pfann_ctx *pfann_create(const pfann_config *cfg, int device);
+void pfann_destroy(pfann_ctx *ctx);
+
+/* Mel filterbank fb[n_freqs][n_mels] (host, row-major), n_freqs = stft_n/2+1.  The host
+ * mirror builds it (pfann_amd/melspec.py) so any bank torchaudio would build can be used. */
+int pfann_set_melbank(pfann_ctx *ctx, const float *fb_host, int n_freqs, int n_mels);
+
+/* One tensor of FpNetwork.state_dict() by its reference name (e.g.
+ * "f.convs.3.conv2.weight", "g.linear1.bias"), host pointer, PyTorch layout.  The library
+ * re-lays it out for its kernels.  Returns -2 for an unknown name, -3 for a size mismatch. */
+int pfann_load_weight(pfann_ctx *ctx, const char *name, const float *host, int64_t numel);
+/* Number of state_dict tensors still missing (0 = ready). */
+int pfann_weights_missing(pfann_ctx *ctx);
+
+/* MelSpec.forward: segs_dev[b*seg_stride + i], i < segment_len  ->  out_dev[B][n_mels][T],
+ * T = 1 + segment_len/stft_hop.  remove_mean=1 additionally subtracts each segment's mean
+ * first (musicdata.py:88), letting callers pass overlapping windows of one waveform
+ * (seg_stride = hop) instead of a materialised unfold. */
+int pfann_melspec(pfann_ctx *ctx, const float *segs_dev, int64_t B, int64_t seg_stride,
+                  int remove_mean, float *out_dev, void *stream);
+
+/* FpNetwork.forward(x, norm): mel_dev[B][n_mels][T] -> emb_dev[B][d]. */
+int pfann_encode(pfann_ctx *ctx, const float *mel_dev, int64_t B, float *emb_dev,
+                 int normalize, void *stream);
+
+/* Fused segmenter tail + MelSpec + FpNetwork: B windows of wav_dev at stride seg_stride. */
+int pfann_segment_embed(pfann_ctx *ctx, const float *wav_dev, int64_t B, int64_t seg_stride,
+                        float *emb_dev, int normalize, void *stream);
+
+/* int16 interleaved PCM -> float32 mono (x/32768, fake-stereo fix, channel mean). */
+int pfann_pcm16_to_mono(pfann_ctx *ctx, const int16_t *pcm_dev, int64_t n_frames, int n_ch,
+                        float *wav_dev, void *stream);
+
+/* Debug/verification taps: copy the activation after sub-layer `idx` (0..15) of the LAST
+ * pfann_encode call's first `B` samples to host as NCHW floats.  Returns numel or <0. */
+int64_t pfann_debug_activation(pfann_ctx *ctx, int idx, int64_t B, float *host, int64_t cap);
+/* Enable keeping those taps (costs one D2D copy per sub-layer; off by default). */
+void pfann_debug_keep(pfann_ctx *ctx, int on);
+
+/* ---- database: device-resident fingerprints, exact search, sequence match ------------ */
+typedef struct pfann_db pfann_db;
+
+pfann_db *pfann_db_create(int d, int device);
+void pfann_db_destroy(pfann_db *db);
+int pfann_db_dim(pfann_db *db);
+int64_t pfann_db_ntotal(pfann_db *db);
+
+/* Loads rows emb[n][d] (host pointer if emb_is_device==0, else device pointer; copied) and
+ * the int64 prefix sums song_pos_host[n_songs+1] (database.py:84-86).  `label_base` is
+ * added to every label this shard reports (song-sharded multi-GPU: global row id of local
+ * row 0); song_pos stays GLOBAL and the shard must start and end on song boundaries. */
+int pfann_db_load(pfann_db *db, const float *emb, int emb_is_device, int64_t n,
+                  const int64_t *song_pos_host, int n_songs, int64_t label_base);
+
+/* Exact inner-product top-k of q_dev[nq][d] over the shard: D_dev[nq][k] descending,
+ * I_dev[nq][k] int64 labels (+label_base); unfilled slots D=-FLT_MAX, I=-1. */
+int pfann_search_topk(pfann_db *db, const float *q_dev, int64_t nq, int k, float *D_dev,
+                      int64_t *I_dev, void *stream);
+
+/* Exact top-k of arbitrary (score,label) lists: in[nq][m] -> out[nq][k] (merging per-shard
+ * top-k lists after an all-gather).  Entries with label<0 are ignored. */
+int pfann_topk_merge(pfann_db *db, const float *S_dev, const int64_t *L_dev, int64_t nq, int m,
+                     int k, float *D_dev, int64_t *I_dev, void *stream);
+
+/* Result of the sequence matcher for one query. */
+typedef struct pfann_match_result {
+    int32_t song;        /* best song id (global), -1 if no candidate                     */
+    int32_t offset;      /* best offset in sub-query frames (t), python path              */
+    int32_t shift;       /* frame shift of the best candidate                             */
+    int32_t n_cand;      /* unique candidates scored                                       */
+    double  score;       /* python path: fp32 dot / sub_len in double (database.py:157)   */
+} pfann_match_result;
+
+/* Candidate generation + sequence score + argmax for nQ queries at once, given labels.
+ * Query j owns rows [qstart[j], qstart[j]+qlen[j]) of q_dev / labels_dev[.][k].
+ * mode 0 = python path (database.py:129-163), mode 1 = native path (seqscore.cpp:49-135,
+ * fp32 divide, offsets t*fsm-shift, score_alpha honoured).
+ * results_dev[nQ]; song_scores_dev[nQ][n_songs][2] may be NULL; when given it must be
+ * zeroed by the caller and receives (score, offset-in-frames) of songs owned by the shard.
+ * only_owned=1 restricts candidates to songs of this shard (multi-GPU rerank).
+ * max_qlen = largest qlen[j] (sizes the LDS candidate buffer: max_qlen*k <= 8192);
+ * a query that exceeds it gets song=-2. */
+int pfann_match(pfann_db *db, const float *q_dev, const int64_t *labels_dev, int k,
+                const int64_t *qstart_dev, const int32_t *qlen_dev, int64_t nQ, int max_qlen,
+                int frame_shift_mul, float score_alpha, int mode, int only_owned,
+                pfann_match_result *results_dev, float *song_scores_dev, void *stream);
+
+/* Bytes of the shard's fingerprint matrix (for roofline accounting). */
+int64_t pfann_db_bytes(pfann_db *db);
+
+/* Timing hooks for bench.py: HIP events on the caller's stream around a tagged region.
+ * With profiling enabled every kernel launch is bracketed by an event pair tagged with
+ * the kernel's name ("conv_gemm", "scan_topk", "ln_act", ...); pfann_prof_elapsed_ms sums
+ * all completed brackets of that tag since pfann_prof_reset, returning their count in *count. */
+void pfann_prof_enable(int on);
+void pfann_prof_reset(void);
+double pfann_prof_elapsed_ms(const char *tag, int64_t *count);
+/* Comma-separated tags recorded since the last reset; returns their number or -1. */
+int pfann_prof_tags(char *out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFANN_AMD_H */

@@ -1,0 +1,545 @@
+// C-ABI of libpfann_amd.so (include/pfann_amd.h): handles, weight re-layout, workspaces,
+// per-kernel HIP-event profiling and the reference's native seam (version / seq_score).
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+
+#include "kernels.h"
+
+namespace pfann {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---- profiling ------------------------------------------------------------------------
+struct ProfRec { std::string tag; hipEvent_t e0, e1; };
+static bool g_prof = false;
+static std::vector<ProfRec> g_recs;
+static std::vector<hipEvent_t> g_pool;
+static hipEvent_t g_pending = nullptr;
+bool prof_on() { return g_prof; }
+static hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void prof_begin(const char *, hipStream_t s) {
+    g_pending = get_event();
+    (void)hipEventRecord(g_pending, s);
+}
+void prof_end(const char *tag, hipStream_t s) {
+    hipEvent_t e1 = get_event();
+    (void)hipEventRecord(e1, s);
+    g_recs.push_back({tag, g_pending, e1});
+    g_pending = nullptr;
+}
+
+}  // namespace pfann
+
+using namespace pfann;
+
+// =========================================================================================
+// encoder context
+// =========================================================================================
+struct pfann_ctx {
+    pfann_config cfg;
+    int device;
+    MelPlan mel;
+    bool mel_ready = false;
+    int F, T;                       // encoder input dims (n_mels, n_frames)
+    SubLayer sub[16];
+    float *g_w1 = nullptr, *g_b1 = nullptr, *g_w2 = nullptr, *g_b2 = nullptr;
+    std::map<std::string, bool> loaded;
+    int n_expected = 0;
+    float *buf[2] = {nullptr, nullptr};
+    int64_t buf_elems[2] = {0, 0};  // per sample
+    float *mel_buf = nullptr;
+    double *scratch = nullptr;
+    bool keep = false;
+    int64_t keep_B = 0;
+    float *dbg[16] = {};
+    float *dbg_tmp = nullptr;
+    int64_t dbg_cap = 0;
+};
+
+static int build_plan(pfann_ctx *c) {
+    const pfann_config &g = c->cfg;
+    const int ch[9] = {1, g.d, g.d, 2 * g.d, 2 * g.d, 4 * g.d, 4 * g.d, g.h, g.h};
+    int F = c->F, T = c->T;
+    for (int i = 0; i < 8; ++i) {
+        const int st = g.stride_t[i] > 0 ? g.stride_t[i] : 2;
+        const int sf = g.stride_f[i] > 0 ? g.stride_f[i] : 2;
+        const int p1 = (T - 1) / st * st + 3 - T, p2 = (F - 1) / sf * sf + 3 - F;
+        const int T1 = (T - 1) / st + 1, F2 = (F - 1) / sf + 1;
+        SubLayer &a = c->sub[2 * i], &b = c->sub[2 * i + 1];
+        a = SubLayer{};
+        b = SubLayer{};
+        a.ci = ch[i]; a.co = ch[i + 1]; a.F = F; a.T = T; a.Fo = F; a.To = T1;
+        a.axis = 0; a.stride = st; a.pad_lo = p1 / 2; a.depthwise = 0;
+        b.ci = ch[i + 1]; b.co = ch[i + 1]; b.F = F; b.T = T1; b.Fo = F2; b.To = T1;
+        b.axis = 1; b.stride = sf; b.pad_lo = p2 / 2; b.depthwise = g.fuller ? 0 : 1;
+        F = F2; T = T1;
+    }
+    if (F != 1 || T != 1) { set_error("encoder output must be 1x1, got %dx%d", F, T); return -1; }
+    if (g.h % g.d != 0) { set_error("h must be divisible by d"); return -1; }
+    if (g.d % 4 != 0) { set_error("d must be a multiple of 4"); return -1; }
+    return 0;
+}
+
+static int upload(float **dst, const float *src, size_t n) {
+    if (*dst == nullptr) PF_HIP(hipMalloc(dst, n * sizeof(float)));
+    PF_HIP(hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" {
+
+long long version(void) { return PFANN_SEQSCORE_VERSION; }
+
+const char *pfann_last_error(void) { return g_err; }
+
+pfann_ctx *pfann_create(const pfann_config *cfg, int device) {
+    if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice(%d) failed: no usable GPU", device); return nullptr; }
+    pfann_ctx *c = new pfann_ctx();
+    c->cfg = *cfg;
+    c->device = device;
+    if (c->cfg.max_batch <= 0) c->cfg.max_batch = 512;
+    const int n_fft = cfg->stft_n;
+    int log2n = 0;
+    while ((1 << log2n) < n_fft) ++log2n;
+    if ((1 << log2n) != n_fft || n_fft < 64 || n_fft > 4096) { set_error("stft_n must be a power of two in 64..4096"); delete c; return nullptr; }
+    if (cfg->n_mels % 1 != 0 || cfg->n_mels <= 0) { set_error("bad n_mels"); delete c; return nullptr; }
+    MelPlan &m = c->mel;
+    memset(&m, 0, sizeof(m));
+    m.seg_len = cfg->segment_len; m.n_fft = n_fft; m.hop = cfg->stft_hop; m.n_mels = cfg->n_mels;
+    m.n_frames = 1 + cfg->segment_len / cfg->stft_hop;
+    m.n_freqs = n_fft / 2 + 1; m.log2n = log2n;
+    m.power = cfg->power; m.pad_reflect = cfg->pad_reflect; m.log_mode = cfg->log_mode;
+    m.spec_norm_max = cfg->spec_norm_max; m.log_eps = cfg->log_eps;
+    if (m.pad_reflect && n_fft / 2 >= cfg->segment_len) { set_error("reflect padding needs stft_n/2 < segment_len"); delete c; return nullptr; }
+    // periodic hann window and twiddles, computed in double on the host
+    std::vector<float> win(n_fft);
+    std::vector<float2> tw(n_fft / 2);
+    for (int n = 0; n < n_fft; ++n) win[n] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * n / n_fft));
+    for (int j = 0; j < n_fft / 2; ++j) {
+        tw[j].x = (float)cos(-2.0 * M_PI * j / n_fft);
+        tw[j].y = (float)sin(-2.0 * M_PI * j / n_fft);
+    }
+    if (hipMalloc(&m.window, n_fft * sizeof(float)) != hipSuccess ||
+        hipMalloc(&m.twiddle, (n_fft / 2) * sizeof(float2)) != hipSuccess) { set_error("hipMalloc failed"); delete c; return nullptr; }
+    (void)hipMemcpy(m.window, win.data(), n_fft * sizeof(float), hipMemcpyHostToDevice);
+    (void)hipMemcpy(m.twiddle, tw.data(), (n_fft / 2) * sizeof(float2), hipMemcpyHostToDevice);
+    c->F = cfg->n_mels;
+    c->T = m.n_frames;
+    if (build_plan(c)) { delete c; return nullptr; }
+    c->n_expected = 8 * 8 + 4;
+    // workspaces: ping-pong activation buffers (even sub-layers -> buf[0], odd -> buf[1])
+    for (int i = 0; i < 16; ++i) {
+        const int64_t e = (int64_t)c->sub[i].co * c->sub[i].Fo * c->sub[i].To;
+        c->buf_elems[i & 1] = std::max(c->buf_elems[i & 1], e);
+    }
+    if (hipMalloc(&c->scratch, 16 * sizeof(double)) != hipSuccess) {
+        set_error("hipMalloc failed");
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+void pfann_destroy(pfann_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < 16; ++i) {
+        if (c->sub[i].w) (void)hipFree(c->sub[i].w);
+        if (c->sub[i].bias) (void)hipFree(c->sub[i].bias);
+        if (c->sub[i].ln_w) (void)hipFree(c->sub[i].ln_w);
+        if (c->sub[i].ln_b) (void)hipFree(c->sub[i].ln_b);
+        if (c->dbg[i]) (void)hipFree(c->dbg[i]);
+    }
+    float *ptrs[] = {c->g_w1, c->g_b1, c->g_w2, c->g_b2, c->buf[0], c->buf[1], c->mel_buf, c->mel.window,
+                     c->mel.fb_val, c->dbg_tmp};
+    for (float *p : ptrs) if (p) (void)hipFree(p);
+    if (c->mel.twiddle) (void)hipFree(c->mel.twiddle);
+    if (c->mel.fb_ptr) (void)hipFree(c->mel.fb_ptr);
+    if (c->mel.fb_idx) (void)hipFree(c->mel.fb_idx);
+    if (c->scratch) (void)hipFree(c->scratch);
+    delete c;
+}
+
+int pfann_set_melbank(pfann_ctx *c, const float *fb, int n_freqs, int n_mels) {
+    if (n_freqs != c->mel.n_freqs || n_mels != c->mel.n_mels) {
+        set_error("melbank shape [%d,%d] != [%d,%d]", n_freqs, n_mels, c->mel.n_freqs, c->mel.n_mels);
+        return -3;
+    }
+    PF_HIP(hipSetDevice(c->device));
+    std::vector<int> ptr(n_mels + 1, 0), idx;
+    std::vector<float> val;
+    int mx = 0;
+    for (int m = 0; m < n_mels; ++m) {
+        for (int k = 0; k < n_freqs; ++k) {
+            const float v = fb[(size_t)k * n_mels + m];
+            if (v != 0.0f) { idx.push_back(k); val.push_back(v); }
+        }
+        ptr[m + 1] = (int)idx.size();
+        mx = std::max(mx, ptr[m + 1] - ptr[m]);
+    }
+    if (idx.empty()) { idx.push_back(0); val.push_back(0.f); }
+    MelPlan &mp = c->mel;
+    if (mp.fb_ptr) { (void)hipFree(mp.fb_ptr); (void)hipFree(mp.fb_idx); (void)hipFree(mp.fb_val); }
+    PF_HIP(hipMalloc(&mp.fb_ptr, ptr.size() * sizeof(int)));
+    PF_HIP(hipMalloc(&mp.fb_idx, idx.size() * sizeof(int)));
+    PF_HIP(hipMalloc(&mp.fb_val, val.size() * sizeof(float)));
+    PF_HIP(hipMemcpy(mp.fb_ptr, ptr.data(), ptr.size() * sizeof(int), hipMemcpyHostToDevice));
+    PF_HIP(hipMemcpy(mp.fb_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
+    PF_HIP(hipMemcpy(mp.fb_val, val.data(), val.size() * sizeof(float), hipMemcpyHostToDevice));
+    mp.max_nnz_row = mx;
+    c->mel_ready = true;
+    return 0;
+}
+
+int pfann_load_weight(pfann_ctx *c, const char *name, const float *host, int64_t numel) {
+    PF_HIP(hipSetDevice(c->device));
+    const pfann_config &g = c->cfg;
+    int blk = -1;
+    char mod[16] = "", kind[16] = "";
+    if (sscanf(name, "f.convs.%d.%15[a-z0-9].%15s", &blk, mod, kind) == 3 && blk >= 0 && blk < 8) {
+        const bool second = mod[strlen(mod) - 1] == '2';
+        SubLayer &L = c->sub[2 * blk + (second ? 1 : 0)];
+        const bool is_w = strcmp(kind, "weight") == 0;
+        if (!is_w && strcmp(kind, "bias") != 0) { set_error("unknown tensor %s", name); return -2; }
+        if (strncmp(mod, "conv", 4) == 0) {
+            if (!is_w) {
+                if (numel != L.co) { set_error("%s: numel %lld != %d", name, (long long)numel, L.co); return -3; }
+                if (upload(&L.bias, host, numel)) return -1;
+            } else {
+                const int ci = L.depthwise ? 1 : L.ci;
+                if (numel != (int64_t)L.co * ci * 3) { set_error("%s: numel %lld != %lld", name, (long long)numel, (long long)L.co * ci * 3); return -3; }
+                std::vector<float> w((size_t)numel);
+                if (ci == 1) {          // [co][1][3] -> [3][co]
+                    for (int o = 0; o < L.co; ++o)
+                        for (int t = 0; t < 3; ++t) w[(size_t)t * L.co + o] = host[(size_t)o * 3 + t];
+                } else {                // [co][ci][3] -> [co][3][ci]
+                    for (int o = 0; o < L.co; ++o)
+                        for (int i = 0; i < ci; ++i)
+                            for (int t = 0; t < 3; ++t)
+                                w[((size_t)o * 3 + t) * ci + i] = host[((size_t)o * ci + i) * 3 + t];
+                }
+                if (upload(&L.w, w.data(), numel)) return -1;
+            }
+        } else if (strncmp(mod, "ln", 2) == 0) {
+            const int64_t hw = (int64_t)L.Fo * L.To;
+            if (numel != L.co * hw) { set_error("%s: numel %lld != %lld", name, (long long)numel, (long long)(L.co * hw)); return -3; }
+            std::vector<float> w((size_t)numel);   // [co][Fo][To] -> [Fo][To][co]
+            for (int o = 0; o < L.co; ++o)
+                for (int64_t p = 0; p < hw; ++p) w[(size_t)p * L.co + o] = host[(size_t)o * hw + p];
+            if (upload(is_w ? &L.ln_w : &L.ln_b, w.data(), numel)) return -1;
+        } else {
+            set_error("unknown tensor %s", name);
+            return -2;
+        }
+    } else if (strncmp(name, "g.linear", 8) == 0) {
+        const int v = g.h / g.d;
+        float **dst = nullptr;
+        int64_t want = 0;
+        if (!strcmp(name, "g.linear1.weight")) { dst = &c->g_w1; want = (int64_t)g.d * g.u * v; }
+        else if (!strcmp(name, "g.linear1.bias")) { dst = &c->g_b1; want = (int64_t)g.d * g.u; }
+        else if (!strcmp(name, "g.linear2.weight")) { dst = &c->g_w2; want = (int64_t)g.d * g.u; }
+        else if (!strcmp(name, "g.linear2.bias")) { dst = &c->g_b2; want = g.d; }
+        else { set_error("unknown tensor %s", name); return -2; }
+        if (numel != want) { set_error("%s: numel %lld != %lld", name, (long long)numel, (long long)want); return -3; }
+        if (upload(dst, host, numel)) return -1;
+    } else {
+        set_error("unknown tensor %s", name);
+        return -2;
+    }
+    c->loaded[name] = true;
+    return 0;
+}
+
+int pfann_weights_missing(pfann_ctx *c) { return c->n_expected - (int)c->loaded.size(); }
+
+int pfann_melspec(pfann_ctx *c, const float *segs, int64_t B, int64_t seg_stride, int remove_mean, float *out,
+                  void *stream) {
+    PF_HIP(hipSetDevice(c->device));
+    if (!c->mel_ready) { set_error("pfann_melspec: mel filterbank not set"); return -5; }
+    return launch_melspec(c->mel, segs, B, seg_stride, remove_mean, out, (hipStream_t)stream);
+}
+
+static int keep_tap(pfann_ctx *c, int idx, const float *act, int64_t B, hipStream_t s) {
+    const SubLayer &L = c->sub[idx];
+    const int64_t e = (int64_t)L.co * L.Fo * L.To;
+    const int64_t nb = std::min<int64_t>(B, 8);
+    if (!c->dbg[idx]) PF_HIP(hipMalloc(&c->dbg[idx], 8 * e * sizeof(float)));
+    PF_HIP(hipMemcpyAsync(c->dbg[idx], act, nb * e * sizeof(float), hipMemcpyDeviceToDevice, s));
+    c->keep_B = nb;
+    return 0;
+}
+
+// activation / mel workspaces are allocated on first use (a mel-only context stays small)
+static int ensure_workspace(pfann_ctx *c, bool need_mel) {
+    const int64_t mb = c->cfg.max_batch;
+    if (!c->buf[0]) {
+        PF_HIP(hipMalloc(&c->buf[0], mb * c->buf_elems[0] * sizeof(float)));
+        PF_HIP(hipMalloc(&c->buf[1], mb * c->buf_elems[1] * sizeof(float)));
+    }
+    if (need_mel && !c->mel_buf) PF_HIP(hipMalloc(&c->mel_buf, mb * (int64_t)c->F * c->T * sizeof(float)));
+    return 0;
+}
+
+static int encode_chunk(pfann_ctx *c, const float *mel, int64_t B, float *emb, int normalize, hipStream_t s) {
+    const float *x = mel;
+    for (int i = 0; i < 16; ++i) {
+        const SubLayer &L = c->sub[i];
+        float *y = c->buf[i & 1];
+        int rc;
+        if (L.ci == 1 && !L.depthwise) rc = launch_conv_first(L, x, y, B, s);
+        else if (L.depthwise) rc = launch_conv_depthwise(L, x, y, B, s);
+        else rc = launch_conv_gemm(L, x, y, B, s);
+        if (rc) return rc;
+        if (launch_ln_act(L, y, B, c->cfg.activation, c->cfg.relu_after_bn, s)) return -1;
+        if (c->keep && keep_tap(c, i, y, B, s)) return -1;
+        x = y;
+    }
+    const pfann_config &g = c->cfg;
+    return launch_myg(x, c->g_w1, c->g_b1, c->g_w2, c->g_b2, g.d, g.u, g.h / g.d, B, emb, normalize, s);
+}
+
+int pfann_encode(pfann_ctx *c, const float *mel, int64_t B, float *emb, int normalize, void *stream) {
+    PF_HIP(hipSetDevice(c->device));
+    if (pfann_weights_missing(c) != 0) { set_error("pfann_encode: %d state_dict tensors not loaded", pfann_weights_missing(c)); return -5; }
+    hipStream_t s = (hipStream_t)stream;
+    if (ensure_workspace(c, false)) return -1;
+    const int64_t per = (int64_t)c->F * c->T;
+    for (int64_t b0 = 0; b0 < B; b0 += c->cfg.max_batch) {
+        const int64_t nb = std::min<int64_t>(c->cfg.max_batch, B - b0);
+        if (encode_chunk(c, mel + b0 * per, nb, emb + b0 * c->cfg.d, normalize, s)) return -1;
+    }
+    return 0;
+}
+
+int pfann_segment_embed(pfann_ctx *c, const float *wav, int64_t B, int64_t seg_stride, float *emb, int normalize,
+                        void *stream) {
+    PF_HIP(hipSetDevice(c->device));
+    if (!c->mel_ready) { set_error("pfann_segment_embed: mel filterbank not set"); return -5; }
+    if (pfann_weights_missing(c) != 0) { set_error("pfann_segment_embed: %d state_dict tensors not loaded", pfann_weights_missing(c)); return -5; }
+    hipStream_t s = (hipStream_t)stream;
+    if (ensure_workspace(c, true)) return -1;
+    for (int64_t b0 = 0; b0 < B; b0 += c->cfg.max_batch) {
+        const int64_t nb = std::min<int64_t>(c->cfg.max_batch, B - b0);
+        if (launch_melspec(c->mel, wav + b0 * seg_stride, nb, seg_stride, 1, c->mel_buf, s)) return -1;
+        if (encode_chunk(c, c->mel_buf, nb, emb + b0 * c->cfg.d, normalize, s)) return -1;
+    }
+    return 0;
+}
+
+int pfann_pcm16_to_mono(pfann_ctx *c, const int16_t *pcm, int64_t n_frames, int n_ch, float *wav, void *stream) {
+    PF_HIP(hipSetDevice(c->device));
+    if (n_ch < 1) { set_error("n_ch < 1"); return -1; }
+    return launch_pcm16_to_mono(pcm, n_frames, n_ch, wav, reinterpret_cast<float *>(c->scratch), (hipStream_t)stream);
+}
+
+void pfann_debug_keep(pfann_ctx *c, int on) { c->keep = on != 0; }
+
+int64_t pfann_debug_activation(pfann_ctx *c, int idx, int64_t B, float *host, int64_t cap) {
+    if (idx < 0 || idx > 15 || !c->dbg[idx]) { set_error("no tap %d (call pfann_debug_keep(ctx,1) before encoding)", idx); return -1; }
+    if (hipSetDevice(c->device) != hipSuccess) return -1;
+    const SubLayer &L = c->sub[idx];
+    const int64_t e = (int64_t)L.co * L.Fo * L.To;
+    B = std::min(B, c->keep_B);
+    if (B * e > cap) { set_error("tap buffer too small"); return -1; }
+    if (c->dbg_cap < B * e) {
+        if (c->dbg_tmp) (void)hipFree(c->dbg_tmp);
+        if (hipMalloc(&c->dbg_tmp, B * e * sizeof(float)) != hipSuccess) return -1;
+        c->dbg_cap = B * e;
+    }
+    if (launch_cl_to_nchw(c->dbg[idx], c->dbg_tmp, B, L.co, L.Fo * L.To, 0)) return -1;
+    if (hipMemcpy(host, c->dbg_tmp, B * e * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return B * e;
+}
+
+}  // extern "C"
+
+// =========================================================================================
+// database shard
+// =========================================================================================
+struct pfann_db {
+    int d, device;
+    int64_t n = 0, label_base = 0;
+    float *emb = nullptr;
+    int64_t *song_pos = nullptr;
+    std::vector<int64_t> song_pos_h;
+    int n_songs = 0, song_lo = 0, song_hi = 0;
+    SearchWorkspace ws;
+};
+
+extern "C" {
+
+pfann_db *pfann_db_create(int d, int device) {
+    if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice(%d) failed: no usable GPU", device); return nullptr; }
+    pfann_db *db = new pfann_db();
+    db->d = d;
+    db->device = device;
+    return db;
+}
+
+void pfann_db_destroy(pfann_db *db) {
+    if (!db) return;
+    (void)hipSetDevice(db->device);
+    (void)hipDeviceSynchronize();
+    if (db->emb) (void)hipFree(db->emb);
+    if (db->song_pos) (void)hipFree(db->song_pos);
+    if (db->ws.thr) { (void)hipFree(db->ws.thr); (void)hipFree(db->ws.cnt); (void)hipFree(db->ws.cl); }
+    if (db->ws.overflow) (void)hipFree(db->ws.overflow);
+    delete db;
+}
+
+int pfann_db_dim(pfann_db *db) { return db->d; }
+int64_t pfann_db_ntotal(pfann_db *db) { return db->n; }
+int64_t pfann_db_bytes(pfann_db *db) { return db->n * db->d * (int64_t)sizeof(float); }
+
+int pfann_db_load(pfann_db *db, const float *emb, int emb_is_device, int64_t n, const int64_t *song_pos,
+                  int n_songs, int64_t label_base) {
+    PF_HIP(hipSetDevice(db->device));
+    if (db->emb) { (void)hipFree(db->emb); db->emb = nullptr; }
+    if (db->song_pos) { (void)hipFree(db->song_pos); db->song_pos = nullptr; }
+    db->n = n;
+    db->label_base = label_base;
+    db->n_songs = n_songs;
+    if (n > 0) {
+        PF_HIP(hipMalloc(&db->emb, (size_t)n * db->d * sizeof(float)));
+        PF_HIP(hipMemcpy(db->emb, emb, (size_t)n * db->d * sizeof(float),
+                         emb_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    }
+    db->song_pos_h.assign(song_pos, song_pos + n_songs + 1);
+    PF_HIP(hipMalloc(&db->song_pos, (size_t)(n_songs + 1) * sizeof(int64_t)));
+    PF_HIP(hipMemcpy(db->song_pos, song_pos, (size_t)(n_songs + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    // songs whose rows all live in [label_base, label_base + n)
+    int lo = 0;
+    while (lo < n_songs && song_pos[lo] < label_base) ++lo;
+    int hi = lo;
+    while (hi < n_songs && song_pos[hi + 1] <= label_base + n) ++hi;
+    db->song_lo = lo;
+    db->song_hi = hi;
+    if (n > 0 && (lo >= n_songs || song_pos[lo] != label_base || song_pos[hi] != label_base + n)) {
+        set_error("db_load: shard rows [%lld,%lld) do not align with song boundaries", (long long)label_base,
+                  (long long)(label_base + n));
+        return -3;
+    }
+    return 0;
+}
+
+int pfann_search_topk(pfann_db *db, const float *q, int64_t nq, int k, float *D, int64_t *I, void *stream) {
+    PF_HIP(hipSetDevice(db->device));
+    return search_topk(db->emb, db->n, db->d, db->label_base, q, nq, k, D, I, db->ws, (hipStream_t)stream);
+}
+
+int pfann_topk_merge(pfann_db *db, const float *S, const int64_t *L, int64_t nq, int m, int k, float *D,
+                     int64_t *I, void *stream) {
+    PF_HIP(hipSetDevice(db->device));
+    return topk_merge(S, L, nq, m, k, D, I, (hipStream_t)stream);
+}
+
+int pfann_match(pfann_db *db, const float *q, const int64_t *labels, int k, const int64_t *qstart,
+                const int32_t *qlen, int64_t nQ, int max_qlen, int frame_shift_mul, float score_alpha, int mode,
+                int only_owned, pfann_match_result *results, float *song_scores, void *stream) {
+    PF_HIP(hipSetDevice(db->device));
+    RerankArgs a;
+    a.db = db->emb; a.n = db->n; a.d = db->d; a.label_base = db->label_base;
+    a.song_pos = db->song_pos; a.n_songs = db->n_songs; a.song_lo = db->song_lo; a.song_hi = db->song_hi;
+    a.q = q; a.labels = labels; a.k = k; a.qstart = qstart; a.qlen = qlen; a.nQ = nQ;
+    a.fsm = frame_shift_mul; a.alpha = score_alpha; a.mode = mode; a.only_owned = only_owned;
+    int P = 1;
+    while (P < (int64_t)max_qlen * k) P <<= 1;
+    a.pmax = P;
+    a.results = results; a.song_scores = song_scores;
+    return launch_match(a, (hipStream_t)stream);
+}
+
+int seq_score(void *index, const int64_t *song_pos, int n_songs, const float *query, int query_len,
+              const int64_t *labels, int top_k, float *song_scores, int frame_shift_mul, float score_alpha) {
+    pfann_db *db = (pfann_db *)index;
+    if (!db) { set_error("seq_score: null index"); return -1; }
+    if (hipSetDevice(db->device) != hipSuccess) { set_error("seq_score: hipSetDevice failed"); return -1; }
+    if (n_songs != db->n_songs || memcmp(song_pos, db->song_pos_h.data(), sizeof(int64_t) * (n_songs + 1)) != 0) {
+        set_error("seq_score: song_pos differs from the one the database handle was loaded with");
+        return -1;
+    }
+    if (query_len <= 0) return -1;
+    float *dq = nullptr, *dss = nullptr;
+    int64_t *dl = nullptr, *dqs = nullptr;
+    int32_t *dql = nullptr;
+    pfann_match_result *dres = nullptr, res;
+    int rc = -1;
+    const size_t nq = (size_t)query_len;
+    const int64_t zero = 0;
+    const int32_t ql = query_len;
+    std::vector<float> ss((size_t)n_songs * 2);
+    if (hipMalloc(&dq, nq * db->d * sizeof(float)) != hipSuccess) goto done;
+    if (hipMalloc(&dl, nq * top_k * sizeof(int64_t)) != hipSuccess) goto done;
+    if (hipMalloc(&dss, (size_t)std::max(n_songs, 1) * 2 * sizeof(float)) != hipSuccess) goto done;
+    if (hipMalloc(&dqs, sizeof(int64_t)) != hipSuccess) goto done;
+    if (hipMalloc(&dql, sizeof(int32_t)) != hipSuccess) goto done;
+    if (hipMalloc(&dres, sizeof(pfann_match_result)) != hipSuccess) goto done;
+    (void)hipMemcpy(dq, query, nq * db->d * sizeof(float), hipMemcpyHostToDevice);
+    (void)hipMemcpy(dl, labels, nq * top_k * sizeof(int64_t), hipMemcpyHostToDevice);
+    (void)hipMemset(dss, 0, (size_t)std::max(n_songs, 1) * 2 * sizeof(float));
+    (void)hipMemcpy(dqs, &zero, sizeof(int64_t), hipMemcpyHostToDevice);
+    (void)hipMemcpy(dql, &ql, sizeof(int32_t), hipMemcpyHostToDevice);
+    if (pfann_match(db, dq, dl, top_k, dqs, dql, 1, query_len, frame_shift_mul, score_alpha, 1, 0, dres, dss,
+                    nullptr) != 0) goto done;
+    if (hipMemcpy(&res, dres, sizeof(res), hipMemcpyDeviceToHost) != hipSuccess) goto done;
+    if (hipMemcpy(ss.data(), dss, ss.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) goto done;
+    if (res.song == -2) { set_error("seq_score: query_len*top_k too large for the LDS candidate buffer"); goto done; }
+    for (int s = 0; s < n_songs; ++s)            // seqscore.cpp:126-133 against the caller's slots
+        if (ss[2 * s] > song_scores[2 * s]) { song_scores[2 * s] = ss[2 * s]; song_scores[2 * s + 1] = ss[2 * s + 1]; }
+    rc = res.song;
+done:
+    if (rc == -1 && g_err[0] == 0) set_error("seq_score: device allocation or copy failed");
+    if (dq) (void)hipFree(dq);
+    if (dl) (void)hipFree(dl);
+    if (dss) (void)hipFree(dss);
+    if (dqs) (void)hipFree(dqs);
+    if (dql) (void)hipFree(dql);
+    if (dres) (void)hipFree(dres);
+    return rc;
+}
+
+// ---- profiling ------------------------------------------------------------------------
+void pfann_prof_enable(int on) { g_prof = on != 0; }
+void pfann_prof_reset(void) {
+    for (auto &r : g_recs) { g_pool.push_back(r.e0); g_pool.push_back(r.e1); }
+    g_recs.clear();
+}
+double pfann_prof_elapsed_ms(const char *tag, int64_t *count) {
+    double tot = 0;
+    int64_t n = 0;
+    for (auto &r : g_recs) {
+        if (r.tag != tag) continue;
+        (void)hipEventSynchronize(r.e1);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { tot += ms; ++n; }
+    }
+    if (count) *count = n;
+    return tot;
+}
+int pfann_prof_tags(char *out, int cap) {
+    std::map<std::string, int> seen;
+    for (auto &r : g_recs) seen[r.tag]++;
+    std::string s;
+    for (auto &kv : seen) { if (!s.empty()) s += ","; s += kv.first; }
+    if ((int)s.size() + 1 > cap) return -1;
+    memcpy(out, s.c_str(), s.size() + 1);
+    return (int)seen.size();
+}
+
+}  // extern "C"

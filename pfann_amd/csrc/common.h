@@ -1,0 +1,68 @@
+// Internal helpers shared by the HIP translation units of libpfann_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/pfann_amd.h"
+
+namespace pfann {
+
+void set_error(const char *fmt, ...);
+
+#define PF_HIP(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            pfann::set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr,                 \
+                             hipGetErrorString(_e));                                      \
+            return -1;                                                                    \
+        }                                                                                 \
+    } while (0)
+
+// ---- per-kernel HIP-event profiling (bench.py roofline leg) -----------------------------
+bool prof_on();
+void prof_begin(const char *tag, hipStream_t s);
+void prof_end(const char *tag, hipStream_t s);
+
+struct ProfScope {
+    const char *tag; hipStream_t s; bool on;
+    ProfScope(const char *t, hipStream_t st) : tag(t), s(st), on(prof_on()) { if (on) prof_begin(tag, s); }
+    ~ProfScope() { if (on) prof_end(tag, s); }
+};
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- device helpers ---------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- encoder plan shared between api and kernels ---------------------------------------
+struct SubLayer {          // one conv (+LN+act) sub-layer, channels-last activations
+    int ci, co;            // input / output channels
+    int F, T;              // input spatial dims
+    int Fo, To;            // output spatial dims
+    int axis;              // 0: conv along T (conv1, 1x3), 1: conv along F (conv2, 3x1)
+    int stride, pad_lo;    // along the convolved axis
+    int depthwise;         // conv2 of non-"fuller" models
+    float *w;              // [co][3][ci] (full) or [co][3] (depthwise / ci==1)
+    float *bias;           // [co]
+    float *ln_w, *ln_b;    // [Fo][To][co]  (channels-last re-layout of [co][Fo][To])
+};
+
+}  // namespace pfann

@@ -1,0 +1,413 @@
+// Fingerprint encoder kernels for gfx950 (CDNA4): the 8 separable-conv blocks and the
+// grouped projection head of the reference's FpNetwork (model.py:14-153), re-designed as
+//   * channels-last activations  x[b][f][t][c]  (K = taps x channels is contiguous),
+//   * conv-as-implicit-GEMM on the exact-fp32 MFMA  v_mfma_f32_32x32x2_f32
+//     (bitwise an fmaf chain, so embeddings stay inside the 1e-4 parity budget),
+//   * LDS-staged 128x128x32 / 64x64x32 tiles read with ds_read_b128 (row pitch 36 dwords:
+//     conflict-free for the b128 lane groups), register-prefetched global loads,
+//   * XCD-aware block->tile mapping (blocks sharing an activation panel share an L2).
+#include "kernels.h"
+
+namespace pfann {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float act_fn(float v, int act) {
+    return act == 0 ? fmaxf(v, 0.0f) : (v > 0.0f ? v : expm1f(v));
+}
+
+// Bijective XCD remap: hardware places block b on XCD b%8; give each XCD a contiguous
+// chunk of the logical tile order.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + idx;
+}
+
+// ------------------------------------------------------------------------------------
+// Implicit-GEMM convolution:  y[m][n] = bias[n] + sum_{tap,c} x[row(m) + tap][c] * w[n][tap][c]
+// ------------------------------------------------------------------------------------
+struct GemmConvParams {
+    const float *x, *w, *bias;
+    float *y;
+    int64_t M;
+    int N, K, Ci;
+    int rows_per_sample, To, F, T;
+    int axis, stride, pad_lo, in_len;
+    int64_t tap_stride;
+    int n_tiles_n;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(GemmConvParams p) {
+    constexpr int BK = 32, LDK = BK + 4;
+    constexpr int WAVES_N = BN / WN;
+    static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int AR = BM / 32, BR = BN / 32;
+    __shared__ __attribute__((aligned(16))) float As[BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = L / p.n_tiles_n, nt = L - mt * p.n_tiles_n;
+    const int64_t m0 = (int64_t)mt * BM;
+    const int n0 = nt * BN;
+
+    const int col4 = tid & 7, rowq = tid >> 3;
+    // per-thread A row descriptors
+    int64_t abase[AR];
+    int ap0[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const int64_t m = m0 + rowq + 32 * i;
+        if (m < p.M) {
+            const int64_t b = m / p.rows_per_sample;
+            const int r = (int)(m - b * p.rows_per_sample);
+            const int fo = r / p.To, to = r - fo * p.To;
+            if (p.axis == 0) {
+                ap0[i] = to * p.stride - p.pad_lo;
+                abase[i] = ((b * p.F + fo) * (int64_t)p.T + ap0[i]) * p.Ci;
+            } else {
+                ap0[i] = fo * p.stride - p.pad_lo;
+                abase[i] = ((b * p.F + ap0[i]) * (int64_t)p.T + to) * p.Ci;
+            }
+        } else {
+            ap0[i] = -(1 << 20);  // never valid
+            abase[i] = 0;
+        }
+    }
+    // running (tap, c) of this thread's float4 inside the K dimension
+    int kap = col4 * 4;
+    int tap = kap / p.Ci, c = kap - tap * p.Ci;
+
+    f32x4 ra[AR], rb[BR];
+    auto load_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const bool ok = kap < p.K && (unsigned)(ap0[i] + tap) < (unsigned)p.in_len;
+            ra[i] = ok ? *reinterpret_cast<const f32x4 *>(p.x + abase[i] + tap * p.tap_stride + c)
+                       : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < BR; ++j) {
+            const int n = n0 + rowq + 32 * j;
+            const bool ok = kap < p.K && n < p.N;
+            rb[j] = ok ? *reinterpret_cast<const f32x4 *>(p.w + (int64_t)n * p.K + kap)
+                       : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        kap += BK;
+        c += BK;
+        while (c >= p.Ci) { c -= p.Ci; ++tap; }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < AR; ++i)
+            *reinterpret_cast<f32x4 *>(&As[(rowq + 32 * i) * LDK + col4 * 4]) = ra[i];
+#pragma unroll
+        for (int j = 0; j < BR; ++j)
+            *reinterpret_cast<f32x4 *>(&Bs[(rowq + 32 * j) * LDK + col4 * 4]) = rb[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tile();
+    store_tile();
+    __syncthreads();
+    const int l31 = lane & 31, lhalf = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_tile();
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            f32x4 a4[TM], b4[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a4[i] = *reinterpret_cast<const f32x4 *>(
+                    &As[(wm * WM + i * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b4[j] = *reinterpret_cast<const f32x4 *>(
+                    &Bs[(wn * WN + j * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][s], b4[j][s],
+                                                                         acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+    // epilogue: + bias, store.  C layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 32 + l31;
+        const float bv = n < p.N ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                if (m < p.M && n < p.N) p.y[m * p.N + n] = acc[i][j][r] + bv;
+            }
+        }
+    }
+}
+
+int launch_conv_gemm(const SubLayer &L, const float *x, float *y, int64_t B, hipStream_t s) {
+    GemmConvParams p;
+    p.x = x; p.w = L.w; p.bias = L.bias; p.y = y;
+    p.rows_per_sample = L.Fo * L.To;
+    p.M = B * p.rows_per_sample;
+    p.N = L.co; p.Ci = L.ci; p.K = 3 * L.ci;
+    p.To = L.To; p.F = L.F; p.T = L.T;
+    p.axis = L.axis; p.stride = L.stride; p.pad_lo = L.pad_lo;
+    p.in_len = L.axis == 0 ? L.T : L.F;
+    p.tap_stride = L.axis == 0 ? (int64_t)L.ci : (int64_t)L.T * L.ci;
+    if (L.ci % 4 != 0) { set_error("conv_gemm needs ci %% 4 == 0 (ci=%d)", L.ci); return -1; }
+    ProfScope ps("conv_gemm", s);
+    // tile choice: big tiles when the grid still fills 256 CUs a few times over
+    const int64_t blocks128 = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128);
+    if (p.N >= 128 && blocks128 >= 1024) {
+        p.n_tiles_n = cdiv(p.N, 128);
+        hipLaunchKernelGGL((conv_gemm_kernel<128, 128, 64, 64>), dim3((unsigned)blocks128), dim3(256),
+                           0, s, p);
+    } else {
+        p.n_tiles_n = cdiv(p.N, 64);
+        const int64_t blocks = (int64_t)cdiv(p.M, 64) * p.n_tiles_n;
+        hipLaunchKernelGGL((conv_gemm_kernel<64, 64, 32, 32>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    }
+    PF_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// First conv (ci == 1): x[b][f][t] -> y[b][f][to][co]; pure bandwidth (2 MiB written/sample).
+// w is stored [3][co].
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict__ x,
+                                                         const float *__restrict__ w,
+                                                         const float *__restrict__ bias,
+                                                         float *__restrict__ y, int64_t M, int co,
+                                                         int To, int T, int stride, int pad_lo) {
+    const int co4 = co >> 2;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= M * co4) return;
+    const int64_t m = gid / co4;
+    const int c = (int)(gid - m * co4) * 4;
+    const int64_t bf = m / To;           // (b*F + f)
+    const int to = (int)(m - bf * To);
+    const int p0 = to * stride - pad_lo;
+    f32x4 o = *reinterpret_cast<const f32x4 *>(bias + c);
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) {
+        const int t = p0 + tap;
+        if ((unsigned)t < (unsigned)T) {
+            const float xv = x[bf * T + t];
+            const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + tap * co + c);
+            o += xv * wv;
+        }
+    }
+    *reinterpret_cast<f32x4 *>(y + m * co + c) = o;
+}
+
+int launch_conv_first(const SubLayer &L, const float *x, float *y, int64_t B, hipStream_t s) {
+    const int64_t M = B * L.Fo * L.To;
+    const int64_t n = M * (L.co / 4);
+    ProfScope ps("conv_first", s);
+    hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, x, L.w, L.bias,
+                       y, M, L.co, L.To, L.T, L.stride, L.pad_lo);
+    PF_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// Depthwise 3x1 conv along F (conv2 of non-"fuller" models): w stored [3][co].
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_dw_kernel(const float *__restrict__ x,
+                                                      const float *__restrict__ w,
+                                                      const float *__restrict__ bias,
+                                                      float *__restrict__ y, int64_t M, int C, int Fo,
+                                                      int To, int F, int T, int axis, int stride,
+                                                      int pad_lo) {
+    const int c4n = C >> 2;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= M * c4n) return;
+    const int64_t m = gid / c4n;
+    const int c = (int)(gid - m * c4n) * 4;
+    const int rps = Fo * To;
+    const int64_t b = m / rps;
+    const int r = (int)(m - b * rps);
+    const int fo = r / To, to = r - fo * To;
+    f32x4 o = *reinterpret_cast<const f32x4 *>(bias + c);
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) {
+        int f = fo, t = to;
+        bool ok;
+        if (axis == 0) { t = to * stride - pad_lo + tap; ok = (unsigned)t < (unsigned)T; }
+        else { f = fo * stride - pad_lo + tap; ok = (unsigned)f < (unsigned)F; }
+        if (ok) {
+            const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + ((b * F + f) * (int64_t)T + t) * C + c);
+            const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + tap * C + c);
+            o += xv * wv;
+        }
+    }
+    *reinterpret_cast<f32x4 *>(y + m * C + c) = o;
+}
+
+int launch_conv_depthwise(const SubLayer &L, const float *x, float *y, int64_t B, hipStream_t s) {
+    const int64_t M = B * L.Fo * L.To;
+    const int64_t n = M * (L.co / 4);
+    ProfScope ps("conv_depthwise", s);
+    hipLaunchKernelGGL(conv_dw_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, x, L.w, L.bias, y, M,
+                       L.co, L.Fo, L.To, L.F, L.T, L.axis, L.stride, L.pad_lo);
+    PF_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// LayerNorm over the whole (C,F,T) sample + activation, in place, one block per sample.
+// model.py:58-72: relu_after_bn ? act(LN(x)) : LN(act(x)).  Statistics: per-thread fp32
+// partials, combined in fp64 (biased variance, eps 1e-5).
+// ------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(NT) void ln_act_kernel(float *__restrict__ xy, const float *__restrict__ w,
+                                                    const float *__restrict__ b, int n, int act,
+                                                    int after_bn) {
+    __shared__ double red[2][NT / 64];
+    __shared__ float stat[2];
+    float *x = xy + (int64_t)blockIdx.x * n;
+    const int tid = threadIdx.x, n4 = n >> 2;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = tid; i < n4; i += NT) {
+        f32x4 v = reinterpret_cast<const f32x4 *>(x)[i];
+        if (!after_bn) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_fn(v[e], act);
+        }
+        s1 += (v[0] + v[1]) + (v[2] + v[3]);
+        s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    double d1 = wave_sum_d((double)s1), d2 = wave_sum_d((double)s2);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = d1; red[1][tid >> 6] = d2; }
+    __syncthreads();
+    if (tid == 0) {
+        double t1 = 0, t2 = 0;
+        for (int i = 0; i < NT / 64; ++i) { t1 += red[0][i]; t2 += red[1][i]; }
+        const double mean = t1 / n;
+        double var = t2 / n - mean * mean;
+        if (var < 0) var = 0;
+        stat[0] = (float)mean;
+        stat[1] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+    __syncthreads();
+    const float mean = stat[0], rstd = stat[1];
+    for (int i = tid; i < n4; i += NT) {
+        f32x4 v = reinterpret_cast<const f32x4 *>(x)[i];
+        const f32x4 wv = reinterpret_cast<const f32x4 *>(w)[i];
+        const f32x4 bv = reinterpret_cast<const f32x4 *>(b)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = after_bn ? v[e] : act_fn(v[e], act);
+            t = (t - mean) * rstd * wv[e] + bv[e];
+            v[e] = after_bn ? act_fn(t, act) : t;
+        }
+        reinterpret_cast<f32x4 *>(x)[i] = v;
+    }
+}
+
+int launch_ln_act(const SubLayer &L, float *xy, int64_t B, int activation, int relu_after_bn,
+                  hipStream_t s) {
+    const int n = L.co * L.Fo * L.To;
+    ProfScope ps("ln_act", s);
+    if (n >= 65536)
+        hipLaunchKernelGGL((ln_act_kernel<1024>), dim3((unsigned)B), dim3(1024), 0, s, xy, L.ln_w, L.ln_b, n,
+                           activation, relu_after_bn);
+    else
+        hipLaunchKernelGGL((ln_act_kernel<256>), dim3((unsigned)B), dim3(256), 0, s, xy, L.ln_w, L.ln_b, n,
+                           activation, relu_after_bn);
+    PF_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// Projection head MyG (model.py:122-130): d groups x (v -> u, ELU, u -> 1), then optional
+// L2 normalise  y / max(||y||, 1e-12).  One block per sample, one thread per group.
+// ------------------------------------------------------------------------------------
+__global__ void myg_kernel(const float *__restrict__ x, const float *__restrict__ w1,
+                           const float *__restrict__ b1, const float *__restrict__ w2,
+                           const float *__restrict__ b2, int d, int u, int v, float *__restrict__ emb,
+                           int normalize) {
+    __shared__ float red[16];
+    const int g = threadIdx.x;
+    const float *xs = x + (int64_t)blockIdx.x * d * v;
+    float y = 0.f;
+    if (g < d) {
+        float xin[32];
+        for (int j = 0; j < v; ++j) xin[j] = xs[g * v + j];
+        for (int k = 0; k < u; ++k) {
+            const float *wr = w1 + ((int64_t)g * u + k) * v;
+            float hsum = 0.f;
+            for (int j = 0; j < v; ++j) hsum = fmaf(wr[j], xin[j], hsum);
+            hsum += b1[g * u + k];
+            hsum = hsum > 0.f ? hsum : expm1f(hsum);
+            y = fmaf(w2[g * u + k], hsum, y);
+        }
+        y += b2[g];
+    }
+    if (normalize) {
+        float ss = wave_sum(g < d ? y * y : 0.f);
+        if ((g & 63) == 0) red[g >> 6] = ss;
+        __syncthreads();
+        float tot = 0.f;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) tot += red[i];
+        y = y / fmaxf(sqrtf(tot), 1e-12f);
+    }
+    if (g < d) emb[(int64_t)blockIdx.x * d + g] = y;
+}
+
+int launch_myg(const float *x, const float *w1, const float *b1, const float *w2, const float *b2,
+               int d, int u, int v, int64_t B, float *emb, int normalize, hipStream_t s) {
+    if (v > 32) { set_error("MyG: h/d = %d > 32 unsupported", v); return -1; }
+    const int nt = ((d + 63) / 64) * 64;
+    if (nt > 1024) { set_error("MyG: d = %d > 1024 unsupported", d); return -1; }
+    ProfScope ps("myg", s);
+    hipLaunchKernelGGL(myg_kernel, dim3((unsigned)B), dim3(nt), 0, s, x, w1, b1, w2, b2, d, u, v, emb,
+                       normalize);
+    PF_HIP(hipGetLastError());
+    return 0;
+}
+
+// channels-last [B][HW][C] -> NCHW [B][C][HW] (verification taps only)
+__global__ void cl_to_nchw_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t total, int C,
+                                  int HW) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t b = i / ((int64_t)C * HW);
+    const int r = (int)(i - b * C * HW);
+    const int c = r / HW, hw = r - c * HW;
+    y[i] = x[(b * HW + hw) * C + c];
+}
+int launch_cl_to_nchw(const float *x, float *y, int64_t B, int C, int HW, hipStream_t s) {
+    const int64_t total = B * C * HW;
+    hipLaunchKernelGGL(cl_to_nchw_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, x, y, total, C, HW);
+    PF_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace pfann

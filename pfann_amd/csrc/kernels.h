@@ -1,0 +1,61 @@
+// Host-side launchers of the HIP kernels (one translation unit per stage).
+#pragma once
+#include "common.h"
+
+namespace pfann {
+
+// ---- mel.hip -------------------------------------------------------------------------
+struct MelPlan {
+    int seg_len, n_fft, hop, n_mels, n_frames, n_freqs, log2n;
+    int power, pad_reflect, log_mode, spec_norm_max;
+    float log_eps;
+    float *window;        // [n_fft] periodic hann
+    float2 *twiddle;      // [n_fft/2] exp(-2*pi*i*j/n_fft)
+    int *fb_ptr;          // [n_mels+1] CSR over mel bins
+    int *fb_idx;          // [nnz] frequency bin
+    float *fb_val;        // [nnz]
+    int max_nnz_row;
+};
+int launch_melspec(const MelPlan &mp, const float *segs, int64_t B, int64_t seg_stride,
+                   int remove_mean, float *out, hipStream_t s);
+int launch_pcm16_to_mono(const int16_t *pcm, int64_t n_frames, int n_ch, float *wav,
+                         float *scratch2, hipStream_t s);
+
+// ---- encoder.hip ---------------------------------------------------------------------
+int launch_conv_first(const SubLayer &L, const float *x, float *y, int64_t B, hipStream_t s);
+int launch_conv_gemm(const SubLayer &L, const float *x, float *y, int64_t B, hipStream_t s);
+int launch_conv_depthwise(const SubLayer &L, const float *x, float *y, int64_t B, hipStream_t s);
+int launch_ln_act(const SubLayer &L, float *xy, int64_t B, int activation, int relu_after_bn,
+                  hipStream_t s);
+int launch_myg(const float *x, const float *w1, const float *b1, const float *w2, const float *b2,
+               int d, int u, int v, int64_t B, float *emb, int normalize, hipStream_t s);
+int launch_cl_to_nchw(const float *x, float *y, int64_t B, int C, int HW, hipStream_t s);
+
+// ---- search.hip ----------------------------------------------------------------------
+struct SearchWorkspace {
+    int64_t cap_q = 0;      // query rows the buffers are sized for
+    int cap_c = 0;          // candidate slots per query row
+    float *thr = nullptr;   // [cap_q]
+    int *cnt = nullptr;     // [cap_q]
+    float *cs = nullptr;    // [cap_q][cap_c]
+    int64_t *cl = nullptr;  // [cap_q][cap_c]
+    int *overflow = nullptr;
+};
+int search_topk(const float *db, int64_t n, int d, int64_t label_base, const float *q, int64_t nq,
+                int k, float *D, int64_t *I, SearchWorkspace &ws, hipStream_t s);
+int topk_merge(const float *S, const int64_t *L, int64_t nq, int m, int k, float *D, int64_t *I,
+               hipStream_t s);
+
+// ---- rerank.hip ----------------------------------------------------------------------
+struct RerankArgs {
+    const float *db; int64_t n; int d; int64_t label_base;
+    const int64_t *song_pos; int n_songs; int song_lo, song_hi;  // owned songs [lo,hi)
+    const float *q; const int64_t *labels; int k;
+    const int64_t *qstart; const int32_t *qlen; int64_t nQ;
+    int fsm; float alpha; int mode; int only_owned;
+    int pmax;               // next pow2 >= max_qlen * k (LDS sizing)
+    pfann_match_result *results; float *song_scores;
+};
+int launch_match(const RerankArgs &a, hipStream_t s);
+
+}  // namespace pfann

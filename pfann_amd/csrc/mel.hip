@@ -1,0 +1,232 @@
+// Front-end kernels for gfx950: segment mean-removal + L2/max normalise + STFT + |.|^p +
+// sparse mel filterbank + log, all in one kernel (reference datautil/musicdata.py:88 and
+// datautil/melspec.py:33-50 around torchaudio MelSpectrogram/torch.stft).
+//
+// One 256-thread workgroup per 1-second segment.  The segment is read from HBM/L2 with
+// coalesced loads (each sample is touched by 4 overlapping frames, served by L1/L2); each of
+// the 4 waves runs a 1024-point real FFT for one frame at a time as a 512-point complex
+// radix-2 FFT in LDS (SoA re/im, host-computed twiddles staged in LDS), the power spectrum
+// goes through the 0.7 %-dense mel bank as a CSR gather-MAC (never a dense GEMM), and the
+// [n_mels][n_frames] tile is assembled in LDS so the store to HBM is one coalesced stream.
+#include "kernels.h"
+
+namespace pfann {
+
+struct MelArgs {
+    const float *segs; float *out;
+    int64_t seg_stride;
+    int seg_len, n_fft, hop, n_mels, n_frames, log2n;
+    int power, pad_reflect, log_mode, spec_norm_max, remove_mean;
+    float log_eps;
+    const float *window; const float2 *twiddle;
+    const int *fb_ptr, *fb_idx; const float *fb_val;
+};
+
+__device__ __forceinline__ unsigned bitrev(unsigned x, int bits) { return __brev(x) >> (32 - bits); }
+
+__global__ __launch_bounds__(256) void melspec_kernel(MelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int M = a.n_fft >> 1;           // complex FFT length
+    const int log2m = a.log2n - 1;
+    const int n_freqs = M + 1;
+    // LDS carve-up
+    float *tw_re = smem;                  // [M]   exp(-2*pi*i*j/n_fft), j < M
+    float *tw_im = tw_re + M;             // [M]
+    float *fre = tw_im + M;               // [4][M]
+    float *fim = fre + 4 * M;             // [4][M]
+    float *pw = fim + 4 * M;              // [4][M+4]  power spectrum per wave
+    float *tile = pw + 4 * (M + 4);       // [n_mels][n_frames+1]
+    float *red = tile + a.n_mels * (a.n_frames + 1);  // [8]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *x = a.segs + (int64_t)blockIdx.x * a.seg_stride;
+
+    for (int j = tid; j < M; j += 256) { const float2 t = a.twiddle[j]; tw_re[j] = t.x; tw_im[j] = t.y; }
+
+    // ---- segment statistics: mean (optional), then L2 norm or max-abs of (x - mean)
+    float mean = 0.f;
+    if (a.remove_mean) {
+        float s = 0.f;
+        for (int i = tid; i < a.seg_len; i += 256) s += x[i];
+        s = wave_sum(s);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)a.seg_len;
+        __syncthreads();
+    }
+    float denom;
+    {
+        float s = 0.f;
+        if (a.spec_norm_max) {
+            for (int i = tid; i < a.seg_len; i += 256) s = fmaxf(s, fabsf(x[i] - mean));
+            s = wave_max(s);
+        } else {
+            for (int i = tid; i < a.seg_len; i += 256) { const float v = x[i] - mean; s = fmaf(v, v, s); }
+            s = wave_sum(s);
+        }
+        if (lane == 0) red[4 + wave] = s;
+        __syncthreads();
+        const float t = a.spec_norm_max ? fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]))
+                                        : sqrtf((red[4] + red[5]) + (red[6] + red[7]));
+        denom = fmaxf(t, 1e-12f);
+    }
+
+    float *zre = fre + wave * M, *zim = fim + wave * M, *pwr = pw + wave * (M + 4);
+    const int n_groups = (a.n_frames + 3) >> 2;
+    for (int g = 0; g < n_groups; ++g) {
+        const int t = g * 4 + wave;
+        const bool live = t < a.n_frames;
+        // ---- gather frame (reflect / zero padding), normalise, window; write bit-reversed
+        for (int m = lane; m < M; m += 64) {
+            float v[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int n = 2 * m + e;
+                int idx = t * a.hop - M + n;
+                float s = 0.f;
+                if (live) {
+                    if (a.pad_reflect) {
+                        if (idx < 0) idx = -idx;
+                        if (idx > a.seg_len - 1) idx = 2 * (a.seg_len - 1) - idx;
+                        s = (x[idx] - mean) / denom;
+                    } else if (idx >= 0 && idx < a.seg_len) {
+                        s = (x[idx] - mean) / denom;
+                    }
+                }
+                v[e] = s * a.window[n];
+            }
+            const unsigned r = bitrev((unsigned)m, log2m);
+            zre[r] = v[0];
+            zim[r] = v[1];
+        }
+        __syncthreads();
+        // ---- radix-2 DIT stages
+        for (int s = 1; s <= log2m; ++s) {
+            const int half = 1 << (s - 1);
+            for (int bf = lane; bf < (M >> 1); bf += 64) {
+                const int grp = bf >> (s - 1), j = bf & (half - 1);
+                const int i0 = (grp << s) + j, i1 = i0 + half;
+                const int k = (j << (log2m - s)) << 1;   // W_M^(j*M/2^s) = tw[2*...]
+                const float wr = tw_re[k], wi = tw_im[k];
+                const float xr = zre[i1], xi = zim[i1];
+                const float tr = wr * xr - wi * xi, ti = wr * xi + wi * xr;
+                const float ur = zre[i0], ui = zim[i0];
+                zre[i0] = ur + tr; zim[i0] = ui + ti;
+                zre[i1] = ur - tr; zim[i1] = ui - ti;
+            }
+            __syncthreads();
+        }
+        // ---- real-FFT split + power:  X[k] = E[k] + W_N^k O[k],  k = 0..M
+        for (int k = lane; k <= M; k += 64) {
+            const int k0 = k & (M - 1), k1 = (M - k) & (M - 1);
+            const float ar = zre[k0], ai = zim[k0], br = zre[k1], bi = -zim[k1];  // Z[k], conj(Z[M-k])
+            const float er = 0.5f * (ar + br), ei = 0.5f * (ai + bi);
+            const float dr = 0.5f * (ar - br), di = 0.5f * (ai - bi);            // (Z - conj)/2
+            const float orr = di, oi = -dr;                                      // O = -i * d
+            float wr, wi;
+            if (k < M) { wr = tw_re[k]; wi = tw_im[k]; } else { wr = -1.f; wi = 0.f; }
+            const float xr = er + (wr * orr - wi * oi), xi = ei + (wr * oi + wi * orr);
+            const float p2 = xr * xr + xi * xi;
+            pwr[k] = a.power == 2 ? p2 : sqrtf(p2);
+        }
+        __syncthreads();
+        // ---- sparse mel + log into the LDS tile
+        if (live) {
+            for (int m = lane; m < a.n_mels; m += 64) {
+                float acc = 0.f;
+                const int e1 = a.fb_ptr[m + 1];
+                for (int e = a.fb_ptr[m]; e < e1; ++e) acc = fmaf(a.fb_val[e], pwr[a.fb_idx[e]], acc);
+                acc += a.log_eps;
+                if (a.log_mode == 1) acc = logf(acc);
+                else if (a.log_mode == 2) acc = log10f(acc);
+                tile[m * (a.n_frames + 1) + t] = acc;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- spec_norm == 'max': subtract the tile maximum (melspec.py:48-49)
+    float sub = 0.f;
+    if (a.spec_norm_max) {
+        float mx = -INFINITY;
+        for (int i = tid; i < a.n_mels * a.n_frames; i += 256)
+            mx = fmaxf(mx, tile[(i / a.n_frames) * (a.n_frames + 1) + (i % a.n_frames)]);
+        mx = wave_max(mx);
+        if (lane == 0) red[wave] = mx;
+        __syncthreads();
+        sub = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    }
+    float *o = a.out + (int64_t)blockIdx.x * a.n_mels * a.n_frames;
+    for (int i = tid; i < a.n_mels * a.n_frames; i += 256)
+        o[i] = tile[(i / a.n_frames) * (a.n_frames + 1) + (i % a.n_frames)] - sub;
+}
+
+int launch_melspec(const MelPlan &mp, const float *segs, int64_t B, int64_t seg_stride, int remove_mean,
+                   float *out, hipStream_t s) {
+    if (B <= 0) return 0;
+    MelArgs a;
+    a.segs = segs; a.out = out; a.seg_stride = seg_stride;
+    a.seg_len = mp.seg_len; a.n_fft = mp.n_fft; a.hop = mp.hop; a.n_mels = mp.n_mels;
+    a.n_frames = mp.n_frames; a.log2n = mp.log2n;
+    a.power = mp.power; a.pad_reflect = mp.pad_reflect; a.log_mode = mp.log_mode;
+    a.spec_norm_max = mp.spec_norm_max; a.remove_mean = remove_mean; a.log_eps = mp.log_eps;
+    a.window = mp.window; a.twiddle = mp.twiddle;
+    a.fb_ptr = mp.fb_ptr; a.fb_idx = mp.fb_idx; a.fb_val = mp.fb_val;
+    const int M = mp.n_fft / 2;
+    const size_t lds = sizeof(float) * (size_t)(2 * M + 8 * M + 4 * (M + 4) + mp.n_mels * (mp.n_frames + 1) + 8);
+    if (lds > 160 * 1024) { set_error("melspec: LDS need %zu B > 160 KiB", lds); return -1; }
+    static bool attr_set = false;
+    if (!attr_set) {
+        PF_HIP(hipFuncSetAttribute((const void *)melspec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024));
+        attr_set = true;
+    }
+    ProfScope ps("melspec", s);
+    hipLaunchKernelGGL(melspec_kernel, dim3((unsigned)B), dim3(256), lds, s, a);
+    PF_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// int16 interleaved PCM -> float mono (musicdata.py:48,72-80)
+// ------------------------------------------------------------------------------------
+__global__ void stereo_power_kernel(const int16_t *__restrict__ pcm, int64_t n, double *pw) {
+    double p1 = 0, p2 = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float l = (float)pcm[2 * i] * (1.0f / 32768.0f), r = (float)pcm[2 * i + 1] * (1.0f / 32768.0f);
+        p1 += (double)((l - r) * (l - r));
+        p2 += (double)((l + r) * (l + r));
+    }
+    p1 = wave_sum_d(p1); p2 = wave_sum_d(p2);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&pw[0], p1); atomicAdd(&pw[1], p2); }
+}
+__global__ void pcm_to_mono_kernel(const int16_t *__restrict__ pcm, int64_t n, int n_ch, const double *pw,
+                                   float *__restrict__ wav) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (n_ch == 1) { wav[i] = (float)pcm[i] * (1.0f / 32768.0f); return; }
+    float acc = 0.f;
+    const bool flip = n_ch == 2 && (float)(pw[0] / (double)n) > (float)(pw[1] / (double)n) * 1000.0f;
+    for (int c = 0; c < n_ch; ++c) {
+        float v = (float)pcm[i * n_ch + c] * (1.0f / 32768.0f);
+        if (flip && c == 1) v = -v;
+        acc += v;
+    }
+    wav[i] = acc / (float)n_ch;
+}
+
+int launch_pcm16_to_mono(const int16_t *pcm, int64_t n_frames, int n_ch, float *wav, float *scratch2,
+                         hipStream_t s) {
+    if (n_frames <= 0) return 0;
+    double *pw = reinterpret_cast<double *>(scratch2);
+    ProfScope ps("pcm16_to_mono", s);
+    if (n_ch == 2) {
+        PF_HIP(hipMemsetAsync(pw, 0, 2 * sizeof(double), s));
+        hipLaunchKernelGGL(stereo_power_kernel, dim3(512), dim3(256), 0, s, pcm, n_frames, pw);
+    }
+    hipLaunchKernelGGL(pcm_to_mono_kernel, dim3((unsigned)cdiv(n_frames, 256)), dim3(256), 0, s, pcm, n_frames,
+                       n_ch, pw, wav);
+    PF_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace pfann

@@ -1,0 +1,232 @@
+// Candidate generation + sequence score + argmax on the GPU, one workgroup per query
+// (reference database.py:129-163 `query_embeddings_base`, mode 0; and the native scorer
+// cpp/seqscore.cpp:49-135 `seq_score`, mode 1).
+//
+//   labels[t][i] -> (song, offset = label - song_pos[song] - t/fsm, shift = t%fsm)
+//   -> 64-bit packed keys, bitonic sort + dedup in LDS (= np.unique / std::sort+unique)
+//   -> one wave per unique candidate gathers the <= qlen consecutive db rows of that
+//      alignment (coalesced 512-byte rows, L2-resident after the scan) and accumulates the
+//      inner products; out-of-song rows contribute 0; the divisor is always sub_len
+//   -> first-wins strict-> argmax in the reference's own candidate order, so ties resolve
+//      to the smallest (song, offset) exactly as the reference does.
+#include "kernels.h"
+
+namespace pfann {
+
+static constexpr int MAXC = 8192;       // candidate slots per query (qlen * top_k)
+static constexpr unsigned long long SENT = ~0ull;
+static constexpr int OFF_BIAS = 1 << 27;
+
+struct Cand { int song, off, shift; };
+
+__device__ __forceinline__ unsigned long long pack_cand(int mode, int song, int off, int shift) {
+    const unsigned long long ob = (unsigned long long)(unsigned)(off + OFF_BIAS);
+    if (mode == 0) return ((unsigned long long)shift << 58) | ((unsigned long long)song << 28) | ob;
+    return ((unsigned long long)song << 34) | (ob << 6) | (unsigned long long)shift;
+}
+__device__ __forceinline__ Cand unpack_cand(int mode, unsigned long long key) {
+    Cand c;
+    if (mode == 0) {
+        c.shift = (int)(key >> 58);
+        c.song = (int)((key >> 28) & 0x3FFFFFFFull);
+        c.off = (int)(key & 0xFFFFFFFull) - OFF_BIAS;
+    } else {
+        c.song = (int)(key >> 34);
+        c.off = (int)((key >> 6) & 0xFFFFFFFull) - OFF_BIAS;
+        c.shift = (int)(key & 63ull);
+    }
+    return c;
+}
+
+__device__ void bitonic_sort_keys(unsigned long long *sk, int P, int tid) {
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long x = sk[i], y = sk[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { sk[i] = y; sk[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void match_kernel(RerankArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sk[];   // [P] keys
+    __shared__ int s_nc;
+    const int64_t qi = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t q0 = a.qstart[qi];
+    const int qlen = a.qlen[qi];
+    const int ntot = qlen * a.k;
+    int P = 1;
+    while (P < ntot) P <<= 1;
+    if (P > a.pmax) {   // host sized the LDS for max_qlen: refuse rather than overrun
+        if (tid == 0) { pfann_match_result r; r.song = -2; r.offset = 0; r.shift = 0; r.n_cand = -1; r.score = -INFINITY; a.results[qi] = r; }
+        return;
+    }
+    float *score = reinterpret_cast<float *>(sk + P);                        // [P] candidate sums
+
+    // ---- candidates (database.py:133-138 / seqscore.cpp:49-60)
+    for (int i = tid; i < P; i += 256) {
+        unsigned long long key = SENT;
+        if (i < ntot) {
+            const int t = i / a.k;
+            const int64_t lab = a.labels[(q0 + t) * a.k + (i - t * a.k)];
+            if (lab >= 0) {
+                // largest s with song_pos[s] <= lab  (searchsorted side='right' - 1)
+                int lo = 0, hi = a.n_songs;   // song_pos has n_songs+1 entries; search [0, n_songs)
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (a.song_pos[mid] <= lab) lo = mid + 1; else hi = mid;
+                }
+                const int song = lo - 1;
+                const int tim = t / a.fsm, shift = t - tim * a.fsm;
+                const int off = (int)(lab - a.song_pos[song] - tim);
+                const bool owned = song >= a.song_lo && song < a.song_hi;
+                if (song >= 0 && (owned || !a.only_owned)) key = pack_cand(a.mode, song, off, shift);
+            }
+        }
+        sk[i] = key;
+    }
+    __syncthreads();
+    // ---- sort ascending (== lexicographic candidate order of the reference)
+    bitonic_sort_keys(sk, P, tid);
+    // ---- dedup (np.unique / std::unique): blank repeats, re-sort, count survivors
+    int *dupf = reinterpret_cast<int *>(score);
+    for (int i = tid; i < P; i += 256) dupf[i] = (i > 0 && sk[i] == sk[i - 1]) ? 1 : 0;
+    __syncthreads();
+    for (int i = tid; i < P; i += 256) if (dupf[i]) sk[i] = SENT;
+    if (tid == 0) s_nc = 0;
+    __syncthreads();
+    bitonic_sort_keys(sk, P, tid);
+    for (int i = tid; i < P; i += 256)
+        if (sk[i] != SENT && (i + 1 == P || sk[i + 1] == SENT)) s_nc = i + 1;
+    __syncthreads();
+    const int nc = s_nc;
+
+    // ---- score every unique candidate: one wave each
+    for (int c = wave; c < nc; c += 4) {
+        const Cand cd = unpack_cand(a.mode, sk[c]);
+        const int64_t start = a.song_pos[cd.song];
+        const int slen = (int)(a.song_pos[cd.song + 1] - start);
+        const int sub_len = (qlen - cd.shift + a.fsm - 1) / a.fsm;
+        float tot = 0.f;         // mode 0: lane-partial of the whole dot; mode 1: running sco
+        for (int j = 0; j < sub_len; ++j) {
+            const int r = cd.off + j;
+            if (r < 0 || r >= slen) continue;
+            const float *v = a.db + (start + r - a.label_base) * a.d;
+            const float *qv = a.q + (q0 + (int64_t)j * a.fsm + cd.shift) * a.d;
+            float part = 0.f;
+            for (int e = lane; e < a.d; e += 64) part = fmaf(v[e], qv[e], part);
+            if (a.mode == 0) {
+                tot += part;
+            } else {
+                const float ip = wave_sum(part);
+                if (a.alpha == 0.0f) tot += ip;
+                else if (a.alpha > 0.0f) { const float l2 = 1.0f - ip; tot += expf(-a.alpha * l2 * l2); }
+            }
+        }
+        if (a.mode == 0) tot = wave_sum(tot);
+        else tot = tot / (float)max(sub_len, 1);
+        if (lane == 0) score[c] = tot;
+    }
+    __syncthreads();
+
+    // ---- argmax, first-wins in candidate order (database.py:158-163 / seqscore.cpp:115-124)
+    if (tid < 64) {
+        double best = -INFINITY;
+        int besti = 0x7FFFFFFF;
+        for (int c = lane; c < nc; c += 64) {
+            double sco;
+            if (a.mode == 0) {
+                const int shift = (int)(sk[c] >> 58);
+                const int sub_len = (qlen - shift + a.fsm - 1) / a.fsm;
+                sco = (double)score[c] / (double)sub_len;
+            } else {
+                sco = (double)score[c];
+            }
+            if (sco > best) { best = sco; besti = c; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(besti, o, 64);
+            if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+        }
+        if (lane == 0) {
+            pfann_match_result r;
+            r.n_cand = nc;
+            if (nc > 0 && besti != 0x7FFFFFFF) {
+                const Cand cd = unpack_cand(a.mode, sk[besti]);
+                r.song = cd.song; r.offset = cd.off; r.shift = cd.shift; r.score = best;
+            } else {
+                r.song = -1; r.offset = 0; r.shift = 0; r.score = -INFINITY;
+            }
+            a.results[qi] = r;
+        }
+    }
+    // ---- per-song best (only recorded when > the zero-initialised slot)
+    if (a.song_scores != nullptr) {
+        float *ss = a.song_scores + (int64_t)qi * a.n_songs * 2;
+        if (a.mode == 1 || a.fsm == 1) {
+            // one song = one contiguous run of the sorted list: the run's first max wins
+            for (int c = tid; c < nc; c += 256) {
+                const Cand cd = unpack_cand(a.mode, sk[c]);
+                if (c > 0 && unpack_cand(a.mode, sk[c - 1]).song == cd.song) continue;   // not a run head
+                double best = 0.0;   // slots start at 0: only scores > 0 are recorded
+                int besto = 0;
+                bool any = false;
+                for (int e = c; e < nc; ++e) {
+                    const Cand ce = unpack_cand(a.mode, sk[e]);
+                    if (ce.song != cd.song) break;
+                    double sco;
+                    if (a.mode == 0) sco = (double)score[e] / (double)qlen;   // fsm == 1: sub_len == qlen
+                    else sco = (double)score[e];
+                    // the stored slot is float32: compare against its rounded value like numpy does
+                    if (sco > (any ? (double)(float)best : 0.0)) {
+                        best = sco; any = true;
+                        besto = a.mode == 0 ? ce.off : ce.off * a.fsm - ce.shift;
+                    }
+                }
+                if (any) { ss[cd.song * 2] = (float)best; ss[cd.song * 2 + 1] = (float)besto; }
+            }
+        } else if (tid == 0) {
+            // python path with frame_shift_mul > 1: songs recur once per shift; replay serially
+            for (int c = 0; c < nc; ++c) {
+                const Cand cd = unpack_cand(0, sk[c]);
+                const int sub_len = (qlen - cd.shift + a.fsm - 1) / a.fsm;
+                const double sco = (double)score[c] / (double)sub_len;
+                if (sco > (double)ss[cd.song * 2]) {
+                    ss[cd.song * 2] = (float)sco;
+                    ss[cd.song * 2 + 1] = (float)(cd.off * a.fsm - cd.shift);
+                }
+            }
+        }
+    }
+}
+
+int launch_match(const RerankArgs &a, hipStream_t s) {
+    if (a.nQ <= 0) return 0;
+    if (a.fsm < 1 || a.fsm > 32) { set_error("match: frame_shift_mul=%d outside 1..32", a.fsm); return -1; }
+    if (a.n_songs >= (1 << 30)) { set_error("match: too many songs"); return -1; }
+    static bool attr_set = false;
+    if (!attr_set) {
+        PF_HIP(hipFuncSetAttribute((const void *)match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   MAXC * 12));
+        attr_set = true;
+    }
+    if (a.pmax > MAXC) {
+        set_error("match: max_qlen*top_k needs %d candidate slots > %d", a.pmax, MAXC);
+        return -1;
+    }
+    ProfScope ps("seq_match", s);
+    hipLaunchKernelGGL(match_kernel, dim3((unsigned)a.nQ), dim3(256), (size_t)a.pmax * 12, s, a);
+    PF_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace pfann

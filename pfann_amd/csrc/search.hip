@@ -1,0 +1,375 @@
+// Exact brute-force inner-product top-k for gfx950 (reference database.py:121
+// `index.search(query, top_k)` with an IndexFlatIP, i.e. the k largest q.x per query row).
+//
+// Design (MI355X-first, not faiss' GPU design):
+//   * scores are produced by an LDS-tiled fp32-MFMA GEMM tile  q[BM] x db[BN]  (K = d);
+//     every db row is streamed from HBM once per pass (query panels come from L2);
+//   * NO score matrix is ever written.  Each score is compared in the MFMA epilogue with a
+//     per-query threshold tau_q and only survivors are appended (one 8-byte packed key per
+//     survivor, one atomic) to a small per-query list;
+//   * tau_q is a provable lower bound of the query's k-th best score, obtained from the
+//     exact top-k of a strided 1/R, 1/R^2 .. sample of the shard scanned first (the k-th
+//     best of a subset can only be <= the k-th best of the whole).  Each level emits
+//     ~R*k survivors per query, so the lists stay tiny and the final bitonic select in
+//     LDS is exact;
+//   * a list overflow on the final level (pathological ties / duplicates) raises tau from
+//     the captured survivors and rescans; it never degrades to an approximate answer.
+#include "kernels.h"
+
+namespace pfann {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static constexpr int CAP = 8192;   // survivor slots per query row
+
+__device__ __forceinline__ unsigned f2ord(float f) {   // monotone float -> uint
+    const unsigned u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) {
+    const unsigned u = o ^ ((o >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+    return __uint_as_float(u);
+}
+// ascending sort of packed keys == descending score, ascending row
+__device__ __forceinline__ unsigned long long pack_key(float score, unsigned row) {
+    return ((unsigned long long)(~f2ord(score)) << 32) | row;
+}
+
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + idx;
+}
+
+struct ScanParams {
+    const float *q, *db;
+    int64_t nq, nrows;       // nrows = rows scanned at this level = ceil(N / stride)
+    int64_t row_stride;      // db row step (level stride)
+    int d;
+    const float *thr;        // [nq] or nullptr (= emit everything)
+    int *cnt;                // [nq]
+    unsigned long long *keys;  // [nq][CAP]
+    int n_tiles_m;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void scan_emit_kernel(ScanParams p) {
+    constexpr int BK = 32, LDK = BK + 4;
+    constexpr int WAVES_N = BN / WN;
+    static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int AR = (BM + 31) / 32, BR = BN / 32;
+    __shared__ __attribute__((aligned(16))) float As[BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
+    __shared__ float thr_s[BM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = L / p.n_tiles_m, mt = L - nt * p.n_tiles_m;   // query tiles fastest: db tile stays in L2
+    const int64_t m0 = (int64_t)mt * BM, n0 = (int64_t)nt * BN;
+    const int col4 = tid & 7, rowq = tid >> 3;
+
+    if (tid < BM) {
+        const int64_t m = m0 + tid;
+        thr_s[tid] = (p.thr != nullptr && m < p.nq) ? p.thr[m] : -INFINITY;
+    }
+
+    f32x4 ra[AR], rb[BR];
+    int kap = col4 * 4;
+    auto load_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int64_t m = m0 + rowq + 32 * i;
+            const bool ok = (rowq + 32 * i) < BM && m < p.nq && kap < p.d;
+            ra[i] = ok ? *reinterpret_cast<const f32x4 *>(p.q + m * p.d + kap) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < BR; ++j) {
+            const int64_t n = n0 + rowq + 32 * j;
+            const bool ok = n < p.nrows && kap < p.d;
+            rb[j] = ok ? *reinterpret_cast<const f32x4 *>(p.db + n * p.row_stride * p.d + kap)
+                       : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        kap += BK;
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < AR; ++i)
+            if ((rowq + 32 * i) < BM)
+                *reinterpret_cast<f32x4 *>(&As[(rowq + 32 * i) * LDK + col4 * 4]) = ra[i];
+#pragma unroll
+        for (int j = 0; j < BR; ++j)
+            *reinterpret_cast<f32x4 *>(&Bs[(rowq + 32 * j) * LDK + col4 * 4]) = rb[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (p.d + BK - 1) / BK;
+    load_tile();
+    store_tile();
+    __syncthreads();
+    const int l31 = lane & 31, lhalf = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_tile();
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            f32x4 a4[TM], b4[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a4[i] = *reinterpret_cast<const f32x4 *>(&As[(wm * WM + i * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b4[j] = *reinterpret_cast<const f32x4 *>(&Bs[(wn * WN + j * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][s], b4[j][s], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+    // epilogue: threshold filter + append.  acc[i][j][r]: query row = (r&3)+8*(r>>2)+4*lhalf,
+    // db row = lane&31 of the 32x32 tile.
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int64_t n = n0 + wn * WN + j * 32 + l31;
+        const bool nok = n < p.nrows;
+        const unsigned row = (unsigned)(n * p.row_stride);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                const int64_t m = m0 + ml;
+                const float sc = acc[i][j][r];
+                if (nok && m < p.nq && sc >= thr_s[ml]) {
+                    const int pos = atomicAdd(&p.cnt[m], 1);
+                    if (pos < CAP) p.keys[m * CAP + pos] = pack_key(sc, row);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Per-query exact select: bitonic sort of the (<= CAP) packed survivors in LDS.
+//   mode 0: write thr[m] = k-th best score (or -inf when fewer than k survivors)
+//   mode 1: write D[m][k], I[m][k] (+label_base); pad with -FLT_MAX / -1
+// overflow[0] is set when a final-level list overflowed.
+// ------------------------------------------------------------------------------------
+__device__ void bitonic_sort_u64(unsigned long long *s, int P, int tid, int nt) {
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P; i += nt) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = s[i], b = s[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { s[i] = b; s[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void select_kernel(const unsigned long long *__restrict__ keys,
+                                                      const int *__restrict__ cnt, int k, int mode,
+                                                      float *__restrict__ thr, float *__restrict__ D,
+                                                      int64_t *__restrict__ I, int64_t label_base,
+                                                      int *overflow) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
+    const int64_t m = blockIdx.x;
+    const int tid = threadIdx.x;
+    int n = cnt[m];
+    if (n > CAP) {
+        if (mode == 1 && tid == 0) atomicExch(overflow, 1);
+        n = CAP;
+    }
+    int P = 1;
+    while (P < n) P <<= 1;
+    for (int i = tid; i < P; i += 1024) skeys[i] = i < n ? keys[m * CAP + i] : ~0ull;
+    __syncthreads();
+    bitonic_sort_u64(skeys, P, tid, 1024);
+    if (mode == 0) {
+        if (tid == 0) thr[m] = n >= k ? ord2f(~(unsigned)(skeys[k - 1] >> 32)) : -INFINITY;
+    } else {
+        for (int i = tid; i < k; i += 1024) {
+            if (i < n) {
+                const unsigned long long key = skeys[i];
+                D[m * k + i] = ord2f(~(unsigned)(key >> 32));
+                I[m * k + i] = (int64_t)(unsigned)(key & 0xFFFFFFFFu) + label_base;
+            } else {
+                D[m * k + i] = -3.4028234663852886e38f;
+                I[m * k + i] = -1;
+            }
+        }
+        // on overflow, publish the raised threshold for the rescan
+        if (cnt[m] > CAP && tid == 0 && thr != nullptr) thr[m] = ord2f(~(unsigned)(skeys[k - 1] >> 32));
+    }
+}
+
+static int launch_scan(const float *db, int64_t n, int d, int64_t stride, const float *q, int64_t nq,
+                       const float *thr, SearchWorkspace &ws, hipStream_t s) {
+    ScanParams p;
+    p.q = q; p.db = db; p.nq = nq; p.d = d;
+    p.row_stride = stride;
+    p.nrows = (n + stride - 1) / stride;
+    p.thr = thr; p.cnt = ws.cnt; p.keys = reinterpret_cast<unsigned long long *>(ws.cl);
+    PF_HIP(hipMemsetAsync(ws.cnt, 0, sizeof(int) * nq, s));
+    ProfScope ps(stride == 1 ? "scan_topk" : "scan_topk_sample", s);
+    if (nq <= 32) {
+        p.n_tiles_m = 1;
+        const int64_t blocks = cdiv(p.nrows, 128);
+        hipLaunchKernelGGL((scan_emit_kernel<32, 128, 32, 32>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    } else if (nq <= 64) {
+        p.n_tiles_m = 1;
+        const int64_t blocks = cdiv(p.nrows, 64);
+        hipLaunchKernelGGL((scan_emit_kernel<64, 64, 32, 32>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    } else {
+        p.n_tiles_m = cdiv(nq, 128);
+        const int64_t blocks = (int64_t)cdiv(p.nrows, 128) * p.n_tiles_m;
+        hipLaunchKernelGGL((scan_emit_kernel<128, 128, 64, 64>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    }
+    PF_HIP(hipGetLastError());
+    return 0;
+}
+
+static int launch_select(SearchWorkspace &ws, int64_t nq, int k, int mode, float *D, int64_t *I,
+                         int64_t label_base, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        PF_HIP(hipFuncSetAttribute((const void *)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   CAP * 8));
+        attr_set = true;
+    }
+    ProfScope ps("topk_select", s);
+    hipLaunchKernelGGL(select_kernel, dim3((unsigned)nq), dim3(1024), CAP * 8, s,
+                       reinterpret_cast<const unsigned long long *>(ws.cl), ws.cnt, k, mode, ws.thr, D, I,
+                       label_base, ws.overflow);
+    PF_HIP(hipGetLastError());
+    return 0;
+}
+
+static int ensure_ws(SearchWorkspace &ws, int64_t nq) {
+    if (ws.cap_q >= nq) return 0;
+    if (ws.thr) { (void)hipFree(ws.thr); (void)hipFree(ws.cnt); (void)hipFree(ws.cl); }
+    if (!ws.overflow) PF_HIP(hipMalloc(&ws.overflow, sizeof(int)));
+    const int64_t cap = nq < 64 ? 64 : nq;
+    PF_HIP(hipMalloc(&ws.thr, sizeof(float) * cap));
+    PF_HIP(hipMalloc(&ws.cnt, sizeof(int) * cap));
+    PF_HIP(hipMalloc(&ws.cl, sizeof(unsigned long long) * cap * CAP));
+    ws.cap_q = cap;
+    ws.cap_c = CAP;
+    return 0;
+}
+
+__global__ void fill_empty_kernel(float *D, int64_t *I, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) { D[i] = -3.4028234663852886e38f; I[i] = -1; }
+}
+
+int search_topk(const float *db, int64_t n, int d, int64_t label_base, const float *q, int64_t nq, int k,
+                float *D, int64_t *I, SearchWorkspace &ws, hipStream_t s) {
+    if (nq <= 0) return 0;
+    if (k < 1 || k > 1024) { set_error("search_topk: k=%d outside 1..1024", k); return -1; }
+    if (d % 4 != 0) { set_error("search_topk: d=%d must be a multiple of 4", d); return -1; }
+    if (n >= (1ll << 32)) { set_error("search_topk: shard rows %lld >= 2^32", (long long)n); return -1; }
+    if (n == 0) {
+        hipLaunchKernelGGL(fill_empty_kernel, dim3((unsigned)cdiv(nq * k, 256)), dim3(256), 0, s, D, I, nq * k);
+        PF_HIP(hipGetLastError());
+        return 0;
+    }
+    if (ensure_ws(ws, nq)) return -1;
+    // sampling ratio per level: expected survivors ~ R*k per query, kept <= CAP/4
+    const int R = k <= 128 ? 16 : (k <= 512 ? 4 : 2);
+    int levels = 0;
+    int64_t stride = 1;
+    while ((n + stride - 1) / stride > CAP) { stride *= R; ++levels; }
+    PF_HIP(hipMemsetAsync(ws.overflow, 0, sizeof(int), s));
+    const float *thr = nullptr;
+    for (int lev = levels; lev >= 1; --lev) {
+        if (launch_scan(db, n, d, stride, q, nq, thr, ws, s)) return -1;
+        if (launch_select(ws, nq, k, 0, nullptr, nullptr, 0, s)) return -1;
+        thr = ws.thr;
+        stride /= R;
+    }
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        if (launch_scan(db, n, d, 1, q, nq, thr, ws, s)) return -1;
+        if (launch_select(ws, nq, k, 1, D, I, label_base, s)) return -1;
+        int ovf = 0;
+        PF_HIP(hipMemcpyAsync(&ovf, ws.overflow, sizeof(int), hipMemcpyDeviceToHost, s));
+        PF_HIP(hipStreamSynchronize(s));
+        if (!ovf) return 0;
+        // survivors overflowed a list: thresholds were raised by select_kernel; rescan
+        if (thr == nullptr) { set_error("search_topk: survivor list overflow without threshold"); return -1; }
+        PF_HIP(hipMemsetAsync(ws.overflow, 0, sizeof(int), s));
+    }
+    set_error("search_topk: survivor lists keep overflowing (more than %d rows tie at the k-th score?)", CAP);
+    return -4;
+}
+
+// ------------------------------------------------------------------------------------
+// Merge of per-shard top-k lists (after the RCCL all-gather): exact top-k of S/L[nq][m].
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void merge_kernel(const float *__restrict__ S, const int64_t *__restrict__ Lb,
+                                                     int m, int k, float *__restrict__ D,
+                                                     int64_t *__restrict__ I) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
+    const int64_t qi = blockIdx.x;
+    const int tid = threadIdx.x;
+    int P = 1;
+    while (P < m) P <<= 1;
+    for (int i = tid; i < P; i += 1024) {
+        unsigned long long key = ~0ull;
+        if (i < m && Lb[qi * m + i] >= 0) key = pack_key(S[qi * m + i], (unsigned)i);
+        skeys[i] = key;
+    }
+    __syncthreads();
+    bitonic_sort_u64(skeys, P, tid, 1024);
+    for (int i = tid; i < k; i += 1024) {
+        const unsigned long long key = i < P ? skeys[i] : ~0ull;
+        if (key != ~0ull) {
+            D[qi * k + i] = ord2f(~(unsigned)(key >> 32));
+            I[qi * k + i] = Lb[qi * m + (unsigned)(key & 0xFFFFFFFFu)];
+        } else {
+            D[qi * k + i] = -3.4028234663852886e38f;
+            I[qi * k + i] = -1;
+        }
+    }
+}
+
+int topk_merge(const float *S, const int64_t *L, int64_t nq, int m, int k, float *D, int64_t *I,
+               hipStream_t s) {
+    if (nq <= 0) return 0;
+    if (m > 16384) { set_error("topk_merge: m=%d > 16384", m); return -1; }
+    int P = 1;
+    while (P < m) P <<= 1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PF_HIP(hipFuncSetAttribute((const void *)merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   16384 * 8));
+        attr_set = true;
+    }
+    ProfScope ps("topk_merge", s);
+    hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(1024), (size_t)P * 8, s, S, L, m, k, D, I);
+    PF_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace pfann

@@ -1,0 +1,183 @@
+"""Host mirror of the reference's retrieval interface (database.py:74-195):
+`Database(dir_for_db, indexer_params, hop_size)` and
+`Database.query_embeddings(query) -> (score, (song_id, time_s), song_score[n_songs,2])`.
+
+The fingerprints live in HBM; search (exact flat inner-product top-k) and the sequence
+matcher run as HIP kernels (csrc/search.hip, csrc/rerank.hip).  `query_batch` exposes the
+batched form the CLIs and bench use; `query_embeddings` keeps the reference's per-query
+contract, python-path semantics (cpp_accelerate=False, database.py:12).
+"""
+import ctypes
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import faissio
+from . import lib as _l
+from .utils import read_file_list
+
+
+def song_pos_from_key(landmark_key):
+    return np.pad(np.cumsum(np.asarray(landmark_key), dtype=np.int64), (1, 0))      # database.py:86
+
+
+class DeviceIndex:
+    """One shard of fingerprints on one GPU + its search / match kernels."""
+
+    def __init__(self, d, device=0):
+        _l.require_gpu()
+        self.lib = _l.load()
+        self.d = d
+        self.device = torch.device("cuda", device)
+        self.handle = self.lib.pfann_db_create(d, device)
+        if not self.handle:
+            raise _l.PfannError("pfann_db_create failed: " + _l.last_error())
+        self.ntotal = 0
+        self.label_base = 0
+        self.n_songs = 0
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            self.lib.pfann_db_destroy(h)
+
+    def load(self, emb, song_pos, label_base=0):
+        """emb: float32 [n, d] numpy (host) or torch cuda tensor; song_pos: GLOBAL int64 prefix sums."""
+        song_pos = np.ascontiguousarray(song_pos, dtype=np.int64)
+        self.song_pos = song_pos
+        self.n_songs = song_pos.shape[0] - 1
+        if isinstance(emb, torch.Tensor) and emb.is_cuda:
+            e = emb.to(torch.float32).contiguous()
+            ptr, is_dev, n = e.data_ptr(), 1, e.shape[0]
+        else:
+            e = np.ascontiguousarray(emb.cpu().numpy() if isinstance(emb, torch.Tensor) else emb, np.float32)
+            e = e.reshape(-1, self.d)
+            ptr, is_dev, n = e.ctypes.data, 0, e.shape[0]
+        _l.check(self.lib.pfann_db_load(self.handle, ptr, is_dev, n,
+                                        song_pos.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                        self.n_songs, label_base), "pfann_db_load")
+        self.ntotal = n
+        self.label_base = label_base
+
+    def _stream(self):
+        return _l.current_stream_ptr(self.device)
+
+    def search(self, q, k):
+        """index.search(q, k): q torch cuda [nq, d] -> (D [nq,k] f32 desc, I [nq,k] int64) on device."""
+        q = q.to(self.device, torch.float32).contiguous()
+        nq = q.shape[0]
+        D = torch.empty((nq, k), device=self.device, dtype=torch.float32)
+        I = torch.empty((nq, k), device=self.device, dtype=torch.int64)
+        if nq:
+            _l.check(self.lib.pfann_search_topk(self.handle, q.data_ptr(), nq, k, D.data_ptr(), I.data_ptr(),
+                                                self._stream()), "pfann_search_topk")
+        return D, I
+
+    def merge_topk(self, S, L, k):
+        nq, m = S.shape
+        D = torch.empty((nq, k), device=self.device, dtype=torch.float32)
+        I = torch.empty((nq, k), device=self.device, dtype=torch.int64)
+        if nq:
+            _l.check(self.lib.pfann_topk_merge(self.handle, S.contiguous().data_ptr(), L.contiguous().data_ptr(),
+                                               nq, m, k, D.data_ptr(), I.data_ptr(), self._stream()),
+                     "pfann_topk_merge")
+        return D, I
+
+    def match(self, q, labels, qstart, qlen, fsm=1, alpha=0.0, mode=0, only_owned=False, want_song_scores=False):
+        """Sequence matcher for nQ queries.  Returns (results structured array, song_scores or None)."""
+        q = q.to(self.device, torch.float32).contiguous()
+        labels = labels.to(self.device, torch.int64).contiguous()
+        qs = torch.as_tensor(np.asarray(qstart, dtype=np.int64)).to(self.device)
+        ql_np = np.asarray(qlen, dtype=np.int32)
+        ql = torch.as_tensor(ql_np).to(self.device)
+        nQ = int(ql_np.shape[0])
+        k = labels.shape[1]
+        res = torch.empty((nQ, ctypes.sizeof(_l.MatchResult)), device=self.device, dtype=torch.uint8)
+        ss = None
+        if want_song_scores:
+            ss = torch.zeros((nQ, self.n_songs, 2), device=self.device, dtype=torch.float32)
+        if nQ:
+            _l.check(self.lib.pfann_match(self.handle, q.data_ptr(), labels.data_ptr(), k, qs.data_ptr(),
+                                          ql.data_ptr(), nQ, int(ql_np.max()), fsm, float(alpha), mode,
+                                          1 if only_owned else 0, res.data_ptr(),
+                                          ss.data_ptr() if ss is not None else None, self._stream()),
+                     "pfann_match")
+        dt = np.dtype([("song", "<i4"), ("offset", "<i4"), ("shift", "<i4"), ("n_cand", "<i4"),
+                       ("score", "<f8")])
+        out = np.frombuffer(res.cpu().numpy().tobytes(), dtype=dt)
+        if (out["song"] == -2).any():
+            raise _l.PfannError("query longer than the matcher's candidate buffer (qlen*top_k > 8192)")
+        return out, ss
+
+
+def _fine_to_time(fine, fsm, hop_size):
+    """fine = t*fsm - shift  ->  (t - shift/fsm) * hop_size, as database.py:148 computes it."""
+    fine = np.asarray(fine, dtype=np.int64)
+    shift = (-fine) % fsm
+    t = (fine + shift) // fsm
+    return (t - shift / fsm) * hop_size
+
+
+class Database:
+    def __init__(self, dir_for_db, indexer_params, hop_size, device=0, d=None):
+        self.dir_for_db = dir_for_db
+        self.params = indexer_params
+        self.top_k = self.params["top_k"]
+        self.frame_shift_mul = self.params.get("frame_shift_mul", 1)
+        self.hop_size = hop_size
+        self.score_alpha = self.params.get("score_alpha", 0)
+
+        self.songList = read_file_list(os.path.join(dir_for_db, "songList.txt"))
+        key = np.fromfile(os.path.join(dir_for_db, "landmarkKey"), dtype=np.int32)
+        assert len(self.songList) == key.shape[0]
+        self.song_pos = song_pos_from_key(key)
+
+        emb = None
+        lv = os.path.join(dir_for_db, "landmarkValue")
+        if os.path.exists(lv):
+            try:
+                emb, _ = faissio.read_index_flat(lv)
+            except ValueError as x:
+                print(x)
+        if emb is None:                                         # database.py:96-97 fallback
+            if d is None:
+                cfg = os.path.join(dir_for_db, "configs.json")
+                d = json.load(open(cfg))["model"]["d"]
+            emb = np.fromfile(os.path.join(dir_for_db, "embeddings"), dtype=np.float32).reshape(-1, d)
+        self.d = emb.shape[1] if emb.ndim == 2 and emb.shape[0] else (d or emb.shape[-1])
+        assert emb.shape[0] == self.song_pos[-1], "embeddings rows != sum(landmarkKey)"
+        self.index = DeviceIndex(self.d, device)
+        self.index.load(emb, self.song_pos, 0)
+
+    # ---- batched form ------------------------------------------------------------------
+    def query_batch(self, emb, qstart, qlen, want_song_scores=False, mode=0):
+        """emb: torch cuda [sum(qlen), d] unit-norm rows; -> list of (score, (song, time), song_score|None)."""
+        D, I = self.index.search(emb, self.top_k)
+        res, ss = self.index.match(emb, I, qstart, qlen, self.frame_shift_mul, self.score_alpha, mode,
+                                   False, want_song_scores)
+        ss_np = ss.cpu().numpy() if ss is not None else None
+        out = []
+        fsm = self.frame_shift_mul
+        for j in range(len(qlen)):
+            r = res[j]
+            song_score = None
+            if ss_np is not None:
+                song_score = ss_np[j].copy()
+                song_score[:, 1] = _fine_to_time(song_score[:, 1].astype(np.int64), fsm, self.hop_size)
+            if self.index.ntotal == 0 or r["song"] < 0:
+                out.append((-1e999, (-1, 0), song_score))
+                continue
+            real_time = (int(r["offset"]) - int(r["shift"]) / fsm) * self.hop_size
+            out.append((float(r["score"]), (int(r["song"]), real_time), song_score))
+        return out
+
+    # ---- the reference's per-query contract ---------------------------------------------
+    def query_embeddings(self, query):
+        q = torch.as_tensor(np.ascontiguousarray(query, dtype=np.float32)) if not isinstance(query, torch.Tensor) else query
+        q = q.to(self.index.device)
+        (score, best_song_t, song_score), = self.query_batch(q, [0], [q.shape[0]], want_song_scores=True)
+        return score, best_song_t, song_score
+
+    query_embeddings_base = query_embeddings

@@ -1,0 +1,189 @@
+"""Engine: one pfann_ctx (front-end + encoder) on one GPU, driven with torch tensors.
+
+PyTorch is plumbing here (device memory + streams); all arithmetic runs in
+libpfann_amd.so through the C ABI.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib as _l
+from .synth import model_dims
+
+
+def _mel_to_hz_tensor(m, scale):
+    if scale == "htk":
+        return 700.0 * (10.0 ** (m / 2595.0) - 1.0)
+    import math
+    logstep = math.log(6.4) / 27.0
+    return torch.where(m >= 15.0, 1000.0 * torch.exp(logstep * (m - 15.0)), (200.0 / 3) * m)
+
+
+def _hz_to_mel(f, scale):
+    import math
+    if scale == "htk":
+        return 2595.0 * math.log10(1.0 + f / 700.0)
+    if f >= 1000.0:
+        return 15.0 + math.log(f / 1000.0) / (math.log(6.4) / 27.0)
+    return f / (200.0 / 3)
+
+
+def mel_filterbank(sample_rate, n_fft, n_mels, f_min, f_max, naf_mode=False):
+    """Triangular mel bank fb[n_fft//2+1, n_mels] in fp32 torch ops: what
+    torchaudio.transforms.MelSpectrogram(mel_scale='htk', norm=None) (default mode) or
+    (mel_scale='slaney', norm='slaney') (naf_mode) builds for reference melspec.py:19-31."""
+    scale = "slaney" if naf_mode else "htk"
+    n_freqs = n_fft // 2 + 1
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    m_pts = torch.linspace(_hz_to_mel(f_min, scale), _hz_to_mel(f_max, scale), n_mels + 2)
+    f_pts = _mel_to_hz_tensor(m_pts, scale)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    fb = torch.clamp(torch.min(-slopes[:, :-2] / f_diff[:-1], slopes[:, 2:] / f_diff[1:]), min=0.0)
+    if naf_mode:
+        fb = fb * (2.0 / (f_pts[2:n_mels + 2] - f_pts[:n_mels])).unsqueeze(0)
+    return fb.to(torch.float32).contiguous()
+
+
+def config_from_params(params, max_batch=512):
+    """configs/*.json dict -> pfann_config (keys read exactly where the reference reads them:
+    builder.py:46-51, melspec.py:52-63, model.py:135-140)."""
+    d, h, u, F, T = model_dims(params)
+    m = params["model"]
+    naf = params.get("naf_mode", False)
+    cfg = _l.Config()
+    cfg.segment_len = int(params["segment_size"] * params["sample_rate"])
+    cfg.stft_n = params["stft_n"]
+    cfg.stft_hop = params["stft_hop"]
+    cfg.n_mels = params["n_mels"]
+    cfg.power = 1 if naf else 2
+    cfg.pad_reflect = 0 if naf else 1
+    cfg.log_mode = {"log": 1, "log10": 2}.get(params.get("mel_log", "log"), 0)
+    cfg.spec_norm_max = 1 if params.get("spec_norm", "l2") == "max" else 0
+    cfg.log_eps = 0.06 if naf else 1e-8
+    cfg.d, cfg.h, cfg.u = d, h, u
+    cfg.fuller = 1 if m.get("fuller", False) else 0
+    cfg.activation = {"ReLU": 0, "ELU": 1}[m.get("conv_activation", "ReLU")]
+    cfg.relu_after_bn = 1 if m.get("relu_after_bn", True) else 0
+    strides = m.get("strides")
+    for i in range(8):
+        cfg.stride_t[i] = 2 if strides is None else strides[i][0][1]
+        cfg.stride_f[i] = 2 if strides is None else strides[i][1][0]
+    cfg.max_batch = max_batch
+    return cfg
+
+
+class Engine:
+    def __init__(self, params, device=0, max_batch=512):
+        _l.require_gpu()
+        self.lib = _l.load()
+        self.params = params
+        self.device = torch.device("cuda", device if isinstance(device, int) else (device.index or 0))
+        self.cfg = config_from_params(params, max_batch)
+        self.d, self.h, self.u, self.F, self.T = model_dims(params)
+        self.seg_len = self.cfg.segment_len
+        self.handle = self.lib.pfann_create(ctypes.byref(self.cfg), self.device.index)
+        if not self.handle:
+            raise _l.PfannError("pfann_create failed: " + _l.last_error())
+        n_frames = 1 + self.seg_len // self.cfg.stft_hop
+        if n_frames != self.T:
+            raise _l.PfannError("stft yields %d frames but the encoder expects T=%d" % (n_frames, self.T))
+        fb = mel_filterbank(params["sample_rate"], params["stft_n"], params["n_mels"], params["f_min"],
+                            params["f_max"], params.get("naf_mode", False)).numpy()
+        _l.check(self.lib.pfann_set_melbank(self.handle, fb.ctypes.data, fb.shape[0], fb.shape[1]),
+                 "pfann_set_melbank")
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            self.lib.pfann_destroy(h)
+
+    # ---- weights ---------------------------------------------------------------------
+    def load_state_dict(self, sd):
+        """sd: name -> torch tensor / numpy array, reference state_dict names (68 tensors)."""
+        for name, val in sd.items():
+            arr = val.detach().cpu().numpy() if isinstance(val, torch.Tensor) else np.asarray(val)
+            arr = np.ascontiguousarray(arr, dtype=np.float32)
+            _l.check(self.lib.pfann_load_weight(self.handle, name.encode(), arr.ctypes.data, arr.size),
+                     "pfann_load_weight(%s)" % name)
+        missing = self.lib.pfann_weights_missing(self.handle)
+        if missing:
+            raise _l.PfannError("state_dict incomplete: %d tensors missing" % missing)
+
+    # ---- operators -------------------------------------------------------------------
+    def _stream(self):
+        return _l.current_stream_ptr(self.device)
+
+    def _prep(self, x):
+        if not isinstance(x, torch.Tensor):
+            x = torch.as_tensor(np.asarray(x, dtype=np.float32))
+        return x.to(self.device, torch.float32).contiguous()
+
+    def melspec(self, segs):
+        """MelSpec.forward: [..., seg_len] -> [..., n_mels, T]."""
+        x = self._prep(segs)
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, self.seg_len)
+        out = torch.empty((x2.shape[0], self.F, self.T), device=self.device, dtype=torch.float32)
+        if x2.shape[0]:
+            _l.check(self.lib.pfann_melspec(self.handle, x2.data_ptr(), x2.shape[0], self.seg_len, 0,
+                                            out.data_ptr(), self._stream()), "pfann_melspec")
+        return out.reshape(*lead, self.F, self.T)
+
+    def encode(self, mel, norm=True):
+        """FpNetwork.forward: [B, F, T] -> [B, d]."""
+        x = self._prep(mel)
+        assert x.dim() == 3 and x.shape[1] == self.F and x.shape[2] == self.T, x.shape
+        out = torch.empty((x.shape[0], self.d), device=self.device, dtype=torch.float32)
+        if x.shape[0]:
+            _l.check(self.lib.pfann_encode(self.handle, x.data_ptr(), x.shape[0], out.data_ptr(),
+                                           1 if norm else 0, self._stream()), "pfann_encode")
+        return out
+
+    def embed_wav(self, wav, hop, n_seg=None, norm=True):
+        """Fused path: mono float wav [L] on device -> [n_seg, d] embeddings of the windows
+        wav[i*hop : i*hop+seg_len] (mean removal, mel, encoder, optional L2 norm)."""
+        w = self._prep(wav).reshape(-1)
+        if w.shape[0] < self.seg_len:                      # musicdata.py:82-84
+            w = torch.nn.functional.pad(w, (0, self.seg_len - w.shape[0]))
+        if n_seg is None:
+            n_seg = (w.shape[0] - self.seg_len) // hop + 1
+        assert (n_seg - 1) * hop + self.seg_len <= w.shape[0]
+        out = torch.empty((n_seg, self.d), device=self.device, dtype=torch.float32)
+        if n_seg:
+            _l.check(self.lib.pfann_segment_embed(self.handle, w.data_ptr(), n_seg, hop, out.data_ptr(),
+                                                  1 if norm else 0, self._stream()), "pfann_segment_embed")
+        return out
+
+    def embed_windows(self, wav, starts_stride, n_seg, norm=True):
+        return self.embed_wav(wav, starts_stride, n_seg, norm)
+
+    def pcm16_to_mono(self, pcm):
+        """int16 [n] or [n, ch] (torch / numpy) -> float32 mono [n] on device."""
+        p = pcm if isinstance(pcm, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(pcm))
+        p = p.to(self.device, torch.int16).contiguous()
+        n_ch = 1 if p.dim() == 1 else p.shape[1]
+        n = p.shape[0]
+        out = torch.empty((n,), device=self.device, dtype=torch.float32)
+        if n:
+            _l.check(self.lib.pfann_pcm16_to_mono(self.handle, p.data_ptr(), n, n_ch, out.data_ptr(),
+                                                  self._stream()), "pfann_pcm16_to_mono")
+        return out
+
+    # ---- verification taps -----------------------------------------------------------
+    def debug_keep(self, on=True):
+        self.lib.pfann_debug_keep(self.handle, 1 if on else 0)
+
+    def debug_activation(self, idx, B):
+        from .synth import layer_plan
+        L = layer_plan(self.params)[idx // 2]
+        if idx % 2 == 0:
+            shape = (L["co"], L["F"], L["T1"])
+        else:
+            shape = (L["co"], L["F2"], L["T1"])
+        buf = np.empty((B,) + shape, dtype=np.float32)
+        torch.cuda.synchronize(self.device)
+        n = _l.check(self.lib.pfann_debug_activation(self.handle, idx, B, buf.ctypes.data, buf.size),
+                     "pfann_debug_activation")
+        return buf.reshape(-1)[:n].reshape((-1,) + shape)

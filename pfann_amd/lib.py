@@ -1,0 +1,104 @@
+"""ctypes binding of libpfann_amd.so (include/pfann_amd.h).  There is NO CPU fallback:
+if the library is missing or no MI355X is visible, the product path raises."""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int16, c_int32, c_int64,
+                    c_longlong, c_void_p)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpfann_amd.so")
+
+
+class PfannError(RuntimeError):
+    pass
+
+
+class Config(Structure):
+    _fields_ = [("segment_len", c_int32), ("stft_n", c_int32), ("stft_hop", c_int32), ("n_mels", c_int32),
+                ("power", c_int32), ("pad_reflect", c_int32), ("log_mode", c_int32),
+                ("spec_norm_max", c_int32), ("log_eps", c_float),
+                ("d", c_int32), ("h", c_int32), ("u", c_int32), ("fuller", c_int32),
+                ("activation", c_int32), ("relu_after_bn", c_int32),
+                ("stride_t", c_int32 * 8), ("stride_f", c_int32 * 8), ("max_batch", c_int32)]
+
+
+class MatchResult(Structure):
+    _fields_ = [("song", c_int32), ("offset", c_int32), ("shift", c_int32), ("n_cand", c_int32),
+                ("score", c_double)]
+
+
+# every symbol include/pfann_amd.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "version": (c_longlong, []),
+    "seq_score": (c_int, [c_void_p, POINTER(c_int64), c_int, POINTER(c_float), c_int, POINTER(c_int64),
+                          c_int, POINTER(c_float), c_int, c_float]),
+    "pfann_last_error": (c_char_p, []),
+    "pfann_create": (c_void_p, [POINTER(Config), c_int]),
+    "pfann_destroy": (None, [c_void_p]),
+    "pfann_set_melbank": (c_int, [c_void_p, c_void_p, c_int, c_int]),
+    "pfann_load_weight": (c_int, [c_void_p, c_char_p, c_void_p, c_int64]),
+    "pfann_weights_missing": (c_int, [c_void_p]),
+    "pfann_melspec": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
+    "pfann_encode": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p]),
+    "pfann_segment_embed": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p]),
+    "pfann_pcm16_to_mono": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "pfann_debug_activation": (c_int64, [c_void_p, c_int, c_int64, c_void_p, c_int64]),
+    "pfann_debug_keep": (None, [c_void_p, c_int]),
+    "pfann_db_create": (c_void_p, [c_int, c_int]),
+    "pfann_db_destroy": (None, [c_void_p]),
+    "pfann_db_dim": (c_int, [c_void_p]),
+    "pfann_db_ntotal": (c_int64, [c_void_p]),
+    "pfann_db_bytes": (c_int64, [c_void_p]),
+    "pfann_db_load": (c_int, [c_void_p, c_void_p, c_int, c_int64, POINTER(c_int64), c_int, c_int64]),
+    "pfann_search_topk": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "pfann_topk_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
+                                 c_void_p]),
+    "pfann_match": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int,
+                            c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "pfann_prof_enable": (None, [c_int]),
+    "pfann_prof_reset": (None, []),
+    "pfann_prof_elapsed_ms": (c_double, [c_char_p, POINTER(c_int64)]),
+    "pfann_prof_tags": (c_int, [c_char_p, c_int]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads the shared library and binds every declared symbol (raises if any is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PfannError("%s not found: build it with `python -m pfann_amd.build` "
+                         "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    msg = load().pfann_last_error()
+    return msg.decode("utf8", "replace") if msg else ""
+
+
+def check(rc, what):
+    if rc is None or (isinstance(rc, int) and rc < 0):
+        raise PfannError("%s failed (%s): %s" % (what, rc, last_error()))
+    return rc
+
+
+def current_stream_ptr(device=None):
+    import torch
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise PfannError("no HIP device visible: the pfann_amd hot path runs only on an MI355X "
+                         "(there is no CPU fallback)")

@@ -1,0 +1,83 @@
+"""Host mirror of the reference's segmenter interface (datautil/musicdata.py:9-104) for the
+in-scope input class: 16-bit PCM WAV already at the model sample rate (the reference's
+resampler is the identity there).  Other formats/rates need ffmpeg + julius: out of scope.
+
+Two ways to consume a file:
+  * `MusicDataset[i] -> (i, path, float32[n_seg, seg_len])`  -- the reference's contract
+    (materialised unfold on the host; used by the operator-seam API and tests);
+  * `MusicDataset.load_pcm(i) -> int16[n, ch]`               -- raw PCM for the fused device
+    path (Engine.pcm16_to_mono + Engine.embed_wav), which never materialises the unfold.
+"""
+import time
+import wave
+
+import numpy as np
+import torch
+
+from .utils import get_logger, read_file_list
+
+
+def read_wav_pcm16(path):
+    """-> (int16[n_frames, n_ch], sample_rate).  16-bit PCM only (audio.py:130-149)."""
+    with wave.open(path, "rb") as w:
+        if w.getsampwidth() != 2:
+            raise NotImplementedError("wave stream currently only supports 16bit wav")
+        n_ch, sr = w.getnchannels(), w.getframerate()
+        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16).reshape(-1, n_ch)
+    return pcm, sr
+
+
+class MusicDataset:
+    def __init__(self, file_list, params):
+        self.params = params
+        self.sample_rate = params["sample_rate"]
+        self.segment_size = int(self.sample_rate * params["segment_size"])
+        self.hop_size = int(self.sample_rate * params["hop_size"])
+        self.frame_shift_mul = params["indexer"].get("frame_shift_mul", 1)
+        self.files = read_file_list(file_list) if isinstance(file_list, str) else list(file_list)
+
+    @property
+    def hop(self):
+        return self.hop_size // self.frame_shift_mul
+
+    def n_segments(self, n_samples):
+        n = max(n_samples, self.segment_size)
+        return (n - self.segment_size) // self.hop + 1
+
+    def load_pcm(self, index):
+        pcm, sr = read_wav_pcm16(self.files[index])
+        if sr != self.sample_rate:
+            raise NotImplementedError("resampling %d -> %d Hz is out of scope" % (sr, self.sample_rate))
+        return pcm
+
+    def unsafe_getitem(self, index):
+        log = get_logger()
+        t0 = time.time()
+        pcm = self.load_pcm(index)
+        t1 = time.time()
+        x = np.multiply(pcm, 1 / 32768, dtype=np.float32).T.copy()
+        if x.shape[0] == 2:                                    # musicdata.py:72-79
+            pow1 = np.mean((x[0] - x[1]) ** 2, dtype=np.float32)
+            pow2 = np.mean((x[0] + x[1]) ** 2, dtype=np.float32)
+            if pow1 > pow2 * 1000:
+                log.warning("fake stereo with opposite phase detected: %s", self.files[index])
+                x[1] *= -1
+        wav = x.mean(axis=0, dtype=np.float32)
+        if wav.shape[0] < self.segment_size:
+            wav = np.pad(wav, (0, self.segment_size - wav.shape[0]))
+        n_seg = (wav.shape[0] - self.segment_size) // self.hop + 1
+        seg = np.lib.stride_tricks.as_strided(wav, (n_seg, self.segment_size),
+                                              (wav.strides[0] * self.hop, wav.strides[0]))
+        seg = seg - seg.mean(axis=1, dtype=np.float32, keepdims=True)
+        log.info("load %.6fs stereo to mono %.6fs", t1 - t0, time.time() - t1)
+        return index, self.files[index], torch.from_numpy(np.ascontiguousarray(seg, dtype=np.float32))
+
+    def __getitem__(self, index):
+        try:
+            return self.unsafe_getitem(index)
+        except Exception as x:                                  # musicdata.py:95-101
+            get_logger().exception(x)
+            return index, self.files[index], torch.zeros(0, self.segment_size)
+
+    def __len__(self):
+        return len(self.files)

@@ -1,0 +1,362 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the oracle and the
+golden vectors generated from the reference.  Run with `pytest -m gpu` on an MI355X."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+import make_golden as mg
+from pfann_amd import synth
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def cfg(name):
+    return json.load(open(os.path.join(REPO, "configs", name + ".json")))
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch
+
+
+# ----------------------------------------------------------------------------- front-end
+def _segments(params):
+    from oracle import segmenter
+    pcm = synth.make_song(3, seconds=4.0)
+    segs = segmenter.segment(segmenter.pcm_to_mono(pcm[:, None]), 8000, 4000)           # 7 musical segments
+    noise = synth.normal(5, "t/noise", 8000).reshape(1, 8000) * 0.1
+    tone = (0.5 * np.sin(2 * np.pi * 1000.0 * np.arange(8000) / 8000.0)).astype(np.float32).reshape(1, 8000)
+    quiet = (segs[:1] * 1e-4).astype(np.float32)
+    zero = np.zeros((1, 8000), np.float32)
+    return np.concatenate([segs, noise, tone, quiet, zero]).astype(np.float32)
+
+
+def test_melspec_vs_oracle(torch_cuda):
+    """a2.  Tolerance: fp32 STFT implementations differ by ~1e-6 of the frame's peak
+    magnitude, which is a large RELATIVE error only in bins ~1e-7 below the peak; so the
+    log-mel is compared (i) tightly where the bin carries energy and (ii) in linear power
+    relative to the segment's peak everywhere."""
+    from oracle import melspec as om
+    from pfann_amd.engine import Engine
+    params = cfg("default")
+    eng = Engine(params, 0)
+    x = _segments(params)
+    got = eng.melspec(torch_cuda.as_tensor(x).cuda()).cpu().numpy()
+    ref32 = om.melspec(x, params)
+    ref64 = om.melspec_f64(x, params)
+    assert got.shape == ref32.shape == (x.shape[0], 256, 32)
+    p_got, p_ref = np.exp(got.astype(np.float64)), np.exp(ref64)
+    peak = p_ref.max(axis=(1, 2), keepdims=True)
+    lin_err = np.abs(p_got - p_ref) / peak
+    loud = ref64 > (np.log(peak) - 11.5)             # within 1e-5 of the segment's peak power
+    log_err = np.abs(got - ref64)
+    print("mel: max lin err/peak %.3e, max log err (loud bins) %.3e, vs fp32-oracle max %.3e" %
+          (lin_err.max(), log_err[loud].max(), np.abs(got - ref32)[loud].max()))
+    assert lin_err.max() < 2e-6
+    assert log_err[loud].max() < 2e-3
+    # the torch.stft restatement is no closer to the fp64 truth than the kernel is
+    assert log_err[loud].max() <= max(3 * np.abs(ref32 - ref64)[loud].max(), 1e-4)
+
+
+def test_melspec_fused_mean_removal_matches_operator_form(torch_cuda):
+    from oracle import segmenter
+    from pfann_amd.engine import Engine
+    params = cfg("default")
+    eng = Engine(params, 0)
+    pcm = synth.make_song(4, seconds=3.0)
+    wav = segmenter.pcm_to_mono(pcm[:, None]) + np.float32(0.05)      # DC offset: mean removal matters
+    segs = segmenter.segment(wav, 8000, 4000)
+    a = eng.melspec(torch_cuda.as_tensor(segs).cuda()).cpu().numpy()
+    lib = eng.lib
+    w = torch_cuda.as_tensor(wav).cuda()
+    out = torch_cuda.empty((segs.shape[0], 256, 32), device="cuda")
+    rc = lib.pfann_melspec(eng.handle, w.data_ptr(), segs.shape[0], 4000, 1, out.data_ptr(), None)
+    assert rc == 0
+    torch_cuda.cuda.synchronize()
+    b = out.cpu().numpy()
+    loud = a > a.max() - 11.5
+    assert np.abs(a - b)[loud].max() < 1e-3
+
+
+@pytest.mark.parametrize("variant", ["naf", "log10max"])
+def test_melspec_variants(torch_cuda, variant):
+    """naf_mode / log10 / spec_norm='max' (melspec.py:27-30,38-49) against the oracle."""
+    from oracle import melspec as om
+    from pfann_amd.engine import Engine
+    params = cfg("default")
+    if variant == "naf":
+        params.update(naf_mode=True, mel_log="log10")
+    else:
+        params.update(mel_log="log10", spec_norm="max")
+    eng = Engine(params, 0)
+    x = _segments(params)[:8]
+    got = eng.melspec(torch_cuda.as_tensor(x).cuda()).cpu().numpy()
+    ref = om.melspec(x, params)
+    err = np.abs(got - ref)
+    loud = ref > ref.max(axis=(1, 2), keepdims=True) - 4.5
+    print(variant, "max err loud", err[loud].max(), "overall", err.max())
+    assert err[loud].max() < 2e-3
+
+
+def test_pcm16_to_mono_and_segment_embed(torch_cuda):
+    """a1 on device: int16 -> mono (bit-exact), fake-stereo flip, then the fused
+    window/mean/mel/encode path equals the operator-seam path."""
+    from oracle import segmenter
+    from pfann_amd.engine import Engine
+    params = cfg("tiny")
+    eng = Engine(params, 0)
+    eng.load_state_dict(synth.make_state_dict(params))
+    ins = mg.segmenter_inputs()
+    for name in ("stereo12", "fakestereo12", "short", "len_8001"):
+        pcm = ins[name]
+        pcm2 = pcm if pcm.ndim == 2 else pcm[:, None]
+        want = segmenter.pcm_to_mono(pcm2)
+        got = eng.pcm16_to_mono(pcm2).cpu().numpy()
+        assert np.array_equal(got, want), name
+        segs = segmenter.segment(want, 8000, 4000)
+        e_ref = eng.encode(eng.melspec(torch_cuda.as_tensor(segs).cuda())).cpu().numpy()
+        e_fused = eng.embed_wav(torch_cuda.as_tensor(want).cuda(), 4000).cpu().numpy()
+        assert e_fused.shape == e_ref.shape == (segs.shape[0], 16)
+        assert np.abs(e_fused - e_ref).max() < 1e-4, name
+
+
+# ------------------------------------------------------------------------------- encoder
+@pytest.mark.parametrize("name", ["tiny", "nafstyle", "n640d64", "seg", "default"])
+def test_encoder_vs_reference_golden(torch_cuda, name):
+    """a3-a5: embeddings within 1e-4 of the reference's own outputs (golden), and every one
+    of the 16 sub-layer activations against the oracle."""
+    from oracle import encoder as oe
+    from pfann_amd.engine import Engine
+    z = np.load(os.path.join(G, "encoder_%s.npz" % name))
+    params = json.loads(str(z["params"]))
+    _, _, _, F, T = synth.model_dims(params)
+    sd = synth.make_state_dict(params, seed=123)
+    eng = Engine(params, 0, max_batch=8)
+    eng.load_state_dict(sd)
+    eng.debug_keep(True)
+    x = mg.encoder_inputs(F, T)
+    xt = torch_cuda.as_tensor(x).cuda()
+    emb = eng.encode(xt, norm=True).cpu().numpy()
+    taps_ref = []
+    oe.encode(x, sd, params, norm=True, taps=taps_ref)
+    worst = 0.0
+    for i, tr in enumerate(taps_ref):
+        tg = eng.debug_activation(i, x.shape[0])
+        assert tg.shape == tr.shape, (i, tg.shape, tr.shape)
+        e = np.abs(tg - tr).max()
+        worst = max(worst, e)
+        assert e < 2e-4 * max(1.0, np.abs(tr).max()), "sub-layer %d: max err %g" % (i, e)
+    raw = eng.encode(xt, norm=False).cpu().numpy()
+    print(name, "emb err %.3e raw err %.3e worst tap err %.3e" %
+          (np.abs(emb - z["emb"]).max(), np.abs(raw - z["raw"]).max(), worst))
+    assert np.abs(emb - z["emb"]).max() < 1e-4
+    assert np.abs(raw - z["raw"]).max() < 1e-4 * max(1.0, np.abs(z["raw"]).max())
+
+
+def test_encoder_batch_independence_and_chunking(torch_cuda):
+    """Batch 37 through max_batch=16 chunks equals per-sample results."""
+    from pfann_amd.engine import Engine
+    params = cfg("tiny")
+    eng = Engine(params, 0, max_batch=16)
+    eng.load_state_dict(synth.make_state_dict(params))
+    x = (-17 + 19 * synth.uniform01(1, "t/batch", 37 * 256 * 32)).reshape(37, 256, 32).astype(np.float32)
+    xt = torch_cuda.as_tensor(x).cuda()
+    all_ = eng.encode(xt).cpu().numpy()
+    one = np.concatenate([eng.encode(xt[i:i + 1]).cpu().numpy() for i in (0, 15, 16, 36)])
+    assert np.array_equal(all_[[0, 15, 16, 36]], one)
+    assert eng.encode(xt[:0]).shape == (0, 16)
+
+
+def test_missing_weights_fail_loudly(torch_cuda):
+    from pfann_amd import lib
+    from pfann_amd.engine import Engine
+    params = cfg("tiny")
+    eng = Engine(params, 0)
+    with pytest.raises(lib.PfannError):
+        eng.encode(torch_cuda.zeros(1, 256, 32).cuda())
+    sd = synth.make_state_dict(params)
+    with pytest.raises(lib.PfannError):
+        eng.load_state_dict({"f.convs.0.conv1.weight": sd["f.convs.0.conv1.weight"][:1]})
+    with pytest.raises(lib.PfannError):
+        eng.load_state_dict({"bogus.weight": np.zeros(3, np.float32)})
+
+
+# -------------------------------------------------------------------------------- search
+def _check_topk(torch, db, q, k):
+    from oracle import search as osr
+    from pfann_amd.database import DeviceIndex
+    d = q.shape[1]
+    idx = DeviceIndex(d, 0)
+    pos = np.array([0, db.shape[0]], np.int64)
+    idx.load(db, pos, 0)
+    D, I = idx.search(torch.as_tensor(q).cuda(), k)
+    D, I = D.cpu().numpy(), I.cpu().numpy()
+    Dr, Ir = osr.flat_ip_topk(q, db, k)
+    n = min(k, db.shape[0])
+    assert (I[:, n:] == -1).all() and (I[:, :n] >= 0).all()
+    assert (D[:, n:] == -np.finfo(np.float32).max).all()
+    if n == 0:
+        return D, I
+    # scores descending and equal to the oracle's to fp32 rounding
+    assert (np.diff(D[:, :n], axis=1) <= 0).all()
+    assert np.abs(D[:, :n] - Dr[:, :n]).max() < 2e-6
+    # identical label sets, except where the k-th score is tied to rounding
+    for r in range(q.shape[0]):
+        a, b = set(I[r, :n].tolist()), set(Ir[r, :n].tolist())
+        if a != b:
+            kth = Dr[r, n - 1]
+            for lab in a ^ b:
+                assert abs(float(db[lab] @ q[r]) - kth) < 2e-6, "row %d label %d not a k-th tie" % (r, lab)
+    # reported scores belong to the reported labels
+    chk = np.einsum("qkd,qd->qk", db[I[:, :n].clip(0)], q)
+    assert np.abs(chk - D[:, :n]).max() < 2e-6
+    return D, I
+
+
+@pytest.mark.parametrize("n,d,nq,k", [
+    (0, 128, 3, 10), (7, 128, 19, 100), (5000, 128, 19, 100), (8192, 64, 5, 1), (8193, 16, 33, 20),
+    (100000, 128, 19, 100), (300000, 128, 130, 100), (140000, 128, 64, 300), (200000, 64, 40, 1000),
+])
+def test_search_topk_exact(torch_cuda, n, d, nq, k):
+    db = synth.unit_rows(11, "t/db%d" % n, max(n, 1), d)[:n]
+    q = synth.unit_rows(12, "t/q%d" % n, nq, d)
+    if n > 100:                      # plant near-duplicates of db rows so real matches exist
+        q[::3] = db[(np.arange(0, nq, 3) * 7919) % n] * 0.8 + 0.2 * q[::3]
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+    _check_topk(torch_cuda, db, q.astype(np.float32), k)
+
+
+def test_search_topk_clustered_and_duplicate_rows(torch_cuda):
+    """Non-iid db: long runs of near-identical rows (one 'song') and exact duplicates; the
+    sampled thresholds must stay valid lower bounds (never lose a true top-k row)."""
+    d, n = 128, 120000
+    base = synth.unit_rows(21, "t/cl", n, d)
+    c = synth.unit_rows(22, "t/center", 1, d)
+    base[40000:40600] = c + 0.05 * base[40000:40600]       # 600 rows around one centre
+    base[70000:70300] = base[70000]                        # 300 exact duplicates
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    q = np.concatenate([c, base[70000:70001], synth.unit_rows(23, "t/q", 17, d)]).astype(np.float32)
+    _check_topk(torch_cuda, base.astype(np.float32), q, 100)
+
+
+def test_topk_merge(torch_cuda):
+    from pfann_amd.database import DeviceIndex
+    idx = DeviceIndex(128, 0)
+    rng = np.random.default_rng(3)
+    S = rng.standard_normal((9, 800)).astype(np.float32)
+    L = rng.permutation(10 ** 6)[:9 * 800].reshape(9, 800).astype(np.int64) + (1 << 33)
+    L[0, :700] = -1
+    D, I = idx.merge_topk(torch_cuda.as_tensor(S).cuda(), torch_cuda.as_tensor(L).cuda(), 100)
+    D, I = D.cpu().numpy(), I.cpu().numpy()
+    for r in range(9):
+        ok = L[r] >= 0
+        o = np.argsort(-S[r][ok], kind="stable")[:100]
+        assert np.array_equal(I[r, :len(o)], L[r][ok][o])
+        assert np.array_equal(D[r, :len(o)], S[r][ok][o])
+
+
+# --------------------------------------------------------------------- sequence matcher
+DB_CASES = ["clean_hit", "negative_offset", "past_end", "k_gt_ntotal", "duplicate_songs",
+            "nonpositive_best", "no_candidates", "frame_shift_mul2", "random_noisy"]
+
+
+def _index_for(z, name):
+    from oracle import seqscore as osq
+    from pfann_amd.database import DeviceIndex
+    db = z[name + "_db"]
+    pos = osq.song_pos_from_key(z[name + "_key"])
+    idx = DeviceIndex(db.shape[1], 0)
+    idx.load(db, pos, 0)
+    return idx, db, pos
+
+
+@pytest.mark.parametrize("name", DB_CASES)
+def test_match_python_path_vs_reference_golden(torch_cuda, name):
+    """a8-a9, decisions exact: (song, time) identical to the reference's
+    query_embeddings_base on the same (query, labels); score to fp32 rounding."""
+    from pfann_amd.database import _fine_to_time
+    z = np.load(os.path.join(G, "database.npz"))
+    idx, db, pos = _index_for(z, name)
+    q, labels, fsm = z[name + "_q"], z[name + "_labels"], int(z[name + "_fsm"])
+    res, ss = idx.match(torch_cuda.as_tensor(q).cuda(), torch_cuda.as_tensor(labels).cuda(), [0], [q.shape[0]],
+                        fsm, 0.0, 0, False, True)
+    r = res[0]
+    want_song, want_sec, want_score = int(z[name + "_song"]), float(z[name + "_sec"]), float(z[name + "_score"])
+    assert int(r["song"]) == want_song
+    if want_song >= 0:
+        assert (int(r["offset"]) - int(r["shift"]) / fsm) * 0.5 == want_sec
+        assert abs(float(r["score"]) - want_score) < 1e-6
+    else:
+        assert float(r["score"]) == -np.inf
+    got_ss = ss.cpu().numpy()[0]
+    got_ss[:, 1] = _fine_to_time(got_ss[:, 1].astype(np.int64), fsm, 0.5)
+    assert np.allclose(got_ss, z[name + "_song_score"], atol=1e-6)
+    assert np.array_equal(got_ss[:, 1], z[name + "_song_score"][:, 1])
+
+
+@pytest.mark.parametrize("name", DB_CASES)
+def test_seq_score_c_abi_vs_oracle(torch_cuda, name):
+    """The reference's ctypes seam (database.py:15-32,178-189) against the C restatement of
+    cpp/seqscore.cpp, incl. score_alpha > 0."""
+    from oracle import native
+    from pfann_amd import lib as L
+    z = np.load(os.path.join(G, "database.npz"))
+    idx, db, pos = _index_for(z, name)
+    q = np.ascontiguousarray(z[name + "_q"], np.float32)
+    labels = np.ascontiguousarray(z[name + "_labels"], np.int64)
+    fsm = int(z[name + "_fsm"])
+    lib = L.load()
+    assert lib.version() == 20220625002
+    for alpha in (0.0, 3.0):
+        ss = np.zeros((pos.shape[0] - 1, 2), np.float32)
+        best = lib.seq_score(idx.handle, pos.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), pos.shape[0] - 1,
+                             q.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), q.shape[0],
+                             labels.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), labels.shape[1],
+                             ss.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), fsm, alpha)
+        wbest, wss = native.seq_score(db, pos, q, labels, fsm, alpha)
+        assert best == wbest, (name, alpha, L.last_error())
+        assert np.array_equal(ss[:, 1], wss[:, 1])
+        assert np.allclose(ss[:, 0], wss[:, 0], atol=2e-6)
+
+
+def test_match_batched_random_vs_oracle(torch_cuda):
+    """Many queries in one launch, real search output as labels, vs the python-path oracle."""
+    from oracle import seqscore as osq
+    from pfann_amd.database import DeviceIndex
+    d = 128
+    key = [int(x) for x in (30 + 60 * synth.uniform01(31, "t/key", 300))]
+    key[7] = 0
+    db = synth.unit_rows(32, "t/mdb", sum(key), d)
+    pos = osq.song_pos_from_key(key)
+    idx = DeviceIndex(d, 0)
+    idx.load(db, pos, 0)
+    qs, qstart, qlen = [], [], []
+    n = 0
+    for j in range(40):
+        s = (j * 37) % 300
+        if key[s] < 25:
+            s += 1
+        ln = 5 + (j % 15)
+        off = (j * 13) % (key[s] - ln)
+        qq = db[pos[s] + off: pos[s] + off + ln] + (0.3 + 0.03 * j) * synth.unit_rows(100 + j, "t/qn", ln, d)
+        qs.append(qq / np.linalg.norm(qq, axis=1, keepdims=True))
+        qstart.append(n)
+        qlen.append(ln)
+        n += ln
+    q = np.concatenate(qs).astype(np.float32)
+    qt = torch_cuda.as_tensor(q).cuda()
+    D, I = idx.search(qt, 100)
+    res, _ = idx.match(qt, I, qstart, qlen, 1, 0.0, 0, False, False)
+    In = I.cpu().numpy()
+    for j in range(40):
+        sl = slice(qstart[j], qstart[j] + qlen[j])
+        score, (song, sec), _ = osq.query_embeddings_base(q[sl], In[sl], db, pos, 0.5, 1)
+        assert int(res[j]["song"]) == song and int(res[j]["offset"]) * 0.5 == sec, j
+        assert abs(float(res[j]["score"]) - score) < 1e-6
