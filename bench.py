@@ -1,0 +1,256 @@
+#!/usr/bin/env python
+"""bench.py -- the reference's headline metric on MI355X: query segments/sec (+ top-1
+hit-rate) for 10 s @ SNR 0 queries against a 1 M-segment fingerprint database.
+
+One "step" = one pass of the whole hot path over one batch of synthetic queries whose
+int16 PCM is already resident in HBM:
+    PCM -> mono float -> 1 s windows (0.5 s hop) -> log-mel -> CNN encoder -> unit-norm
+    128-d fingerprints -> exact inner-product top-100 over the db -> sequence matcher
+    -> (song, offset) decisions on the host.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: the db is sharded by songs over the ranks (strong scaling: same db, same query batch);
+each rank embeds 1/N of the query windows, embeddings and per-shard top-k are all-gathered
+over RCCL, each rank sequence-scores the candidates it owns.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+SEG_PER_SONG = 59            # 30 s song, 1 s window, 0.5 s hop (reference musicdata.py:87)
+QUERY_SEGS = 19              # 10 s query (matcher.py:109)
+GEMM_FLOP_PER_SEG = 2 * (291.02e6 - 1.57e6 - 0.037e6)   # the 15 implicit-GEMM convs
+ENC_FLOP_PER_SEG = 0.58204e9                             # whole encoder
+PEAK_F32_MFMA = 157.3        # TFLOP/s, MI355X_MICROARCH.md
+PEAK_HBM = 8000.0            # GB/s
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--queries", type=int, default=256, help="10 s queries per step (whole job)")
+    ap.add_argument("--db-songs", type=int, default=16950, help="16950 x 59 = 1,000,050 segments")
+    ap.add_argument("--real-songs", type=int, default=48)
+    ap.add_argument("--snr", type=float, default=0.0)
+    ap.add_argument("--max-batch", type=int, default=1024)
+    ap.add_argument("--cpu-queries", type=int, default=12, help="bounded sample for the CPU baseline")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from pfann_amd import lib as plib
+    from pfann_amd import synth
+    from pfann_amd.database import DeviceIndex
+    from pfann_amd.dist import ShardedIndex, all_gather_ragged, shard_songs, split_even
+    from pfann_amd.engine import Engine
+    from pfann_amd.utils import read_config
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node = --gpus"
+    plib.require_gpu()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    params = read_config(os.path.join(REPO, "configs", "default.json"))
+    d, k = params["model"]["d"], params["indexer"]["top_k"]
+    t_setup = time.time()
+    eng = Engine(params, local_rank, max_batch=args.max_batch)
+    eng.load_state_dict(synth.make_state_dict(params, seed=123))
+
+    # ---------------------------------------------------------------- database (untimed)
+    n_songs = args.db_songs
+    song_pos = np.arange(n_songs + 1, dtype=np.int64) * SEG_PER_SONG
+    n_rows = int(song_pos[-1])
+    real_ids = np.unique(np.linspace(0, n_songs - 1, args.real_songs).astype(np.int64))
+    songs = {int(s): synth.make_song(int(s)) for s in real_ids}
+    s_lo, s_hi = shard_songs(song_pos, world)[rank]
+    r_lo, r_hi = int(song_pos[s_lo]), int(song_pos[s_hi])
+    gen = torch.Generator(device=dev)
+    shard = torch.empty((r_hi - r_lo, d), device=dev, dtype=torch.float32)
+    blk = 1 << 18
+    for b0 in range(r_lo, r_hi, blk):                      # seeded filler rows: unit-norm Gaussian
+        b1 = min(b0 + blk, r_hi)
+        gen.manual_seed(1234567 + b0)
+        x = torch.randn((b1 - b0, d), device=dev, generator=gen)
+        shard[b0 - r_lo:b1 - r_lo] = x / x.norm(dim=1, keepdim=True)
+    for s in real_ids:                                     # real songs embedded by the hot path itself
+        if s_lo <= s < s_hi:
+            e = eng.embed_wav(eng.pcm16_to_mono(songs[int(s)]), 4000)
+            assert e.shape[0] == SEG_PER_SONG
+            shard[int(song_pos[s]) - r_lo: int(song_pos[s + 1]) - r_lo] = e
+    index = DeviceIndex(d, local_rank)
+    index.load(shard, song_pos, r_lo)
+    if world > 1:
+        sharded = ShardedIndex(index, song_pos, k, 1, 0.0)
+
+    # ----------------------------------------------------------------- queries (untimed)
+    Q = args.queries
+    q_song = [int(real_ids[j % len(real_ids)]) for j in range(Q)]
+    q_pcm, q_off = [], []
+    for j in range(Q):
+        pcm, off = synth.make_query(songs[q_song[j]], j, 10.0, args.snr)
+        q_pcm.append(pcm)
+        q_off.append(off)
+    q_len = q_pcm[0].shape[0]
+    my_q = split_even(Q, world)[rank]
+    q_counts = [(hi - lo) * QUERY_SEGS for lo, hi in split_even(Q, world)]
+    pcm_dev = torch.as_tensor(np.concatenate(q_pcm[my_q[0]:my_q[1]]) if my_q[1] > my_q[0]
+                              else np.zeros(0, np.int16)).to(dev)          # resident in HBM
+    starts = (np.arange(my_q[1] - my_q[0], dtype=np.int64)[:, None] * q_len +
+              np.arange(QUERY_SEGS, dtype=np.int64)[None, :] * 4000).reshape(-1)
+    starts_dev = torch.as_tensor(starts).to(dev)
+    qstart = np.arange(Q, dtype=np.int64) * QUERY_SEGS
+    qlen = np.full(Q, QUERY_SEGS, dtype=np.int32)
+    torch.cuda.synchronize()
+    log("[rank %d] setup %.1fs: shard rows %d (songs %d..%d), %d queries/step" %
+        (rank, time.time() - t_setup, r_hi - r_lo, s_lo, s_hi, Q))
+
+    def step():
+        wav = eng.pcm16_to_mono(pcm_dev)
+        emb = eng.embed_windows(wav, starts_dev)
+        if world > 1:
+            emb = all_gather_ragged(emb, q_counts)
+            return sharded.query_batch(emb, qstart, qlen), emb
+        D, I = index.search(emb, k)
+        res, _ = index.match(emb, I, qstart, qlen)
+        return res, emb
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    lib = plib.load()
+    prof = not args.no_prof
+    if prof:
+        lib.pfann_prof_reset()
+        lib.pfann_prof_enable(1)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res, emb = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if prof:
+        lib.pfann_prof_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    n_seg = Q * QUERY_SEGS
+    value = n_seg * args.steps / elapsed
+
+    # ------------------------------------------------------------ per-kernel event times
+    kernels = {}
+    if prof:
+        import ctypes
+        buf = ctypes.create_string_buffer(4096)
+        lib.pfann_prof_tags(buf, 4096)
+        for tag in buf.value.decode().split(","):
+            if not tag:
+                continue
+            cnt = ctypes.c_int64(0)
+            ms = lib.pfann_prof_elapsed_ms(tag.encode(), ctypes.byref(cnt))
+            kernels[tag] = {"ms_per_step": ms / args.steps, "launches_per_step": cnt.value / args.steps,
+                            "avg_us": 1e3 * ms / max(cnt.value, 1)}
+    my_windows = len(starts)
+    roofline = None
+    if "conv_gemm" in kernels:
+        kg = kernels["conv_gemm"]
+        tf = my_windows * GEMM_FLOP_PER_SEG / (kg["ms_per_step"] * 1e-3) / 1e12
+        roofline = {"kernel": "conv_gemm_kernel (15 implicit-GEMM convs, fp32 MFMA 32x32x2)", "bound": "mfma",
+                    "achieved": round(tf, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
+                    "frac": round(tf / PEAK_F32_MFMA, 4), "traffic": None,
+                    "avg_launch_us": round(kg["avg_us"], 1),
+                    "flop_per_launch_avg": my_windows * GEMM_FLOP_PER_SEG / kg["launches_per_step"]}
+    if "scan_topk" in kernels:
+        ks = kernels["scan_topk"]
+        gbs = (r_hi - r_lo) * d * 4 / (ks["avg_us"] * 1e-6) / 1e9
+        kernels["scan_topk"].update({"algorithmic_GBps": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM, 4),
+                                     "TFLOPs": round(2.0 * n_seg * (r_hi - r_lo) * d / (ks["avg_us"] * 1e-6) / 1e12, 2)})
+
+    # ------------------------------------------------------------------------- hit-rate
+    hits = near = exact = 0
+    for j in range(Q):
+        if int(res[j]["song"]) == q_song[j]:
+            hits += 1
+            tm = int(res[j]["offset"]) * 0.5
+            near += abs(tm - q_off[j]) <= 0.5
+            exact += abs(tm - q_off[j]) <= 0.25
+    # ------------------------------------------- CPU baseline + decision parity (rank 0)
+    cpu = None
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import encoder as oe
+        from oracle import melspec as om
+        from oracle import native, search as osr, segmenter as osg
+        nq_cpu = min(args.cpu_queries, Q)
+        db_host = shard.cpu().numpy()
+        sd = synth.make_state_dict(params, seed=123)
+        native.lib()
+        tc = time.perf_counter()
+        agree = 0
+        for j in range(nq_cpu):
+            segs = osg.segment(osg.pcm_to_mono(q_pcm[j][:, None]), 8000, 4000)
+            e = oe.encode(om.melspec(segs, params), sd, params)
+            Dc, Ic = osr.flat_ip_topk_blas(e, db_host, k)
+            best, ss = native.seq_score(db_host, song_pos, e, Ic, 1, 0.0)
+            agree += (best == int(res[j]["song"]) and int(ss[best, 1]) == int(res[j]["offset"]))
+        tcpu = time.perf_counter() - tc
+        cpu = {"value": round(nq_cpu * QUERY_SEGS / tcpu, 2), "unit": "segments/s",
+               "cores": torch.get_num_threads(), "kind": "port",
+               "sample": "%d of the same 10 s queries (%d segments) vs the same %d-row db: torch-CPU "
+                         "mel+encoder, BLAS sgemm + argpartition top-%d, C seq_score; host has %d logical cores"
+                         % (nq_cpu, nq_cpu * QUERY_SEGS, n_rows, k, os.cpu_count())}
+        parity = {"queries": nq_cpu, "identical_song_and_offset": int(agree)}
+
+    if rank == 0:
+        out = {
+            "metric": "query segments/sec, 10 s @ SNR 0 queries vs 1M-segment db (exact flat IP top-100 + sequence match)",
+            "value": round(value, 1), "unit": "segments/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "1M-seg db (%d songs x %d segs, %d real synthetic songs + unit-norm filler rows), "
+                                   "%d x 10 s queries/step at SNR %g dB (%d segments), configs/default.json encoder "
+                                   "(d=128,h=1024,u=32,fuller), top_k=100" %
+                                   (n_songs, SEG_PER_SONG, len(real_ids), Q, args.snr, n_seg),
+                       "db_rows": n_rows, "queries_per_step": Q, "segments_per_step": n_seg,
+                       "parallelism": "song-sharded db x%d" % world, "max_batch": args.max_batch},
+            "top1_hit_rate": round(hits / Q, 4), "top1_near_0.5s": round(near / Q, 4),
+            "top1_exact_0.25s": round(exact / Q, 4),
+            "roofline": roofline, "cpu_baseline": cpu, "oracle_decision_parity": parity,
+            "kernels": {t: {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in v.items()}
+                        for t, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

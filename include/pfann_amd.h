@@ -100,6 +100,11 @@ int pfann_encode(pfann_ctx *ctx, const float *mel_dev, int64_t B, float *emb_dev
 int pfann_segment_embed(pfann_ctx *ctx, const float *wav_dev, int64_t B, int64_t seg_stride,
                         float *emb_dev, int normalize, void *stream);
 
+/* Same, with explicit window starts: window b = wav_dev[starts_dev[b] .. +segment_len)
+ * (many queries concatenated in one buffer; windows never straddle two recordings). */
+int pfann_segment_embed_at(pfann_ctx *ctx, const float *wav_dev, const int64_t *starts_dev,
+                           int64_t B, float *emb_dev, int normalize, void *stream);
+
 /* int16 interleaved PCM -> float32 mono (x/32768, fake-stereo fix, channel mean). */
 int pfann_pcm16_to_mono(pfann_ctx *ctx, const int16_t *pcm_dev, int64_t n_frames, int n_ch,
                         float *wav_dev, void *stream);

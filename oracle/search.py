@@ -20,3 +20,25 @@ def flat_ip_topk(query, db, k):
     D[:, :kk] = np.take_along_axis(s, order, axis=1)
     I[:, :kk] = order
     return D, I
+
+
+def flat_ip_topk_blas(query, db, k):
+    """Same result as flat_ip_topk, via BLAS sgemm + argpartition (the faiss-cpu IndexFlatIP
+    stand-in named in BASELINE.md §3 for CPU-baseline timing)."""
+    query = np.ascontiguousarray(query, dtype=np.float32)
+    nq, n = query.shape[0], db.shape[0]
+    D = np.full((nq, k), -np.finfo(np.float32).max, dtype=np.float32)
+    I = np.full((nq, k), -1, dtype=np.int64)
+    if n == 0:
+        return D, I
+    s = query @ db.T
+    kk = min(k, n)
+    if kk < n:
+        part = np.argpartition(-s, kk - 1, axis=1)[:, :kk]
+    else:
+        part = np.tile(np.arange(n), (nq, 1))
+    ps = np.take_along_axis(s, part, axis=1)
+    o = np.lexsort((part, -ps), axis=1)
+    D[:, :kk] = np.take_along_axis(ps, o, axis=1)
+    I[:, :kk] = np.take_along_axis(part, o, axis=1)
+    return D, I

@@ -272,7 +272,7 @@ int pfann_melspec(pfann_ctx *c, const float *segs, int64_t B, int64_t seg_stride
                   void *stream) {
     PF_HIP(hipSetDevice(c->device));
     if (!c->mel_ready) { set_error("pfann_melspec: mel filterbank not set"); return -5; }
-    return launch_melspec(c->mel, segs, B, seg_stride, remove_mean, out, (hipStream_t)stream);
+    return launch_melspec(c->mel, segs, B, seg_stride, nullptr, remove_mean, out, (hipStream_t)stream);
 }
 
 static int keep_tap(pfann_ctx *c, int idx, const float *act, int64_t B, hipStream_t s) {
@@ -327,8 +327,8 @@ int pfann_encode(pfann_ctx *c, const float *mel, int64_t B, float *emb, int norm
     return 0;
 }
 
-int pfann_segment_embed(pfann_ctx *c, const float *wav, int64_t B, int64_t seg_stride, float *emb, int normalize,
-                        void *stream) {
+static int segment_embed_impl(pfann_ctx *c, const float *wav, int64_t B, int64_t seg_stride, const int64_t *starts,
+                              float *emb, int normalize, void *stream) {
     PF_HIP(hipSetDevice(c->device));
     if (!c->mel_ready) { set_error("pfann_segment_embed: mel filterbank not set"); return -5; }
     if (pfann_weights_missing(c) != 0) { set_error("pfann_segment_embed: %d state_dict tensors not loaded", pfann_weights_missing(c)); return -5; }
@@ -336,10 +336,21 @@ int pfann_segment_embed(pfann_ctx *c, const float *wav, int64_t B, int64_t seg_s
     if (ensure_workspace(c, true)) return -1;
     for (int64_t b0 = 0; b0 < B; b0 += c->cfg.max_batch) {
         const int64_t nb = std::min<int64_t>(c->cfg.max_batch, B - b0);
-        if (launch_melspec(c->mel, wav + b0 * seg_stride, nb, seg_stride, 1, c->mel_buf, s)) return -1;
+        const float *src = starts ? wav : wav + b0 * seg_stride;
+        if (launch_melspec(c->mel, src, nb, seg_stride, starts ? starts + b0 : nullptr, 1, c->mel_buf, s)) return -1;
         if (encode_chunk(c, c->mel_buf, nb, emb + b0 * c->cfg.d, normalize, s)) return -1;
     }
     return 0;
+}
+
+int pfann_segment_embed(pfann_ctx *c, const float *wav, int64_t B, int64_t seg_stride, float *emb, int normalize,
+                        void *stream) {
+    return segment_embed_impl(c, wav, B, seg_stride, nullptr, emb, normalize, stream);
+}
+
+int pfann_segment_embed_at(pfann_ctx *c, const float *wav, const int64_t *starts_dev, int64_t B, float *emb,
+                           int normalize, void *stream) {
+    return segment_embed_impl(c, wav, B, 0, starts_dev, emb, normalize, stream);
 }
 
 int pfann_pcm16_to_mono(pfann_ctx *c, const int16_t *pcm, int64_t n_frames, int n_ch, float *wav, void *stream) {

@@ -17,7 +17,7 @@ struct MelPlan {
     int max_nnz_row;
 };
 int launch_melspec(const MelPlan &mp, const float *segs, int64_t B, int64_t seg_stride,
-                   int remove_mean, float *out, hipStream_t s);
+                   const int64_t *starts, int remove_mean, float *out, hipStream_t s);
 int launch_pcm16_to_mono(const int16_t *pcm, int64_t n_frames, int n_ch, float *wav,
                          float *scratch2, hipStream_t s);
 

@@ -15,6 +15,7 @@ namespace pfann {
 struct MelArgs {
     const float *segs; float *out;
     int64_t seg_stride;
+    const int64_t *starts;   // optional [B]: window b begins at segs + starts[b]
     int seg_len, n_fft, hop, n_mels, n_frames, log2n;
     int power, pad_reflect, log_mode, spec_norm_max, remove_mean;
     float log_eps;
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs a) {
     float *red = tile + a.n_mels * (a.n_frames + 1);  // [8]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float *x = a.segs + (int64_t)blockIdx.x * a.seg_stride;
+    const float *x = a.segs + (a.starts ? a.starts[blockIdx.x] : (int64_t)blockIdx.x * a.seg_stride);
 
     for (int j = tid; j < M; j += 256) { const float2 t = a.twiddle[j]; tw_re[j] = t.x; tw_im[j] = t.y; }
 
@@ -160,11 +161,11 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs a) {
         o[i] = tile[(i / a.n_frames) * (a.n_frames + 1) + (i % a.n_frames)] - sub;
 }
 
-int launch_melspec(const MelPlan &mp, const float *segs, int64_t B, int64_t seg_stride, int remove_mean,
-                   float *out, hipStream_t s) {
+int launch_melspec(const MelPlan &mp, const float *segs, int64_t B, int64_t seg_stride, const int64_t *starts,
+                   int remove_mean, float *out, hipStream_t s) {
     if (B <= 0) return 0;
     MelArgs a;
-    a.segs = segs; a.out = out; a.seg_stride = seg_stride;
+    a.segs = segs; a.out = out; a.seg_stride = seg_stride; a.starts = starts;
     a.seg_len = mp.seg_len; a.n_fft = mp.n_fft; a.hop = mp.hop; a.n_mels = mp.n_mels;
     a.n_frames = mp.n_frames; a.log2n = mp.log2n;
     a.power = mp.power; a.pad_reflect = mp.pad_reflect; a.log_mode = mp.log_mode;

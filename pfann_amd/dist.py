@@ -1,0 +1,119 @@
+"""Song-sharded retrieval across the GPUs of one node (new capability, the
+reference is single-device).  One process per GPU, `torch.distributed` backend "nccl"
+(= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
+
+Per query batch there is exactly one exchange step, two tiny collectives:
+  1. every rank scans ITS shard for all query rows -> all_gather of the per-shard top-k
+     (score f32, global label i64)[Q,k] -> every rank merges to the GLOBAL top-k (needed for
+     parity: the reference's candidates come from the global list);
+  2. every rank sequence-scores the candidates whose song it owns -> all_gather of the
+     per-rank best (score, song, offset, shift) -> lexicographic argmax in the reference's
+     candidate order (ties -> smallest (shift, song, offset)).
+Shards are contiguous song ranges balanced by row count and never split a song, because a
+sequence score only touches consecutive rows of one song.
+
+The compute backend is any object with the DeviceIndex interface
+(search / merge_topk / match); the product uses pfann_amd.database.DeviceIndex (HIP).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_songs(song_pos, world):
+    """-> list of (song_lo, song_hi) per rank: contiguous, balanced by rows, whole songs."""
+    song_pos = np.asarray(song_pos, dtype=np.int64)
+    n_songs = song_pos.shape[0] - 1
+    total = int(song_pos[-1])
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r // world
+        s = int(np.searchsorted(song_pos, target, side="left"))
+        s = min(max(s, cuts[-1]), n_songs)
+        cuts.append(s)
+    cuts.append(n_songs)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def split_even(n, world):
+    """-> list of (lo, hi) splitting range(n) into `world` near-equal contiguous parts."""
+    base, rem = divmod(n, world)
+    out, lo = [], 0
+    for r in range(world):
+        hi = lo + base + (1 if r < rem else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def all_gather_rows(x, group=None):
+    """all_gather of equally shaped tensors -> [world, *x.shape]."""
+    world = dist.get_world_size(group)
+    out = torch.empty((world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out.view(-1), x.contiguous().view(-1), group=group)
+    return out
+
+
+def all_gather_ragged(x, counts, group=None):
+    """Rows split unevenly over ranks (counts[r] rows on rank r) -> concatenated [sum, ...]."""
+    world = dist.get_world_size(group)
+    mx = max(counts) if counts else 0
+    pad = torch.zeros((mx,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    pad[: x.shape[0]] = x
+    g = all_gather_rows(pad, group)
+    return torch.cat([g[r, : counts[r]] for r in range(world)], dim=0)
+
+
+class ShardedIndex:
+    def __init__(self, backend, song_pos, top_k, frame_shift_mul=1, score_alpha=0.0, group=None):
+        self.b = backend
+        self.song_pos = np.asarray(song_pos, dtype=np.int64)
+        self.k = top_k
+        self.fsm = frame_shift_mul
+        self.alpha = score_alpha
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    @staticmethod
+    def my_rows(song_pos, rank, world):
+        lo, hi = shard_songs(song_pos, world)[rank]
+        return int(song_pos[lo]), int(song_pos[hi])
+
+    def search_global(self, q):
+        """q [Q, d] (identical on all ranks) -> global (D, I) [Q, k], identical on all ranks."""
+        D, I = self.b.search(q, self.k)
+        gD = all_gather_rows(D, self.group)                       # [G, Q, k]
+        gI = all_gather_rows(I, self.group)
+        Q = q.shape[0]
+        S = gD.permute(1, 0, 2).reshape(Q, self.world * self.k)   # rank-major: ascending labels on ties
+        L = gI.permute(1, 0, 2).reshape(Q, self.world * self.k)
+        return self.b.merge_topk(S, L, self.k)
+
+    def query_batch(self, q, qstart, qlen):
+        """-> structured array (song, offset, shift, score) per query, identical on all ranks."""
+        D, I = self.search_global(q)
+        res, _ = self.b.match(q, I, qstart, qlen, self.fsm, self.alpha, 0, True, False)
+        nQ = len(qlen)
+        dev = q.device
+        pack = torch.empty((nQ, 4), dtype=torch.float64, device=dev)
+        pack[:, 0] = torch.as_tensor(res["score"].copy(), device=dev)
+        pack[:, 1] = torch.as_tensor(res["song"].astype(np.float64), device=dev)
+        pack[:, 2] = torch.as_tensor(res["offset"].astype(np.float64), device=dev)
+        pack[:, 3] = torch.as_tensor(res["shift"].astype(np.float64), device=dev)
+        allp = all_gather_rows(pack, self.group).cpu().numpy()     # [G, nQ, 4]
+        out = np.zeros(nQ, dtype=[("song", "<i4"), ("offset", "<i4"), ("shift", "<i4"), ("score", "<f8")])
+        for j in range(nQ):
+            best = None
+            for r in range(self.world):
+                sc, song, off, sh = allp[r, j]
+                if song < 0:
+                    continue
+                key = (-sc, sh, song, off)                        # max score, then loop order
+                if best is None or key < best[0]:
+                    best = (key, int(song), int(off), int(sh), sc)
+            if best is None:
+                out[j] = (-1, 0, 0, -np.inf)
+            else:
+                out[j] = (best[1], best[2], best[3], best[4])
+        return out

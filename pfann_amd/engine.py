@@ -156,8 +156,18 @@ class Engine:
                                                   1 if norm else 0, self._stream()), "pfann_segment_embed")
         return out
 
-    def embed_windows(self, wav, starts_stride, n_seg, norm=True):
-        return self.embed_wav(wav, starts_stride, n_seg, norm)
+    def embed_windows(self, wav, starts, norm=True):
+        """wav: device float mono buffer (many recordings back to back); starts: int64 window
+        start offsets (device tensor or array) -> [len(starts), d]."""
+        w = self._prep(wav).reshape(-1)
+        st = starts if isinstance(starts, torch.Tensor) else torch.as_tensor(np.asarray(starts, np.int64))
+        st = st.to(self.device, torch.int64).contiguous()
+        B = st.shape[0]
+        out = torch.empty((B, self.d), device=self.device, dtype=torch.float32)
+        if B:
+            _l.check(self.lib.pfann_segment_embed_at(self.handle, w.data_ptr(), st.data_ptr(), B, out.data_ptr(),
+                                                     1 if norm else 0, self._stream()), "pfann_segment_embed_at")
+        return out
 
     def pcm16_to_mono(self, pcm):
         """int16 [n] or [n, ch] (torch / numpy) -> float32 mono [n] on device."""

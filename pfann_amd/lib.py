@@ -41,6 +41,7 @@ SYMBOLS = {
     "pfann_melspec": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "pfann_encode": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p]),
     "pfann_segment_embed": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p]),
+    "pfann_segment_embed_at": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p]),
     "pfann_pcm16_to_mono": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "pfann_debug_activation": (c_int64, [c_void_p, c_int, c_int64, c_void_p, c_int64]),
     "pfann_debug_keep": (None, [c_void_p, c_int]),

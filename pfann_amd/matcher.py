@@ -1,0 +1,96 @@
+"""Matcher CLI, drop-in for the reference's matcher.py:
+    python matcher.py <query list> <database dir> <result file>
+
+Same argv and outputs (matcher.py:34-42,84,158-163): `<result>` TSV "query\\tanswer",
+`<result-stem>_detail.csv` with header query,answer,score,time,part_scores, and
+`<result>.bin` with one float32[n_songs,2] (score, time) block per query; load errors give
+an "error" row with -inf score and a zero block (matcher.py:94-107).  Queries are embedded,
+searched (exact flat IP top-k) and sequence-matched on the MI355X, many queries per launch.
+"""
+import csv
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from .builder import embed_files
+from .database import Database
+from .engine import Engine
+from .musicdata import MusicDataset
+from .utils import StageTimer, read_config
+
+
+def main(argv=None):
+    argv = sys.argv if argv is None else argv
+    if len(argv) < 4:
+        print("Usage: python %s <query list> <database dir> <result file>" % argv[0])
+        return 1
+    file_list_for_query, dir_for_db, result_file = argv[1], argv[2], argv[3]
+    result_file2 = os.path.splitext(result_file)[0] + "_detail.csv"
+    result_file_score = result_file + ".bin"
+    params = read_config(os.path.join(dir_for_db, "configs.json"))
+
+    print("loading model...")
+    engine = Engine(params, 0, max_batch=int(os.environ.get("PFANN_MAX_BATCH", "1024")))
+    engine.load_state_dict(torch.load(os.path.join(dir_for_db, "model.pt"), map_location="cpu"))
+    print("model loaded")
+    print("loading database...")
+    db = Database(dir_for_db, params["indexer"], params["hop_size"], device=0, d=params["model"]["d"])
+    print("database loaded")
+
+    dataset = MusicDataset(file_list_for_query, params)
+    timer = StageTimer()
+    tm_0 = time.time()
+    group = int(os.environ.get("PFANN_QUERY_GROUP", "64"))
+    with open(result_file, "w", encoding="utf8", newline="\n") as fout, \
+            open(result_file2, "w", encoding="utf8", newline="\n") as fout2, \
+            open(result_file_score, "wb") as fout_score:
+        detail_writer = csv.writer(fout2)
+        detail_writer.writerow(["query", "answer", "score", "time", "part_scores"])
+        n_songs = len(db.songList)
+
+        def emit(items):
+            """items: list of (index, n_seg, emb) in list order."""
+            good = [(i, n, e) for i, n, e in items if n]
+            results = {}
+            if good:
+                with timer.stage("search+rerank"):
+                    emb = torch.cat([e for _, _, e in good])
+                    qlen = [n for _, n, _ in good]
+                    qstart = np.concatenate([[0], np.cumsum(qlen)[:-1]])
+                    out = db.query_batch(emb, qstart, qlen, want_song_scores=True)
+                for (i, _, _), r in zip(good, out):
+                    results[i] = r
+            with timer.stage("output answer"):
+                for i, n, _ in items:
+                    name = dataset.files[i]
+                    if n == 0:                                            # matcher.py:94-107
+                        ans, sco, tim = "error", -1e999, 0
+                        song_score = np.zeros([n_songs, 2], dtype=np.float32)
+                    else:
+                        sco, (sid, tim), song_score = results[i]
+                        ans = db.songList[sid]                            # sid == -1 -> last song (matcher.py:138)
+                    fout.write("%s\t%s\n" % (name, ans))
+                    detail_writer.writerow([name, ans, sco, tim])
+                    fout_score.write(song_score.tobytes())
+                fout.flush()
+                fout2.flush()
+
+        buf = []
+        # matcher.py:120-126 asks the model for norm=False and L2-normalises on the CPU;
+        # the same formula runs inside the projection kernel here.
+        for item in embed_files(engine, dataset, dataset.hop, batch_windows=group * 19, timer=timer):
+            buf.append(item)
+            if len(buf) >= group:
+                emit(buf)
+                buf = []
+        emit(buf)
+    print("stages:", {k: round(v, 3) for k, v in timer.t.items()})
+    print("total query time %.6fs" % (time.time() - tm_0))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
