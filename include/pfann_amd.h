@@ -171,8 +171,14 @@ int64_t pfann_db_bytes(pfann_db *db);
  * the kernel's name ("conv_gemm", "scan_topk", "ln_act", ...); pfann_prof_elapsed_ms sums
  * all completed brackets of that tag since pfann_prof_reset, returning their count in *count. */
 void pfann_prof_enable(int on);
+/* Launches an empty kernel named pfann_bench_region_marker on `stream`: bench.py brackets its
+ * timed region with two of them so a rocprofv3 trace can be cut to exactly that region. */
+void pfann_prof_marker(void *stream);
 void pfann_prof_reset(void);
 double pfann_prof_elapsed_ms(const char *tag, int64_t *count);
+/* Sum of the algorithmic work (flops for the MFMA-bound GEMM kernels, HBM bytes for the
+ * streaming ones) of all launches recorded under `tag` since the last reset. */
+double pfann_prof_work(const char *tag);
 /* Comma-separated tags recorded since the last reset; returns their number or -1. */
 int pfann_prof_tags(char *out, int cap);
 

@@ -20,7 +20,7 @@ void set_error(const char *fmt, ...) {
 }
 
 // ---- profiling ------------------------------------------------------------------------
-struct ProfRec { std::string tag; hipEvent_t e0, e1; };
+struct ProfRec { std::string tag; hipEvent_t e0, e1; double work; };
 static bool g_prof = false;
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
@@ -36,10 +36,10 @@ void prof_begin(const char *, hipStream_t s) {
     g_pending = get_event();
     (void)hipEventRecord(g_pending, s);
 }
-void prof_end(const char *tag, hipStream_t s) {
+void prof_end(const char *tag, hipStream_t s, double work) {
     hipEvent_t e1 = get_event();
     (void)hipEventRecord(e1, s);
-    g_recs.push_back({tag, g_pending, e1});
+    g_recs.push_back({tag, g_pending, e1, work});
     g_pending = nullptr;
 }
 
@@ -100,6 +100,8 @@ static int upload(float **dst, const float *src, size_t n) {
     PF_HIP(hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyHostToDevice));
     return 0;
 }
+
+__global__ void pfann_bench_region_marker() {}
 
 extern "C" {
 
@@ -526,6 +528,9 @@ done:
 }
 
 // ---- profiling ------------------------------------------------------------------------
+void pfann_prof_marker(void *stream) {
+    hipLaunchKernelGGL(pfann_bench_region_marker, dim3(1), dim3(64), 0, (hipStream_t)stream);
+}
 void pfann_prof_enable(int on) { g_prof = on != 0; }
 void pfann_prof_reset(void) {
     for (auto &r : g_recs) { g_pool.push_back(r.e0); g_pool.push_back(r.e1); }
@@ -542,6 +547,11 @@ double pfann_prof_elapsed_ms(const char *tag, int64_t *count) {
     }
     if (count) *count = n;
     return tot;
+}
+double pfann_prof_work(const char *tag) {
+    double w = 0;
+    for (auto &r : g_recs) if (r.tag == tag) w += r.work;
+    return w;
 }
 int pfann_prof_tags(char *out, int cap) {
     std::map<std::string, int> seen;

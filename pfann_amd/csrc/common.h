@@ -25,12 +25,16 @@ void set_error(const char *fmt, ...);
 // ---- per-kernel HIP-event profiling (bench.py roofline leg) -----------------------------
 bool prof_on();
 void prof_begin(const char *tag, hipStream_t s);
-void prof_end(const char *tag, hipStream_t s);
+void prof_end(const char *tag, hipStream_t s, double work);
 
+// `work` = algorithmic work of the bracketed launch (flops for MFMA-bound kernels, bytes for
+// HBM-bound ones), summed per tag and read back by bench.py for the roofline.
 struct ProfScope {
-    const char *tag; hipStream_t s; bool on;
-    ProfScope(const char *t, hipStream_t st) : tag(t), s(st), on(prof_on()) { if (on) prof_begin(tag, s); }
-    ~ProfScope() { if (on) prof_end(tag, s); }
+    const char *tag; hipStream_t s; bool on; double work;
+    ProfScope(const char *t, hipStream_t st, double w = 0.0) : tag(t), s(st), on(prof_on()), work(w) {
+        if (on) prof_begin(tag, s);
+    }
+    ~ProfScope() { if (on) prof_end(tag, s, work); }
 };
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -38,6 +38,7 @@ struct GemmConvParams {
     int axis, stride, pad_lo, in_len;
     int64_t tap_stride;
     int n_tiles_n;
+    int k_begin, k_end;   // live part of K = taps x Ci (taps that only ever see padding are skipped)
 };
 
 template <int BM, int BN, int WM, int WN>
@@ -81,21 +82,21 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmConvParams p) {
         }
     }
     // running (tap, c) of this thread's float4 inside the K dimension
-    int kap = col4 * 4;
+    int kap = p.k_begin + col4 * 4;
     int tap = kap / p.Ci, c = kap - tap * p.Ci;
 
     f32x4 ra[AR], rb[BR];
     auto load_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            const bool ok = kap < p.K && (unsigned)(ap0[i] + tap) < (unsigned)p.in_len;
+            const bool ok = kap < p.k_end && (unsigned)(ap0[i] + tap) < (unsigned)p.in_len;
             ra[i] = ok ? *reinterpret_cast<const f32x4 *>(p.x + abase[i] + tap * p.tap_stride + c)
                        : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int j = 0; j < BR; ++j) {
             const int n = n0 + rowq + 32 * j;
-            const bool ok = kap < p.K && n < p.N;
+            const bool ok = kap < p.k_end && n < p.N;
             rb[j] = ok ? *reinterpret_cast<const f32x4 *>(p.w + (int64_t)n * p.K + kap)
                        : f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk = (p.k_end - p.k_begin + BK - 1) / BK;
     load_tile();
     store_tile();
     __syncthreads();
@@ -180,16 +181,30 @@ int launch_conv_gemm(const SubLayer &L, const float *x, float *y, int64_t B, hip
     p.in_len = L.axis == 0 ? L.T : L.F;
     p.tap_stride = L.axis == 0 ? (int64_t)L.ci : (int64_t)L.T * L.ci;
     if (L.ci % 4 != 0) { set_error("conv_gemm needs ci %% 4 == 0 (ci=%d)", L.ci); return -1; }
-    ProfScope ps("conv_gemm", s);
+    // taps that fall into the zero padding for EVERY output position contribute nothing
+    {
+        const int out_len = L.axis == 0 ? L.To : L.Fo;
+        int lo = 3, hi = -1;
+        for (int tap = 0; tap < 3; ++tap)
+            for (int o = 0; o < out_len; ++o) {
+                const int pos = o * L.stride - L.pad_lo + tap;
+                if (pos >= 0 && pos < p.in_len) { lo = tap < lo ? tap : lo; hi = tap > hi ? tap : hi; break; }
+            }
+        p.k_begin = lo * L.ci;
+        p.k_end = (hi + 1) * L.ci;
+    }
+    const double flops = 2.0 * (double)p.M * p.N * (p.k_end - p.k_begin);
     // tile choice: big tiles when the grid still fills 256 CUs a few times over
     const int64_t blocks128 = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128);
-    if (p.N >= 128 && blocks128 >= 1024) {
+    if (p.N >= 128 && blocks128 >= 512) {
         p.n_tiles_n = cdiv(p.N, 128);
+        ProfScope ps("conv_gemm_128", s, flops);
         hipLaunchKernelGGL((conv_gemm_kernel<128, 128, 64, 64>), dim3((unsigned)blocks128), dim3(256),
                            0, s, p);
     } else {
         p.n_tiles_n = cdiv(p.N, 64);
         const int64_t blocks = (int64_t)cdiv(p.M, 64) * p.n_tiles_n;
+        ProfScope ps("conv_gemm_64", s, flops);
         hipLaunchKernelGGL((conv_gemm_kernel<64, 64, 32, 32>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     }
     PF_HIP(hipGetLastError());
@@ -229,7 +244,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
 int launch_conv_first(const SubLayer &L, const float *x, float *y, int64_t B, hipStream_t s) {
     const int64_t M = B * L.Fo * L.To;
     const int64_t n = M * (L.co / 4);
-    ProfScope ps("conv_first", s);
+    ProfScope ps("conv_first", s, 4.0 * ((double)M * L.co + (double)B * L.F * L.T));
     hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, x, L.w, L.bias,
                        y, M, L.co, L.To, L.T, L.stride, L.pad_lo);
     PF_HIP(hipGetLastError());
@@ -334,7 +349,7 @@ __global__ __launch_bounds__(NT) void ln_act_kernel(float *__restrict__ xy, cons
 int launch_ln_act(const SubLayer &L, float *xy, int64_t B, int activation, int relu_after_bn,
                   hipStream_t s) {
     const int n = L.co * L.Fo * L.To;
-    ProfScope ps("ln_act", s);
+    ProfScope ps("ln_act", s, 4.0 * (double)B * n * 3.0);
     if (n >= 65536)
         hipLaunchKernelGGL((ln_act_kernel<1024>), dim3((unsigned)B), dim3(1024), 0, s, xy, L.ln_w, L.ln_b, n,
                            activation, relu_after_bn);

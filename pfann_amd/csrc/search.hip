@@ -48,7 +48,7 @@ struct ScanParams {
     int64_t nq, nrows;       // nrows = rows scanned at this level = ceil(N / stride)
     int64_t row_stride;      // db row step (level stride)
     int d;
-    const float *thr;        // [nq] or nullptr (= emit everything)
+    const float *thr;        // [nq] or nullptr (= emit everything, densely: slot = row index)
     int *cnt;                // [nq]
     unsigned long long *keys;  // [nq][CAP]
     int n_tiles_m;
@@ -157,7 +157,9 @@ __global__ __launch_bounds__(256) void scan_emit_kernel(ScanParams p) {
                 const int ml = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
                 const int64_t m = m0 + ml;
                 const float sc = acc[i][j][r];
-                if (nok && m < p.nq && sc >= thr_s[ml]) {
+                if (p.thr == nullptr) {      // top sampling level: nrows <= CAP, no filter, no atomics
+                    if (nok && m < p.nq) p.keys[m * CAP + n] = pack_key(sc, row);
+                } else if (nok && m < p.nq && sc >= thr_s[ml]) {
                     const int pos = atomicAdd(&p.cnt[m], 1);
                     if (pos < CAP) p.keys[m * CAP + pos] = pack_key(sc, row);
                 }
@@ -224,6 +226,11 @@ __global__ __launch_bounds__(1024) void select_kernel(const unsigned long long *
     }
 }
 
+__global__ void fill_int_kernel(int *p, int v, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
 static int launch_scan(const float *db, int64_t n, int d, int64_t stride, const float *q, int64_t nq,
                        const float *thr, SearchWorkspace &ws, hipStream_t s) {
     ScanParams p;
@@ -231,8 +238,13 @@ static int launch_scan(const float *db, int64_t n, int d, int64_t stride, const 
     p.row_stride = stride;
     p.nrows = (n + stride - 1) / stride;
     p.thr = thr; p.cnt = ws.cnt; p.keys = reinterpret_cast<unsigned long long *>(ws.cl);
-    PF_HIP(hipMemsetAsync(ws.cnt, 0, sizeof(int) * nq, s));
-    ProfScope ps(stride == 1 ? "scan_topk" : "scan_topk_sample", s);
+    if (thr == nullptr) {
+        if (p.nrows > CAP) { set_error("scan: dense level with %lld rows > %d", (long long)p.nrows, CAP); return -1; }
+        hipLaunchKernelGGL(fill_int_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, s, ws.cnt, (int)p.nrows, nq);
+    } else {
+        PF_HIP(hipMemsetAsync(ws.cnt, 0, sizeof(int) * nq, s));
+    }
+    ProfScope ps(stride == 1 ? "scan_topk" : "scan_topk_sample", s, 2.0 * (double)nq * p.nrows * d);
     if (nq <= 32) {
         p.n_tiles_m = 1;
         const int64_t blocks = cdiv(p.nrows, 128);

@@ -58,7 +58,9 @@ SYMBOLS = {
                             c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pfann_prof_enable": (None, [c_int]),
     "pfann_prof_reset": (None, []),
+    "pfann_prof_marker": (None, [c_void_p]),
     "pfann_prof_elapsed_ms": (c_double, [c_char_p, POINTER(c_int64)]),
+    "pfann_prof_work": (c_double, [c_char_p]),
     "pfann_prof_tags": (c_int, [c_char_p, c_int]),
 }
 

@@ -1,0 +1,68 @@
+"""Test-only compute backend with the DeviceIndex interface, implemented by the ORACLE
+(numpy / C restatement).  It lets the multi-GPU host logic in pfann_amd/dist.py run in
+world_size-2 `gloo` tests on CPU.  Lives under tests/: the product never imports it."""
+import numpy as np
+import torch
+
+from oracle import search as osr
+from oracle import seqscore as osq
+
+
+class OracleIndex:
+    def __init__(self, d):
+        self.d = d
+
+    def load(self, emb, song_pos, label_base=0):
+        self.emb = np.ascontiguousarray(emb, np.float32).reshape(-1, self.d)
+        self.song_pos = np.asarray(song_pos, np.int64)
+        self.label_base = label_base
+        self.ntotal = self.emb.shape[0]
+        self.n_songs = self.song_pos.shape[0] - 1
+        lo = int(np.searchsorted(self.song_pos, label_base, side="left"))
+        hi = lo
+        while hi < self.n_songs and self.song_pos[hi + 1] <= label_base + self.ntotal:
+            hi += 1
+        self.song_lo, self.song_hi = lo, hi
+
+    def search(self, q, k):
+        D, I = osr.flat_ip_topk(q.numpy(), self.emb, k)
+        I = np.where(I >= 0, I + self.label_base, -1)
+        return torch.from_numpy(D), torch.from_numpy(I)
+
+    def merge_topk(self, S, L, k):
+        S, L = S.numpy(), L.numpy()
+        D = np.full((S.shape[0], k), -np.finfo(np.float32).max, np.float32)
+        I = np.full((S.shape[0], k), -1, np.int64)
+        for r in range(S.shape[0]):
+            ok = np.nonzero(L[r] >= 0)[0]
+            o = ok[np.argsort(-S[r][ok], kind="stable")[:k]]
+            D[r, :len(o)] = S[r][o]
+            I[r, :len(o)] = L[r][o]
+        return torch.from_numpy(D), torch.from_numpy(I)
+
+    def match(self, q, labels, qstart, qlen, fsm=1, alpha=0.0, mode=0, only_owned=False, want_song_scores=False):
+        """Python-path oracle restricted to owned songs: labels of other shards' songs are
+        dropped before candidate generation, local rows are addressed through label_base."""
+        q, labels = q.numpy(), labels.numpy()
+        out = np.zeros(len(qlen), dtype=[("song", "<i4"), ("offset", "<i4"), ("shift", "<i4"),
+                                         ("n_cand", "<i4"), ("score", "<f8")])
+        # full-size db view so the oracle can index rows globally
+        full = np.zeros((int(self.song_pos[-1]), self.d), np.float32)
+        full[self.label_base:self.label_base + self.ntotal] = self.emb
+        for j in range(len(qlen)):
+            sl = slice(int(qstart[j]), int(qstart[j]) + int(qlen[j]))
+            lab = labels[sl].copy()
+            if only_owned:
+                own_lo, own_hi = self.song_pos[self.song_lo], self.song_pos[self.song_hi]
+                lab[(lab < own_lo) | (lab >= own_hi)] = -1
+            if (lab >= 0).any():
+                score, (song, sec), _ = osq.query_embeddings_base(q[sl], lab, full, self.song_pos, 1.0, fsm)
+            else:
+                score, song, sec = -np.inf, -1, 0
+            if song < 0:
+                out[j] = (-1, 0, 0, 0, -np.inf)
+            else:
+                fine = int(round(sec * fsm))
+                shift = (-fine) % fsm
+                out[j] = (song, (fine + shift) // fsm, shift, 0, score)
+        return out, None

@@ -1,0 +1,127 @@
+"""End-to-end drop-in check of the two CLIs on the GPU: builder.py <list> <db> <cfg>, then
+matcher.py <qlist> <db> <result>, against the oracle pipeline run on the same files
+(BASELINE.json configs[0]: 10-song synthetic db, plumbing + decisions)."""
+import csv
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from pfann_amd import synth
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("cfgname", ["tiny", "default"])
+def test_builder_and_matcher_cli_vs_oracle(tmp_path, cfgname):
+    import torch
+    from oracle import encoder as oe
+    from oracle import melspec as om
+    from oracle import search as osr
+    from oracle import segmenter as osg
+    from oracle import seqscore as osq
+
+    params = json.load(open(os.path.join(REPO, "configs", cfgname + ".json")))
+    d, k = params["model"]["d"], params["indexer"]["top_k"]
+    sd = synth.make_state_dict(params, seed=321)
+    mdir = tmp_path / "model"
+    mdir.mkdir()
+    torch.save({n: torch.from_numpy(v) for n, v in sd.items()}, str(mdir / "model.pt"))
+    shutil.copy(os.path.join(REPO, "configs", cfgname + ".json"), str(mdir / "configs.json"))
+
+    # ---- music: 10 songs of different lengths, one stereo, one unreadable
+    n_songs = 10
+    music = []
+    songs = {}
+    for s in range(n_songs):
+        path = str(tmp_path / ("song%02d.wav" % s))
+        if s == 4:
+            open(path, "wb").write(b"garbage")           # load error -> 0-segment song
+        else:
+            pcm = synth.make_song(100 + s, seconds=8.0 + s)
+            if s == 6:
+                pcm = np.stack([pcm, pcm // 2], 1)
+            synth.write_wav(path, pcm)
+            songs[s] = pcm
+        music.append(path)
+    mlist = tmp_path / "music.txt"
+    mlist.write_text("".join(p + "\n" for p in music))
+
+    # ---- queries: clean + noisy crops, a too-short one, a missing file
+    queries, truth = [], []
+    for j in range(8):
+        s = [0, 1, 2, 3, 5, 6, 7, 9][j]
+        src = songs[s] if songs[s].ndim == 1 else songs[s][:, 0]
+        q, off = synth.make_query(src, j, 4.0, snr_db=6.0 if j % 2 else 30.0)
+        path = str(tmp_path / ("q%02d.wav" % j))
+        synth.write_wav(path, q)
+        queries.append(path)
+        truth.append((s, off))
+    short = str(tmp_path / "qshort.wav")
+    synth.write_wav(short, songs[2][16000:16000 + 3000])
+    queries.append(short)
+    queries.append(str(tmp_path / "qmissing.wav"))
+    qlist = tmp_path / "queries.txt"
+    qlist.write_text("".join(p + "\n" for p in queries))
+
+    db = str(tmp_path / "db")
+    env = dict(os.environ, PYTHONPATH=REPO)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "builder.py"), str(mlist), db, str(mdir)],
+                       capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    result = str(tmp_path / "result.txt")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "matcher.py"), str(qlist), db, result],
+                       capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+    # ---- db directory layout (builder.py:71,136-148)
+    for f in ("embeddings", "landmarkValue", "landmarkKey", "songList.txt", "configs.json", "model.pt"):
+        assert os.path.exists(os.path.join(db, f)), f
+    key = np.fromfile(os.path.join(db, "landmarkKey"), dtype=np.int32)
+    emb = np.fromfile(os.path.join(db, "embeddings"), dtype=np.float32).reshape(-1, d)
+    assert open(os.path.join(db, "songList.txt")).read() == mlist.read_text()
+
+    # ---- oracle pipeline on the same files
+    ref_emb, ref_key = [], []
+    for p in music:
+        segs = osg.load_segments(p, params)
+        ref_key.append(segs.shape[0])
+        if segs.shape[0]:
+            ref_emb.append(oe.encode(om.melspec(segs, params), sd, params))
+    ref_emb = np.concatenate(ref_emb)
+    assert np.array_equal(key, np.asarray(ref_key, np.int32)) and key[4] == 0
+    assert emb.shape == ref_emb.shape
+    assert np.abs(emb - ref_emb).max() < 1e-4
+    pos = osq.song_pos_from_key(ref_key)
+
+    tsv = [ln.rstrip("\n").split("\t") for ln in open(result, encoding="utf8")]
+    raw_detail = open(os.path.splitext(result)[0] + "_detail.csv", "rb").read()
+    assert raw_detail.startswith(b"query,answer,score,time,part_scores\r\n")       # csv module line endings
+    detail = list(csv.reader(open(os.path.splitext(result)[0] + "_detail.csv", newline="")))[1:]
+    scores = np.fromfile(result + ".bin", dtype=np.float32).reshape(len(queries), n_songs, 2)
+    assert len(tsv) == len(detail) == len(queries)
+    hits = 0
+    for j, qp in enumerate(queries):
+        segs = osg.load_segments(qp, params)
+        assert tsv[j][0] == qp == detail[j][0]
+        if segs.shape[0] == 0:                                      # matcher.py:94-107
+            assert tsv[j][1] == "error" and detail[j][1:] == ["error", "-inf", "0"]
+            assert not scores[j].any()
+            continue
+        e = oe.encode(om.melspec(segs, params), sd, params)
+        D, I = osr.flat_ip_topk(e, ref_emb, k)
+        sc, (song, sec), ss = osq.query_embeddings_base(e, I, ref_emb, pos, params["hop_size"], 1)
+        assert tsv[j][1] == music[song] == detail[j][1], j
+        assert float(detail[j][3]) == sec, j
+        assert abs(float(detail[j][2]) - sc) < 2e-5, j
+        assert np.allclose(scores[j], ss, atol=2e-5), j
+        assert np.array_equal(scores[j][:, 1], ss[:, 1])
+        if j < len(truth):
+            hits += (song == truth[j][0] and abs(sec - truth[j][1]) <= 0.5)
+    if cfgname == "default":
+        assert hits >= 6          # random-weight encoder still identifies clean crops

@@ -1,0 +1,198 @@
+"""CPU-side tests: the C-ABI library loads and exports every declared symbol, host logic
+(sharding, file formats, segmenter mirror, mel bank, CLI plumbing helpers) and the N>1
+path on world_size-2 gloo."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import make_golden as mg
+from pfann_amd import synth
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(REPO, "tests", "golden")
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """build() made the library; it must load without a GPU and export exactly what
+    include/pfann_amd.h declares (no compute calls here)."""
+    import __graft_entry__ as ge
+    ge.build()
+    from pfann_amd import lib
+    L = lib.load()
+    hdr = open(os.path.join(REPO, "include", "pfann_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(pfann_[a-z0-9_]+|version|seq_score)\s*\(", hdr))
+    declared -= {"pfann_config", "pfann_match_result"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(L, name), "missing export %s" % name
+        assert name in lib.SYMBOLS, "binding missing for %s" % name
+    assert set(lib.SYMBOLS) == declared
+    assert L.version() == 20220625002                       # database.py:30 handshake
+    assert ctypes.sizeof(lib.MatchResult) == 24
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from pfann_amd import lib
+    from pfann_amd.database import DeviceIndex
+    from pfann_amd.engine import Engine
+    params = json.load(open(os.path.join(REPO, "configs", "tiny.json")))
+    with pytest.raises(lib.PfannError):
+        Engine(params, 0)
+    with pytest.raises(lib.PfannError):
+        DeviceIndex(16, 0)
+
+
+def test_product_never_imports_oracle():
+    for root, _, files in os.walk(os.path.join(REPO, "pfann_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_host_melbank_matches_oracle_restatement():
+    from oracle import melspec as om
+    from pfann_amd.engine import mel_filterbank
+    for naf in (False, True):
+        a = mel_filterbank(8000, 1024, 256, 300, 4000, naf).numpy()
+        b = om.mel_filterbank(8000, 1024, 256, 300, 4000, naf).numpy()
+        assert np.array_equal(a, b)
+
+
+def test_musicdata_mirror_matches_reference_golden(tmp_path):
+    from pfann_amd.musicdata import MusicDataset
+    z = np.load(os.path.join(G, "segmenter.npz"))
+    params = json.load(open(os.path.join(REPO, "configs", "default.json")))
+    inputs = mg.segmenter_inputs()
+    names = []
+    for name, pcm in inputs.items():
+        synth.write_wav(str(tmp_path / (name + ".wav")), pcm)
+        names.append(name)
+    (tmp_path / "notwav.wav").write_bytes(b"this is not a wave file")
+    names += ["missing", "notwav"]
+    lst = tmp_path / "list.txt"
+    lst.write_text("".join(str(tmp_path / (n + ".wav")) + "\n" for n in names))
+    for fsm in (1, 2):
+        p = json.loads(json.dumps(params))
+        p["indexer"]["frame_shift_mul"] = fsm
+        ds = MusicDataset(str(lst), p)
+        assert len(ds) == len(names)
+        for i, name in enumerate(names):
+            idx, path, wav = ds[i]
+            w = wav.numpy()
+            key = "%s_fsm%d" % (name, fsm)
+            assert tuple(z[key + "_shape"]) == w.shape, key
+            if w.shape[0]:
+                assert np.array_equal(w[z[key + "_rows"]], z[key + "_vals"]), key
+                assert ds.n_segments(inputs[name].shape[0]) == w.shape[0]
+
+
+def test_faiss_flat_index_roundtrip(tmp_path):
+    from pfann_amd import faissio
+    x = synth.unit_rows(1, "faiss", 37, 16)
+    p = str(tmp_path / "landmarkValue")
+    faissio.write_index_flat(p, x)
+    y, metric = faissio.read_index_flat(p)
+    assert metric == 0 and np.array_equal(x, y)
+    raw = open(p, "rb").read()
+    assert raw[:4] == b"IxFI" and len(raw) == 4 + 4 + 8 * 3 + 1 + 4 + 8 + x.nbytes
+    faissio.write_index_flat(p, np.zeros((0, 16), np.float32))
+    y, _ = faissio.read_index_flat(p)
+    assert y.shape == (0, 16)
+    open(p, "wb").write(b"IwFl" + raw[4:])
+    with pytest.raises(ValueError):
+        faissio.read_index_flat(p)
+
+
+def test_shard_songs_properties():
+    from pfann_amd.dist import shard_songs, split_even
+    key = [int(x) for x in (1 + 80 * synth.uniform01(3, "shard", 500))]
+    key[10] = key[11] = 0
+    pos = np.pad(np.cumsum(key), (1, 0))
+    for world in (1, 2, 3, 4, 8):
+        sh = shard_songs(pos, world)
+        assert sh[0][0] == 0 and sh[-1][1] == 500
+        assert all(sh[r][1] == sh[r + 1][0] for r in range(world - 1))
+        rows = [pos[hi] - pos[lo] for lo, hi in sh]
+        assert max(rows) - min(rows) <= 2 * max(key)
+    assert shard_songs(np.array([0, 5]), 4)[-1] == (0, 1) or sum(h - l for l, h in shard_songs(np.array([0, 5]), 4)) == 1
+    assert split_even(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
+
+
+def test_fine_to_time_matches_reference_formula():
+    from pfann_amd.database import _fine_to_time
+    for fsm in (1, 2, 3):
+        for t in range(-5, 6):
+            for shift in range(fsm):
+                assert _fine_to_time(t * fsm - shift, fsm, 0.5) == (t - shift / fsm) * 0.5
+
+
+WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from oracle_backend import OracleIndex
+from oracle import search as osr, seqscore as osq
+from pfann_amd import synth
+from pfann_amd.dist import ShardedIndex, all_gather_ragged, split_even
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+d, k = 32, 40
+key = [int(x) for x in (5 + 30 * synth.uniform01(41, "dist/key", 60))]; key[3] = 0
+pos = osq.song_pos_from_key(key)
+db = synth.unit_rows(42, "dist/db", int(pos[-1]), d)
+db[pos[20]:pos[21]] = db[pos[7]:pos[7] + key[20]] if key[7] >= key[20] else db[pos[20]:pos[21]]  # duplicate content
+lo, hi = ShardedIndex.my_rows(pos, rank, world)
+idx = OracleIndex(d); idx.load(db[lo:hi], pos, lo)
+qs, qstart, qlen, n = [], [], [], 0
+for j in range(12):
+    s = (j * 7 + 1) % 60
+    if key[s] < 12: s = 7
+    ln = 4 + j % 8
+    off = (j * 5) % (key[s] - ln)
+    qq = db[pos[s] + off: pos[s] + off + ln] + 0.4 * synth.unit_rows(50 + j, "dist/q", ln, d)
+    qs.append(qq / np.linalg.norm(qq, axis=1, keepdims=True)); qstart.append(n); qlen.append(ln); n += ln
+q = np.concatenate(qs).astype(np.float32)
+# ragged all-gather of "embeddings" computed by their owning rank
+parts = split_even(q.shape[0], world)
+mine = torch.from_numpy(q[parts[rank][0]:parts[rank][1]])
+qt = all_gather_ragged(mine, [h - l for l, h in parts])
+assert np.array_equal(qt.numpy(), q)
+sh = ShardedIndex(idx, pos, k, 1, 0.0)
+D, I = sh.search_global(qt)
+Dr, Ir = osr.flat_ip_topk(q, db, k)
+assert np.array_equal(I.numpy(), Ir), "global top-k differs from single-device"
+res = sh.query_batch(qt, qstart, qlen)
+for j in range(12):
+    sl = slice(qstart[j], qstart[j] + qlen[j])
+    score, (song, sec), _ = osq.query_embeddings_base(q[sl], Ir[sl], db, pos, 1.0, 1)
+    assert int(res[j]["song"]) == song and int(res[j]["offset"]) == int(sec), (j, res[j], song, sec)
+    assert abs(float(res[j]["score"]) - score) < 1e-9
+dist.barrier()
+if rank == 0: print("DIST_OK")
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_search_world2_gloo(tmp_path, world):
+    """N>1 path on CPU: song-sharded search + owner-side rerank over gloo equals the
+    single-device decisions (incl. a duplicated song across shards: tie -> lower id)."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(29500 + world + os.getpid() % 200),
+           str(script), REPO]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=REPO)
+    assert r.returncode == 0 and "DIST_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
