@@ -181,7 +181,11 @@ def main():
             kernels[tag] = {"ms_per_step": ms / args.steps, "launches_per_step": cnt.value / args.steps,
                             "avg_us": 1e3 * ms / max(cnt.value, 1), "work_per_launch": work / max(cnt.value, 1)}
     # roofline of the dominant kernel (most time in the timed region)
-    ROOF = {"conv_gemm_128": ("pfann::conv_gemm_kernel<128,128,64,64>", "mfma"),
+    ROOF = {"conv_gemm_ln_128": ("pfann::conv_gemm_ln_kernel<128,128,64,64> (implicit-GEMM conv with LayerNorm+ReLU "
+                                 "of its input fused into the A-loader and LN statistics of its output in the epilogue)", "mfma"),
+            "conv_gemm_ln_64": ("pfann::conv_gemm_ln_kernel<64,64,32,32>", "mfma"),
+            "conv_first_stats": ("pfann::conv_first_stats_kernel", "hbm"),
+            "conv_gemm_128": ("pfann::conv_gemm_kernel<128,128,64,64>", "mfma"),
             "conv_gemm_64": ("pfann::conv_gemm_kernel<64,64,32,32>", "mfma"),
             "scan_topk": ("pfann::scan_emit_kernel (full-db pass)", "mfma"),
             "ln_act": ("pfann::ln_act_kernel", "hbm"), "conv_first": ("pfann::conv_first_kernel", "hbm")}

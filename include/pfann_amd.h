@@ -115,6 +115,16 @@ int64_t pfann_debug_activation(pfann_ctx *ctx, int idx, int64_t B, float *host, 
 /* Enable keeping those taps (costs one D2D copy per sub-layer; off by default). */
 void pfann_debug_keep(pfann_ctx *ctx, int on);
 
+/* Selects the LayerNorm-fused encoder path (default: on whenever the model supports it, i.e.
+ * every conv2 is a full conv; off = separate LayerNorm kernels).  Returns the state now in
+ * effect (1 fused / 0 unfused).  Both paths are parity-tested. */
+int pfann_set_fused_layernorm(pfann_ctx *ctx, int on);
+
+/* Number of internal HIP streams (1..8) a batch is split over inside pfann_encode /
+ * pfann_segment_embed*: the MFMA-bound GEMMs of one sub-batch overlap the HBM-bound passes
+ * of another.  Work is forked from and joined back into the caller's stream.  Returns n. */
+int pfann_set_streams(pfann_ctx *ctx, int n);
+
 /* ---- database: device-resident fingerprints, exact search, sequence match ------------ */
 typedef struct pfann_db pfann_db;
 

@@ -2,6 +2,7 @@
 // per-kernel HIP-event profiling and the reference's native seam (version / seq_score).
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -64,12 +65,21 @@ struct pfann_ctx {
     int64_t buf_elems[2] = {0, 0};  // per sample
     float *mel_buf = nullptr;
     double *scratch = nullptr;
+    bool fused = false;             // LayerNorm fused into the GEMMs (encoder_fused.hip)
+    int n_streams = 1;              // sub-batches run on this many internal streams (MFMA-bound GEMMs of one
+                                    // sub-batch overlap the HBM-bound LayerNorm passes of another)
+    hipStream_t side[8] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[8] = {};
+    float *part[2] = {nullptr, nullptr};
+    int64_t part_slots = 0;         // per sample
     bool keep = false;
     int64_t keep_B = 0;
     float *dbg[16] = {};
     float *dbg_tmp = nullptr;
     int64_t dbg_cap = 0;
 };
+
+extern "C" int pfann_set_streams(pfann_ctx *c, int n);
 
 static int build_plan(pfann_ctx *c) {
     const pfann_config &g = c->cfg;
@@ -149,6 +159,14 @@ pfann_ctx *pfann_create(const pfann_config *cfg, int device) {
         const int64_t e = (int64_t)c->sub[i].co * c->sub[i].Fo * c->sub[i].To;
         c->buf_elems[i & 1] = std::max(c->buf_elems[i & 1], e);
     }
+    c->fused = fused_supported(c->sub, 16) && getenv("PFANN_NO_FUSE") == nullptr;
+    if (getenv("PFANN_STREAMS")) pfann_set_streams(c, atoi(getenv("PFANN_STREAMS")));
+    for (int i = 0; i < 16; ++i) {
+        const SubLayer &L = c->sub[i];
+        const int rps = L.Fo * L.To;
+        const int64_t slots = (int64_t)(rps >= 64 ? rps / 64 : 1) * cdiv(L.co, 64);
+        c->part_slots = std::max(c->part_slots, slots);
+    }
     if (hipMalloc(&c->scratch, 16 * sizeof(double)) != hipSuccess) {
         set_error("hipMalloc failed");
         delete c;
@@ -168,7 +186,7 @@ void pfann_destroy(pfann_ctx *c) {
         if (c->sub[i].ln_b) (void)hipFree(c->sub[i].ln_b);
         if (c->dbg[i]) (void)hipFree(c->dbg[i]);
     }
-    float *ptrs[] = {c->g_w1, c->g_b1, c->g_w2, c->g_b2, c->buf[0], c->buf[1], c->mel_buf, c->mel.window,
+    float *ptrs[] = {c->g_w1, c->g_b1, c->g_w2, c->g_b2, c->buf[0], c->buf[1], c->part[0], c->part[1], c->mel_buf, c->mel.window,
                      c->mel.fb_val, c->dbg_tmp};
     for (float *p : ptrs) if (p) (void)hipFree(p);
     if (c->mel.twiddle) (void)hipFree(c->mel.twiddle);
@@ -293,16 +311,47 @@ static int ensure_workspace(pfann_ctx *c, bool need_mel) {
     if (!c->buf[0]) {
         PF_HIP(hipMalloc(&c->buf[0], mb * c->buf_elems[0] * sizeof(float)));
         PF_HIP(hipMalloc(&c->buf[1], mb * c->buf_elems[1] * sizeof(float)));
+        PF_HIP(hipMalloc(&c->part[0], mb * c->part_slots * 2 * sizeof(float)));
+        PF_HIP(hipMalloc(&c->part[1], mb * c->part_slots * 2 * sizeof(float)));
     }
     if (need_mel && !c->mel_buf) PF_HIP(hipMalloc(&c->mel_buf, mb * (int64_t)c->F * c->T * sizeof(float)));
     return 0;
 }
 
-static int encode_chunk(pfann_ctx *c, const float *mel, int64_t B, float *emb, int normalize, hipStream_t s) {
+static int keep_tap_fused(pfann_ctx *c, int idx, const float *z, const float *part, int P, int64_t B, hipStream_t s) {
+    const SubLayer &L = c->sub[idx];
+    const int64_t e = (int64_t)L.co * L.Fo * L.To;
+    const int64_t nb = std::min<int64_t>(B, 8);
+    if (!c->dbg[idx]) PF_HIP(hipMalloc(&c->dbg[idx], 8 * e * sizeof(float)));
+    c->keep_B = nb;
+    return launch_ln_apply(L, z, part, P, c->dbg[idx], nb, c->cfg.activation, c->cfg.relu_after_bn, s);
+}
+
+static int encode_chunk_fused(pfann_ctx *c, const float *mel, int64_t B, float *emb, int normalize, hipStream_t s,
+                              int64_t slot0) {
+    const pfann_config &g = c->cfg;
+    float *buf[2] = {c->buf[0] + slot0 * c->buf_elems[0], c->buf[1] + slot0 * c->buf_elems[1]};
+    float *part[2] = {c->part[0] + slot0 * c->part_slots * 2, c->part[1] + slot0 * c->part_slots * 2};
+    if (launch_conv_first_stats(c->sub[0], mel, buf[0], part[0], B, g.activation, g.relu_after_bn, s)) return -1;
+    int P = fused_out_slots(c->sub[0], B);
+    if (c->keep && keep_tap_fused(c, 0, buf[0], part[0], P, B, s)) return -1;
+    for (int i = 1; i < 16; ++i) {
+        if (launch_conv_gemm_ln(c->sub[i], c->sub[i - 1], buf[(i - 1) & 1], part[(i - 1) & 1], P, buf[i & 1],
+                                part[i & 1], B, g.activation, g.relu_after_bn, s)) return -1;
+        P = fused_out_slots(c->sub[i], B);
+        if (c->keep && keep_tap_fused(c, i, buf[i & 1], part[i & 1], P, B, s)) return -1;
+    }
+    return launch_myg_ln(c->sub[15], buf[1], part[1], P, g.activation, g.relu_after_bn, c->g_w1, c->g_b1,
+                         c->g_w2, c->g_b2, g.d, g.u, g.h / g.d, B, emb, normalize, s);
+}
+
+static int encode_chunk1(pfann_ctx *c, const float *mel, int64_t B, float *emb, int normalize, hipStream_t s,
+                         int64_t slot0) {
+    if (c->fused) return encode_chunk_fused(c, mel, B, emb, normalize, s, slot0);
     const float *x = mel;
     for (int i = 0; i < 16; ++i) {
         const SubLayer &L = c->sub[i];
-        float *y = c->buf[i & 1];
+        float *y = c->buf[i & 1] + slot0 * c->buf_elems[i & 1];
         int rc;
         if (L.ci == 1 && !L.depthwise) rc = launch_conv_first(L, x, y, B, s);
         else if (L.depthwise) rc = launch_conv_depthwise(L, x, y, B, s);
@@ -314,6 +363,31 @@ static int encode_chunk(pfann_ctx *c, const float *mel, int64_t B, float *emb, i
     }
     const pfann_config &g = c->cfg;
     return launch_myg(x, c->g_w1, c->g_b1, c->g_w2, c->g_b2, g.d, g.u, g.h / g.d, B, emb, normalize, s);
+}
+
+// Splits a chunk over the internal streams: fork after the caller's stream, join back into it.
+static int encode_chunk(pfann_ctx *c, const float *mel, int64_t B, float *emb, int normalize, hipStream_t s) {
+    const int ns = (int)std::min<int64_t>(c->n_streams, B / 128);
+    if (ns <= 1) return encode_chunk1(c, mel, B, emb, normalize, s, 0);
+    if (!c->ev_fork) {
+        PF_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        for (int k = 0; k < 8; ++k) {
+            PF_HIP(hipStreamCreateWithFlags(&c->side[k], hipStreamNonBlocking));
+            PF_HIP(hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming));
+        }
+    }
+    PF_HIP(hipEventRecord(c->ev_fork, s));
+    const int64_t per = (int64_t)c->F * c->T;
+    int64_t b0 = 0;
+    for (int k = 0; k < ns; ++k) {
+        const int64_t nb = B / ns + (k < B % ns ? 1 : 0);
+        PF_HIP(hipStreamWaitEvent(c->side[k], c->ev_fork, 0));
+        if (encode_chunk1(c, mel + b0 * per, nb, emb + b0 * c->cfg.d, normalize, c->side[k], b0)) return -1;
+        PF_HIP(hipEventRecord(c->ev_join[k], c->side[k]));
+        PF_HIP(hipStreamWaitEvent(s, c->ev_join[k], 0));
+        b0 += nb;
+    }
+    return 0;
 }
 
 int pfann_encode(pfann_ctx *c, const float *mel, int64_t B, float *emb, int normalize, void *stream) {
@@ -362,6 +436,17 @@ int pfann_pcm16_to_mono(pfann_ctx *c, const int16_t *pcm, int64_t n_frames, int 
 }
 
 void pfann_debug_keep(pfann_ctx *c, int on) { c->keep = on != 0; }
+
+int pfann_set_streams(pfann_ctx *c, int n) {
+    c->n_streams = n < 1 ? 1 : (n > 8 ? 8 : n);
+    return c->n_streams;
+}
+
+int pfann_set_fused_layernorm(pfann_ctx *c, int on) {
+    if (on && !fused_supported(c->sub, 16)) return 0;
+    c->fused = on != 0;
+    return c->fused ? 1 : 0;
+}
 
 int64_t pfann_debug_activation(pfann_ctx *c, int idx, int64_t B, float *host, int64_t cap) {
     if (idx < 0 || idx > 15 || !c->dbg[idx]) { set_error("no tap %d (call pfann_debug_keep(ctx,1) before encoding)", idx); return -1; }

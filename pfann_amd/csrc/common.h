@@ -56,6 +56,37 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- bounds-checked buffer access (gfx950 SRD): out-of-range lanes read 0 / drop stores, so
+// predicated tile loads need neither branches nor selects and can sit in MFMA shadows.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+static constexpr unsigned BUF_OOB = 0x80000000u;          // any offset >= num_records
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void *base, unsigned long long bytes) {
+    const unsigned n = bytes > 0x7FFFFFF0ull ? 0x7FFFFFF0u : (unsigned)bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)n, 0x00020000);
+}
+__device__ __forceinline__ f32x4_t buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+    return __builtin_bit_cast(f32x4_t, v);
+}
+
+__device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)byte_off, 0, 0);
+}
+
+__device__ __forceinline__ float act_fn(float v, int act) {   // 0 ReLU, 1 ELU (model.py:7-12)
+    return act == 0 ? fmaxf(v, 0.0f) : (v > 0.0f ? v : expm1f(v));
+}
+
+// Bijective XCD remap: hardware places block b on XCD b%8; give each XCD a contiguous
+// chunk of the logical tile order so blocks sharing an operand panel share an L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + idx;
+}
+
 // ---- encoder plan shared between api and kernels ---------------------------------------
 struct SubLayer {          // one conv (+LN+act) sub-layer, channels-last activations
     int ci, co;            // input / output channels

@@ -13,18 +13,7 @@ namespace pfann {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ float act_fn(float v, int act) {
-    return act == 0 ? fmaxf(v, 0.0f) : (v > 0.0f ? v : expm1f(v));
-}
 
-// Bijective XCD remap: hardware places block b on XCD b%8; give each XCD a contiguous
-// chunk of the logical tile order.
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-    const int q = nblk >> 3, r = nblk & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return start + idx;
-}
 
 // ------------------------------------------------------------------------------------
 // Implicit-GEMM convolution:  y[m][n] = bias[n] + sum_{tap,c} x[row(m) + tap][c] * w[n][tap][c]
@@ -48,8 +37,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmConvParams p) {
     static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int AR = BM / 32, BR = BN / 32;
-    __shared__ __attribute__((aligned(16))) float As[BM * LDK];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
+    __shared__ __attribute__((aligned(16))) float As[2 * BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BN * LDK];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -59,9 +48,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmConvParams p) {
     const int n0 = nt * BN;
 
     const int col4 = tid & 7, rowq = tid >> 3;
-    // per-thread A row descriptors
-    int64_t abase[AR];
-    int ap0[AR];
+    // Tile operands come through bounds-checked buffer loads (OOB lanes read 0): the A window
+    // starts at the first sample this tile touches, so 32-bit byte offsets suffice.
+    const int64_t b_first = m0 / p.rows_per_sample;
+    const int64_t in_elems = (int64_t)p.F * p.T * p.Ci;
+    const int64_t total_in = (p.M / p.rows_per_sample) * in_elems;
+    const __amdgpu_buffer_rsrc_t srd_a = make_srd(p.x + b_first * in_elems, (total_in - b_first * in_elems) * 4ull);
+    const __amdgpu_buffer_rsrc_t srd_b = make_srd(p.w, (unsigned long long)p.N * p.K * 4ull);
+    int aoff[AR], ap0[AR];      // element offset of tap 0 inside the window; coordinate of tap 0
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
         const int64_t m = m0 + rowq + 32 * i;
@@ -69,48 +63,49 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmConvParams p) {
             const int64_t b = m / p.rows_per_sample;
             const int r = (int)(m - b * p.rows_per_sample);
             const int fo = r / p.To, to = r - fo * p.To;
-            if (p.axis == 0) {
-                ap0[i] = to * p.stride - p.pad_lo;
-                abase[i] = ((b * p.F + fo) * (int64_t)p.T + ap0[i]) * p.Ci;
-            } else {
-                ap0[i] = fo * p.stride - p.pad_lo;
-                abase[i] = ((b * p.F + ap0[i]) * (int64_t)p.T + to) * p.Ci;
-            }
+            int rel;
+            if (p.axis == 0) { ap0[i] = to * p.stride - p.pad_lo; rel = (fo * p.T + ap0[i]) * p.Ci; }
+            else { ap0[i] = fo * p.stride - p.pad_lo; rel = (ap0[i] * p.T + to) * p.Ci; }
+            aoff[i] = (int)((b - b_first) * in_elems) + rel;
         } else {
             ap0[i] = -(1 << 20);  // never valid
-            abase[i] = 0;
+            aoff[i] = 0;
         }
+    }
+    unsigned boff[BR];
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+        const int n = n0 + rowq + 32 * j;
+        boff[j] = n < p.N ? (unsigned)n * (unsigned)p.K * 4u : BUF_OOB;
     }
     // running (tap, c) of this thread's float4 inside the K dimension
     int kap = p.k_begin + col4 * 4;
     int tap = kap / p.Ci, c = kap - tap * p.Ci;
+    const int tap_stride = (int)p.tap_stride;
 
     f32x4 ra[AR], rb[BR];
     auto load_tile = [&]() {
+        const bool kok = kap < p.k_end;
+        const int toff = tap * tap_stride + c;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            const bool ok = kap < p.k_end && (unsigned)(ap0[i] + tap) < (unsigned)p.in_len;
-            ra[i] = ok ? *reinterpret_cast<const f32x4 *>(p.x + abase[i] + tap * p.tap_stride + c)
-                       : f32x4{0.f, 0.f, 0.f, 0.f};
+            const bool ok = kok && (unsigned)(ap0[i] + tap) < (unsigned)p.in_len;
+            ra[i] = buf_load4(srd_a, ok ? (unsigned)(aoff[i] + toff) * 4u : BUF_OOB);
         }
 #pragma unroll
-        for (int j = 0; j < BR; ++j) {
-            const int n = n0 + rowq + 32 * j;
-            const bool ok = kap < p.k_end && n < p.N;
-            rb[j] = ok ? *reinterpret_cast<const f32x4 *>(p.w + (int64_t)n * p.K + kap)
-                       : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int j = 0; j < BR; ++j) rb[j] = buf_load4(srd_b, kok ? boff[j] + (unsigned)kap * 4u : BUF_OOB);
         kap += BK;
         c += BK;
-        while (c >= p.Ci) { c -= p.Ci; ++tap; }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { const bool w = c >= p.Ci; c -= w ? p.Ci : 0; tap += w ? 1 : 0; }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](float *Ad, float *Bd) {
 #pragma unroll
         for (int i = 0; i < AR; ++i)
-            *reinterpret_cast<f32x4 *>(&As[(rowq + 32 * i) * LDK + col4 * 4]) = ra[i];
+            *reinterpret_cast<f32x4 *>(&Ad[(rowq + 32 * i) * LDK + col4 * 4]) = ra[i];
 #pragma unroll
         for (int j = 0; j < BR; ++j)
-            *reinterpret_cast<f32x4 *>(&Bs[(rowq + 32 * j) * LDK + col4 * 4]) = rb[j];
+            *reinterpret_cast<f32x4 *>(&Bd[(rowq + 32 * j) * LDK + col4 * 4]) = rb[j];
     };
 
     f32x16 acc[TM][TN];
@@ -121,40 +116,46 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Main loop: LDS double buffer, ONE barrier per K-tile.  The global loads of tile kt+1 are
+    // issued right after the first fragment reads of tile kt and their LDS stores (into the
+    // other buffer) right before the last MFMA group, so both sit in MFMA shadows.
     const int nk = (p.k_end - p.k_begin + BK - 1) / BK;
     load_tile();
-    store_tile();
+    store_tile(As, Bs);
     __syncthreads();
     const int l31 = lane & 31, lhalf = lane >> 5;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_tile();
+        const float *Ac = As + (kt & 1) * (BM * LDK), *Bc = Bs + (kt & 1) * (BN * LDK);
+        float *An = As + ((kt + 1) & 1) * (BM * LDK), *Bn = Bs + ((kt + 1) & 1) * (BN * LDK);
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
             f32x4 a4[TM], b4[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                a4[i] = *reinterpret_cast<const f32x4 *>(
-                    &As[(wm * WM + i * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
+                a4[i] = *reinterpret_cast<const f32x4 *>(&Ac[(wm * WM + i * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                b4[j] = *reinterpret_cast<const f32x4 *>(
-                    &Bs[(wn * WN + j * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
+                b4[j] = *reinterpret_cast<const f32x4 *>(&Bc[(wn * WN + j * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
+            // unconditional (past the last tile every lane is out of range and reads zeros):
+            // keeps the iteration one basic block so loads/stores interleave with the MFMAs
+            if (kk == 0) {
+                load_tile();
+                __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs (never sink it)
+            }
+            if (kk == BK / 8 - 1) store_tile(An, Bn);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][s], b4[j][s],
-                                                                         acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][s], b4[j][s], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
-        if (kt + 1 < nk) {
-            store_tile();
-            __syncthreads();
-        }
     }
-    // epilogue: + bias, store.  C layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // epilogue: + bias, bounds-checked stores (rows >= M and cols >= N fall outside the SRD).
+    // C layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const __amdgpu_buffer_rsrc_t srd_y = make_srd(p.y + m0 * p.N, (unsigned long long)(p.M - m0) * p.N * 4ull);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * WN + j * 32 + l31;
@@ -163,8 +164,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmConvParams p) {
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-                if (m < p.M && n < p.N) p.y[m * p.N + n] = acc[i][j][r] + bv;
+                const int ml = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                buf_store1(srd_y, n < p.N ? (unsigned)(ml * p.N + n) * 4u : BUF_OOB, acc[i][j][r] + bv);
             }
         }
     }

@@ -1,0 +1,554 @@
+// LayerNorm-fused encoder path for gfx950 ("fuller" models: every conv2 is a full conv).
+//
+// The reference normalises every conv output over the whole (C,F,T) sample before the next
+// conv (model.py:58-72), i.e. 16 grid-wide reductions per forward.  Unfused that is two extra
+// HBM round trips per sub-layer (csrc/encoder.hip: ln_act_kernel, 20 % of the step).  Here:
+//
+//   producer epilogue : z = PRE(acc + bias) is stored once, and the block reduces its tile to
+//                       per-sample partial (sum, sum of squares) in a FIXED order (registers ->
+//                       wave shuffle -> LDS -> one thread), written to part[b][slot][2];
+//   consumer prologue : reduces the <= 64 partials of the samples its tile touches (fp64) to
+//                       (mean, rstd) in LDS;
+//   consumer A-loader : while staging the activation tile global -> registers -> LDS it applies
+//                       v = POST((z - mean) * rstd * W + B), W/B being the full-size LayerNorm
+//                       affine tensors in the same channels-last order (L2/Infinity-Cache
+//                       resident, shared by the whole batch); padding stays exactly 0.
+//   (PRE, POST) = (identity, act) for relu_after_bn, (act, identity) otherwise.
+//
+// No atomics: results are bit-reproducible run to run.  The normalised tensor never exists in HBM.
+#include "kernels.h"
+
+namespace pfann {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct FusedGemmParams {
+    const float *x, *w, *bias;
+    float *y;
+    int64_t M;
+    int N, K, Ci;
+    int rows_per_sample, To, F, T;
+    int axis, stride, pad_lo, in_len;
+    int64_t tap_stride;
+    int n_tiles_n;
+    int k_begin, k_end;
+    // input normalisation
+    const float *in_part; int in_P;
+    const float *ln_w, *ln_b;
+    double inv_n_in;
+    int64_t in_elems;            // F*T*Ci
+    // output statistics
+    float *out_part; int out_P;
+    int act, after_bn;
+    int64_t n_samples;
+};
+
+// RELU_BN = true: the default model (ReLU applied after LayerNorm) with the activation folded
+// into straight-line code; false: generic (ELU and/or activation before LayerNorm).
+template <int BM, int BN, int WM, int WN, bool RELU_BN>
+__global__ __launch_bounds__(256) void conv_gemm_ln_kernel(FusedGemmParams p) {
+    constexpr int BK = 32, LDK = BK + 4;
+    constexpr int WAVES_N = BN / WN;
+    static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int AR = BM / 32, BR = BN / 32;
+    __shared__ __attribute__((aligned(16))) float As[2 * BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BN * LDK];
+    __shared__ float s_mu[BM], s_rs[BM];
+    __shared__ double s_red[8];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = L / p.n_tiles_n, nt = L - mt * p.n_tiles_n;
+    const int64_t m0 = (int64_t)mt * BM;
+    const int n0 = nt * BN;
+    const int rps = p.rows_per_sample;
+
+    // ---- (mean, rstd) of every input sample this tile touches -----------------------------
+    const int64_t b_first = m0 / rps;
+    const int ns = rps >= BM ? 1 : BM / rps;
+    if (ns == 1) {
+        double s1 = 0, s2 = 0;
+        const float *pp = p.in_part + b_first * p.in_P * 2;
+        for (int i = tid; i < p.in_P; i += 256) { s1 += (double)pp[2 * i]; s2 += (double)pp[2 * i + 1]; }
+        s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+        if (lane == 0) { s_red[wave] = s1; s_red[4 + wave] = s2; }
+        __syncthreads();
+        if (tid == 0) {
+            const double t1 = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+            const double t2 = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+            const double mean = t1 * p.inv_n_in;
+            double var = t2 * p.inv_n_in - mean * mean;
+            if (var < 0) var = 0;
+            s_mu[0] = (float)mean;
+            s_rs[0] = (float)(1.0 / sqrt(var + 1e-5));
+        }
+    } else if (tid < ns && b_first + tid < p.n_samples) {
+        const float *pp = p.in_part + (b_first + tid) * p.in_P * 2;
+        double s1 = 0, s2 = 0;
+        for (int i = 0; i < p.in_P; ++i) { s1 += (double)pp[2 * i]; s2 += (double)pp[2 * i + 1]; }
+        const double mean = s1 * p.inv_n_in;
+        double var = s2 * p.inv_n_in - mean * mean;
+        if (var < 0) var = 0;
+        s_mu[tid] = (float)mean;
+        s_rs[tid] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+    __syncthreads();
+
+    const int col4 = tid & 7, rowq = tid >> 3;
+    // bounds-checked buffer loads (OOB lanes read 0): activation window from the first sample of
+    // the tile, LayerNorm affine tensors addressed sample-relative, weights by output channel
+    const __amdgpu_buffer_rsrc_t srd_a =
+        make_srd(p.x + b_first * p.in_elems, (unsigned long long)(p.n_samples - b_first) * p.in_elems * 4ull);
+    const __amdgpu_buffer_rsrc_t srd_w = make_srd(p.ln_w, (unsigned long long)p.in_elems * 4ull);
+    const __amdgpu_buffer_rsrc_t srd_lb = make_srd(p.ln_b, (unsigned long long)p.in_elems * 4ull);
+    const __amdgpu_buffer_rsrc_t srd_b = make_srd(p.w, (unsigned long long)p.N * p.K * 4ull);
+    int aoff[AR], arel[AR], ap0[AR];
+    float amu[AR], ars[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const int64_t m = m0 + rowq + 32 * i;
+        if (m < p.M) {
+            const int64_t b = m / rps;
+            const int r = (int)(m - b * rps);
+            const int fo = r / p.To, to = r - fo * p.To;
+            int rel;
+            if (p.axis == 0) { ap0[i] = to * p.stride - p.pad_lo; rel = (fo * p.T + ap0[i]) * p.Ci; }
+            else { ap0[i] = fo * p.stride - p.pad_lo; rel = (ap0[i] * p.T + to) * p.Ci; }
+            const int sl = (int)(b - b_first);
+            arel[i] = rel;
+            aoff[i] = sl * (int)p.in_elems + rel;
+            amu[i] = s_mu[sl];
+            ars[i] = s_rs[sl];
+        } else {
+            ap0[i] = -(1 << 20);
+            aoff[i] = 0; arel[i] = 0; amu[i] = 0.f; ars[i] = 0.f;
+        }
+    }
+    unsigned boff[BR];
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+        const int n = n0 + rowq + 32 * j;
+        boff[j] = n < p.N ? (unsigned)n * (unsigned)p.K * 4u : BUF_OOB;
+    }
+    int kap = p.k_begin + col4 * 4;
+    int tap = kap / p.Ci, c = kap - tap * p.Ci;
+    const int tap_stride = (int)p.tap_stride;
+
+    f32x4 ra[AR], rw[AR], rbb[AR], rb[BR];
+    unsigned okmask = 0;
+    auto load_tile = [&]() {
+        const bool kok = kap < p.k_end;
+        const int toff = tap * tap_stride + c;
+        okmask = 0;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const bool ok = kok && (unsigned)(ap0[i] + tap) < (unsigned)p.in_len;
+            okmask |= ok ? (1u << i) : 0u;
+            ra[i] = buf_load4(srd_a, ok ? (unsigned)(aoff[i] + toff) * 4u : BUF_OOB);
+            rw[i] = buf_load4(srd_w, ok ? (unsigned)(arel[i] + toff) * 4u : BUF_OOB);
+            rbb[i] = buf_load4(srd_lb, ok ? (unsigned)(arel[i] + toff) * 4u : BUF_OOB);
+        }
+#pragma unroll
+        for (int j = 0; j < BR; ++j) rb[j] = buf_load4(srd_b, kok ? boff[j] + (unsigned)kap * 4u : BUF_OOB);
+        kap += BK;
+        c += BK;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { const bool w = c >= p.Ci; c -= w ? p.Ci : 0; tap += w ? 1 : 0; }
+    };
+    // v = POST((z - mean) * rstd * W + B); padding / out-of-range lanes must stay exactly 0
+    auto store_tile = [&](float *Ad, float *Bd) {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const bool ok = (okmask >> i) & 1u;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = (ra[i][e] - amu[i]) * ars[i] * rw[i][e] + rbb[i][e];
+                if (RELU_BN) t = fmaxf(t, 0.f);
+                else t = p.after_bn ? act_fn(t, p.act) : t;
+                v[e] = ok ? t : 0.f;
+            }
+            *reinterpret_cast<f32x4 *>(&Ad[(rowq + 32 * i) * LDK + col4 * 4]) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < BR; ++j)
+            *reinterpret_cast<f32x4 *>(&Bd[(rowq + 32 * j) * LDK + col4 * 4]) = rb[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // LDS double buffer, one barrier per K-tile (see csrc/encoder.hip for the schedule)
+    const int nk = (p.k_end - p.k_begin + BK - 1) / BK;
+    load_tile();
+    store_tile(As, Bs);
+    __syncthreads();
+    const int l31 = lane & 31, lhalf = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const float *Ac = As + (kt & 1) * (BM * LDK), *Bc = Bs + (kt & 1) * (BN * LDK);
+        float *An = As + ((kt + 1) & 1) * (BM * LDK), *Bn = Bs + ((kt + 1) & 1) * (BN * LDK);
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            f32x4 a4[TM], b4[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a4[i] = *reinterpret_cast<const f32x4 *>(&Ac[(wm * WM + i * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b4[j] = *reinterpret_cast<const f32x4 *>(&Bc[(wn * WN + j * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
+            if (kk == 0) {
+                load_tile();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (kk == BK / 8 - 1) {
+                __builtin_amdgcn_sched_barrier(0);   // ...and never hoist the dependent store phase
+                store_tile(An, Bn);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][s], b4[j][s], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: z = PRE(acc + bias) -> HBM; per-sample partial statistics -------------
+    // C layout of a 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    const __amdgpu_buffer_rsrc_t srd_y = make_srd(p.y + m0 * p.N, (unsigned long long)(p.M - m0) * p.N * 4ull);
+    float *red1 = As;                 // [BM][WAVES_N] row (or sub-tile) sums; As/Bs are free now
+    float *red2 = As + BM * WAVES_N;
+    const int G = rps >= BM ? BM : rps;          // rows per statistics group inside the tile
+    float bv[TN];
+    bool nok[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 32 + l31;
+        nok[j] = n < p.N;
+        bv[j] = nok[j] ? p.bias[n] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        float rs1[16], rs2[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float z = acc[i][j][r] + bv[j];
+                if (!RELU_BN && !p.after_bn) z = act_fn(z, p.act);
+                if (m < p.M && nok[j]) {
+                    a1 += z;
+                    a2 = fmaf(z, z, a2);
+                }
+                buf_store1(srd_y, nok[j] ? (unsigned)((int)(m - m0) * p.N + n0 + wn * WN + j * 32 + l31) * 4u : BUF_OOB, z);
+            }
+            rs1[r] = a1; rs2[r] = a2;
+        }
+        if (G >= 32) {
+            // the whole 32-row sub-tile belongs to one sample: registers first, then the wave
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { t1 += rs1[r]; t2 += rs2[r]; }
+            t1 = wave_sum(t1); t2 = wave_sum(t2);
+            if (lane == 0) {
+                red1[(wm * WM + i * 32) * WAVES_N + wn] = t1;
+                red2[(wm * WM + i * 32) * WAVES_N + wn] = t2;
+            }
+        } else {
+            // several samples inside the sub-tile: per-row sums across the 32 lanes of a half
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float t1 = rs1[r], t2 = rs2[r];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o, 64); t2 += __shfl_xor(t2, o, 64); }
+                if (l31 == 0) {
+                    const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                    red1[row * WAVES_N + wn] = t1;
+                    red2[row * WAVES_N + wn] = t2;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int ngroups = BM / G;
+        if (tid < ngroups) {
+            const int64_t mg = m0 + (int64_t)tid * G;
+            if (mg < p.M) {
+                float t1 = 0.f, t2 = 0.f;
+                const int step = G >= 32 ? 32 : 1;
+                for (int row = tid * G; row < (tid + 1) * G; row += step)
+                    for (int w = 0; w < WAVES_N; ++w) { t1 += red1[row * WAVES_N + w]; t2 += red2[row * WAVES_N + w]; }
+                const int64_t b = mg / rps;
+                const int slot = (int)((mg - b * rps) / G) * p.n_tiles_n + nt;
+                float *o = p.out_part + (b * p.out_P + slot) * 2;
+                o[0] = t1;
+                o[1] = t2;
+            }
+        }
+    }
+}
+
+static void live_taps(const SubLayer &L, int in_len, int &k_begin, int &k_end) {
+    const int out_len = L.axis == 0 ? L.To : L.Fo;
+    int lo = 3, hi = -1;
+    for (int tap = 0; tap < 3; ++tap)
+        for (int o = 0; o < out_len; ++o) {
+            const int pos = o * L.stride - L.pad_lo + tap;
+            if (pos >= 0 && pos < in_len) { lo = tap < lo ? tap : lo; hi = tap > hi ? tap : hi; break; }
+        }
+    k_begin = lo * L.ci;
+    k_end = (hi + 1) * L.ci;
+}
+
+// tile size used for sub-layer L at batch B (shared by the launcher and the partial-slot planner)
+static int gemm_tile(const SubLayer &L, int64_t B) {
+    const int64_t M = B * L.Fo * L.To;
+    const int64_t blocks128 = (int64_t)cdiv(M, 128) * cdiv(L.co, 128);
+    return (L.co >= 128 && blocks128 >= 512) ? 128 : 64;
+}
+
+int fused_out_slots(const SubLayer &L, int64_t B) {
+    const int rps = L.Fo * L.To;
+    if (L.ci == 1) return rps / 64 > 0 ? rps / 64 : 1;       // conv_first_stats: 64 rows per block
+    const int bt = gemm_tile(L, B);
+    return (rps >= bt ? rps / bt : 1) * cdiv(L.co, bt);
+}
+
+bool fused_supported(const SubLayer *sub, int n) {
+    for (int i = 0; i < n; ++i) {
+        const SubLayer &L = sub[i];
+        const int rps = L.Fo * L.To;
+        if (L.depthwise) return false;
+        if (rps & (rps - 1)) return false;                  // power of two: tiles never straddle samples unevenly
+        if (L.ci == 1) { if (i != 0 || rps % 64 || L.co % 4) return false; }
+        else if (L.ci % 4) return false;
+    }
+    return true;
+}
+
+int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, const float *in_part, int in_P,
+                        float *y, float *out_part, int64_t B, int act, int after_bn, hipStream_t s) {
+    FusedGemmParams p;
+    p.x = x; p.w = L.w; p.bias = L.bias; p.y = y;
+    p.rows_per_sample = L.Fo * L.To;
+    p.M = B * p.rows_per_sample;
+    p.N = L.co; p.Ci = L.ci; p.K = 3 * L.ci;
+    p.To = L.To; p.F = L.F; p.T = L.T;
+    p.axis = L.axis; p.stride = L.stride; p.pad_lo = L.pad_lo;
+    p.in_len = L.axis == 0 ? L.T : L.F;
+    p.tap_stride = L.axis == 0 ? (int64_t)L.ci : (int64_t)L.T * L.ci;
+    live_taps(L, p.in_len, p.k_begin, p.k_end);
+    p.in_part = in_part; p.in_P = in_P;
+    p.ln_w = Lin.ln_w; p.ln_b = Lin.ln_b;
+    p.in_elems = (int64_t)L.F * L.T * L.ci;
+    p.inv_n_in = 1.0 / (double)p.in_elems;
+    p.out_part = out_part; p.out_P = fused_out_slots(L, B);
+    p.act = act; p.after_bn = after_bn;
+    p.n_samples = B;
+    const double flops = 2.0 * (double)p.M * p.N * (p.k_end - p.k_begin);
+    if (gemm_tile(L, B) == 128) {
+        p.n_tiles_n = cdiv(p.N, 128);
+        const int64_t blocks = (int64_t)cdiv(p.M, 128) * p.n_tiles_n;
+        ProfScope ps("conv_gemm_ln_128", s, flops);
+        if (act == 0 && after_bn)
+            hipLaunchKernelGGL((conv_gemm_ln_kernel<128, 128, 64, 64, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((conv_gemm_ln_kernel<128, 128, 64, 64, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    } else {
+        p.n_tiles_n = cdiv(p.N, 64);
+        const int64_t blocks = (int64_t)cdiv(p.M, 64) * p.n_tiles_n;
+        ProfScope ps("conv_gemm_ln_64", s, flops);
+        if (act == 0 && after_bn)
+            hipLaunchKernelGGL((conv_gemm_ln_kernel<64, 64, 32, 32, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((conv_gemm_ln_kernel<64, 64, 32, 32, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    }
+    PF_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// First conv (ci == 1) with statistics: one block = 64 output positions x all channels.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_first_stats_kernel(const float *__restrict__ x,
+                                                               const float *__restrict__ w,
+                                                               const float *__restrict__ bias,
+                                                               float *__restrict__ y, float *__restrict__ part,
+                                                               int64_t M, int co, int To, int T, int stride,
+                                                               int pad_lo, int rps, int P, int act, int after_bn) {
+    __shared__ float red[8];
+    const int co4 = co >> 2;
+    const int64_t mb = (int64_t)blockIdx.x * 64;
+    const int tid = threadIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+    for (int e = tid; e < 64 * co4; e += 256) {
+        const int64_t m = mb + e / co4;
+        if (m >= M) break;
+        const int c = (e % co4) * 4;
+        const int64_t bf = m / To;
+        const int to = (int)(m - bf * To);
+        const int p0 = to * stride - pad_lo;
+        f32x4 o = *reinterpret_cast<const f32x4 *>(bias + c);
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            const int t = p0 + tap;
+            if ((unsigned)t < (unsigned)T) {
+                const float xv = x[bf * T + t];
+                const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + tap * co + c);
+                o += xv * wv;
+            }
+        }
+        if (!after_bn) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = act_fn(o[q], act);
+        }
+        *reinterpret_cast<f32x4 *>(y + m * co + c) = o;
+        s1 += (o[0] + o[1]) + (o[2] + o[3]);
+        s2 += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if ((tid & 63) == 0) { red[tid >> 6] = s1; red[4 + (tid >> 6)] = s2; }
+    __syncthreads();
+    if (tid == 0 && mb < M) {
+        const int64_t b = mb / rps;
+        const int slot = (int)((mb - b * rps) / 64);
+        float *o = part + (b * P + slot) * 2;
+        o[0] = (red[0] + red[1]) + (red[2] + red[3]);
+        o[1] = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+}
+
+int launch_conv_first_stats(const SubLayer &L, const float *x, float *y, float *part, int64_t B, int act,
+                            int after_bn, hipStream_t s) {
+    const int rps = L.Fo * L.To;
+    const int64_t M = B * rps;
+    ProfScope ps("conv_first_stats", s, 4.0 * ((double)M * L.co + (double)B * L.F * L.T));
+    hipLaunchKernelGGL(conv_first_stats_kernel, dim3((unsigned)cdiv(M, 64)), dim3(256), 0, s, x, L.w, L.bias, y,
+                       part, M, L.co, L.To, L.T, L.stride, L.pad_lo, rps, fused_out_slots(L, B), act, after_bn);
+    PF_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// Materialise POST(LN(z)) from partials (verification taps; also the generic fallback).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_apply_kernel(const float *__restrict__ z, const float *__restrict__ part,
+                                                       int P, const float *__restrict__ w,
+                                                       const float *__restrict__ b, float *__restrict__ out, int n,
+                                                       int act, int after_bn) {
+    __shared__ double red[8];
+    __shared__ float stat[2];
+    const int tid = threadIdx.x;
+    const float *pp = part + (int64_t)blockIdx.x * P * 2;
+    double s1 = 0, s2 = 0;
+    for (int i = tid; i < P; i += 256) { s1 += (double)pp[2 * i]; s2 += (double)pp[2 * i + 1]; }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+    if ((tid & 63) == 0) { red[tid >> 6] = s1; red[4 + (tid >> 6)] = s2; }
+    __syncthreads();
+    if (tid == 0) {
+        const double t1 = (red[0] + red[1]) + (red[2] + red[3]), t2 = (red[4] + red[5]) + (red[6] + red[7]);
+        const double mean = t1 / n;
+        double var = t2 / n - mean * mean;
+        if (var < 0) var = 0;
+        stat[0] = (float)mean;
+        stat[1] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+    __syncthreads();
+    const float mean = stat[0], rstd = stat[1];
+    const float *zi = z + (int64_t)blockIdx.x * n;
+    float *oi = out + (int64_t)blockIdx.x * n;
+    for (int i = tid; i < n; i += 256) {
+        const float t = (zi[i] - mean) * rstd * w[i] + b[i];
+        oi[i] = after_bn ? act_fn(t, act) : t;
+    }
+}
+
+int launch_ln_apply(const SubLayer &L, const float *z, const float *part, int P, float *out, int64_t B, int act,
+                    int after_bn, hipStream_t s) {
+    const int n = L.co * L.Fo * L.To;
+    hipLaunchKernelGGL(ln_apply_kernel, dim3((unsigned)B), dim3(256), 0, s, z, part, P, L.ln_w, L.ln_b, out, n, act,
+                       after_bn);
+    PF_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// Projection head with the last LayerNorm(+act) applied on load.
+// ------------------------------------------------------------------------------------
+__global__ void myg_ln_kernel(const float *__restrict__ z, const float *__restrict__ part, int P,
+                              const float *__restrict__ lw, const float *__restrict__ lb, int act, int after_bn,
+                              const float *__restrict__ w1, const float *__restrict__ b1,
+                              const float *__restrict__ w2, const float *__restrict__ b2, int d, int u, int v,
+                              float *__restrict__ emb, int normalize) {
+    __shared__ float red[16];
+    __shared__ float stat[2];
+    const int g = threadIdx.x;
+    const int h = d * v;
+    if (g == 0) {
+        const float *pp = part + (int64_t)blockIdx.x * P * 2;
+        double s1 = 0, s2 = 0;
+        for (int i = 0; i < P; ++i) { s1 += (double)pp[2 * i]; s2 += (double)pp[2 * i + 1]; }
+        const double mean = s1 / h;
+        double var = s2 / h - mean * mean;
+        if (var < 0) var = 0;
+        stat[0] = (float)mean;
+        stat[1] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+    __syncthreads();
+    const float mean = stat[0], rstd = stat[1];
+    const float *xs = z + (int64_t)blockIdx.x * h;
+    float y = 0.f;
+    if (g < d) {
+        float xin[32];
+        for (int j = 0; j < v; ++j) {
+            const float t = (xs[g * v + j] - mean) * rstd * lw[g * v + j] + lb[g * v + j];
+            xin[j] = after_bn ? act_fn(t, act) : t;
+        }
+        for (int k = 0; k < u; ++k) {
+            const float *wr = w1 + ((int64_t)g * u + k) * v;
+            float hsum = 0.f;
+            for (int j = 0; j < v; ++j) hsum = fmaf(wr[j], xin[j], hsum);
+            hsum += b1[g * u + k];
+            hsum = hsum > 0.f ? hsum : expm1f(hsum);
+            y = fmaf(w2[g * u + k], hsum, y);
+        }
+        y += b2[g];
+    }
+    if (normalize) {
+        float ss = wave_sum(g < d ? y * y : 0.f);
+        if ((g & 63) == 0) red[g >> 6] = ss;
+        __syncthreads();
+        float tot = 0.f;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) tot += red[i];
+        y = y / fmaxf(sqrtf(tot), 1e-12f);
+    }
+    if (g < d) emb[(int64_t)blockIdx.x * d + g] = y;
+}
+
+int launch_myg_ln(const SubLayer &Llast, const float *z, const float *part, int P, int act, int after_bn,
+                  const float *w1, const float *b1, const float *w2, const float *b2, int d, int u, int v, int64_t B,
+                  float *emb, int normalize, hipStream_t s) {
+    if (v > 32) { set_error("MyG: h/d = %d > 32 unsupported", v); return -1; }
+    const int nt = ((d + 63) / 64) * 64;
+    if (nt > 1024) { set_error("MyG: d = %d > 1024 unsupported", d); return -1; }
+    ProfScope ps("myg_ln", s);
+    hipLaunchKernelGGL(myg_ln_kernel, dim3((unsigned)B), dim3(nt), 0, s, z, part, P, Llast.ln_w, Llast.ln_b, act,
+                       after_bn, w1, b1, w2, b2, d, u, v, emb, normalize);
+    PF_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace pfann

@@ -31,6 +31,19 @@ int launch_myg(const float *x, const float *w1, const float *b1, const float *w2
                int d, int u, int v, int64_t B, float *emb, int normalize, hipStream_t s);
 int launch_cl_to_nchw(const float *x, float *y, int64_t B, int C, int HW, hipStream_t s);
 
+// ---- encoder_fused.hip (LayerNorm fused into the GEMM; "fuller" models) -------------------
+bool fused_supported(const SubLayer *sub, int n);
+int fused_out_slots(const SubLayer &L, int64_t B);
+int launch_conv_first_stats(const SubLayer &L, const float *x, float *y, float *part, int64_t B, int act,
+                            int after_bn, hipStream_t s);
+int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, const float *in_part, int in_P,
+                        float *y, float *out_part, int64_t B, int act, int after_bn, hipStream_t s);
+int launch_ln_apply(const SubLayer &L, const float *z, const float *part, int P, float *out, int64_t B, int act,
+                    int after_bn, hipStream_t s);
+int launch_myg_ln(const SubLayer &Llast, const float *z, const float *part, int P, int act, int after_bn,
+                  const float *w1, const float *b1, const float *w2, const float *b2, int d, int u, int v, int64_t B,
+                  float *emb, int normalize, hipStream_t s);
+
 // ---- search.hip ----------------------------------------------------------------------
 struct SearchWorkspace {
     int64_t cap_q = 0;      // query rows the buffers are sized for

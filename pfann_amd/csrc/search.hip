@@ -36,12 +36,6 @@ __device__ __forceinline__ unsigned long long pack_key(float score, unsigned row
     return ((unsigned long long)(~f2ord(score)) << 32) | row;
 }
 
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-    const int q = nblk >> 3, r = nblk & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return start + idx;
-}
 
 struct ScanParams {
     const float *q, *db;
@@ -61,8 +55,8 @@ __global__ __launch_bounds__(256) void scan_emit_kernel(ScanParams p) {
     static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int AR = (BM + 31) / 32, BR = BN / 32;
-    __shared__ __attribute__((aligned(16))) float As[BM * LDK];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
+    __shared__ __attribute__((aligned(16))) float As[2 * BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BN * LDK];
     __shared__ float thr_s[BM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -77,32 +71,41 @@ __global__ __launch_bounds__(256) void scan_emit_kernel(ScanParams p) {
         thr_s[tid] = (p.thr != nullptr && m < p.nq) ? p.thr[m] : -INFINITY;
     }
 
+    // bounds-checked buffer loads (OOB lanes read 0); the db window starts at this tile's first row
+    const __amdgpu_buffer_rsrc_t srd_q = make_srd(p.q + m0 * p.d, (unsigned long long)(p.nq - m0) * p.d * 4ull);
+    const int64_t row0 = n0 * p.row_stride;
+    const int64_t rows_left = (p.nrows - n0 - 1) * p.row_stride + 1;      // db rows from row0 to the last sampled one
+    const __amdgpu_buffer_rsrc_t srd_db = make_srd(p.db + row0 * p.d, (unsigned long long)rows_left * p.d * 4ull);
+    unsigned qoff[AR], doff[BR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const int rl = rowq + 32 * i;
+        qoff[i] = (rl < BM && m0 + rl < p.nq) ? (unsigned)rl * (unsigned)p.d * 4u : BUF_OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+        const int64_t rl = rowq + 32 * j;
+        const unsigned long long off = (unsigned long long)rl * p.row_stride * p.d * 4ull;
+        doff[j] = (n0 + rl < p.nrows && off < 0x7FFF0000ull) ? (unsigned)off : BUF_OOB;
+    }
     f32x4 ra[AR], rb[BR];
     int kap = col4 * 4;
     auto load_tile = [&]() {
+        const bool kok = kap < p.d;
 #pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            const int64_t m = m0 + rowq + 32 * i;
-            const bool ok = (rowq + 32 * i) < BM && m < p.nq && kap < p.d;
-            ra[i] = ok ? *reinterpret_cast<const f32x4 *>(p.q + m * p.d + kap) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int i = 0; i < AR; ++i) ra[i] = buf_load4(srd_q, kok ? qoff[i] + (unsigned)kap * 4u : BUF_OOB);
 #pragma unroll
-        for (int j = 0; j < BR; ++j) {
-            const int64_t n = n0 + rowq + 32 * j;
-            const bool ok = n < p.nrows && kap < p.d;
-            rb[j] = ok ? *reinterpret_cast<const f32x4 *>(p.db + n * p.row_stride * p.d + kap)
-                       : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int j = 0; j < BR; ++j) rb[j] = buf_load4(srd_db, kok ? doff[j] + (unsigned)kap * 4u : BUF_OOB);
         kap += BK;
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](float *Ad, float *Bd) {
 #pragma unroll
         for (int i = 0; i < AR; ++i)
             if ((rowq + 32 * i) < BM)
-                *reinterpret_cast<f32x4 *>(&As[(rowq + 32 * i) * LDK + col4 * 4]) = ra[i];
+                *reinterpret_cast<f32x4 *>(&Ad[(rowq + 32 * i) * LDK + col4 * 4]) = ra[i];
 #pragma unroll
         for (int j = 0; j < BR; ++j)
-            *reinterpret_cast<f32x4 *>(&Bs[(rowq + 32 * j) * LDK + col4 * 4]) = rb[j];
+            *reinterpret_cast<f32x4 *>(&Bd[(rowq + 32 * j) * LDK + col4 * 4]) = rb[j];
     };
 
     f32x16 acc[TM][TN];
@@ -113,22 +116,29 @@ __global__ __launch_bounds__(256) void scan_emit_kernel(ScanParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // LDS double buffer, one barrier per K-tile, prefetch pinned ahead of the MFMAs
     const int nk = (p.d + BK - 1) / BK;
     load_tile();
-    store_tile();
+    store_tile(As, Bs);
     __syncthreads();
     const int l31 = lane & 31, lhalf = lane >> 5;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_tile();
+        const float *Ac = As + (kt & 1) * (BM * LDK), *Bc = Bs + (kt & 1) * (BN * LDK);
+        float *An = As + ((kt + 1) & 1) * (BM * LDK), *Bn = Bs + ((kt + 1) & 1) * (BN * LDK);
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
             f32x4 a4[TM], b4[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                a4[i] = *reinterpret_cast<const f32x4 *>(&As[(wm * WM + i * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
+                a4[i] = *reinterpret_cast<const f32x4 *>(&Ac[(wm * WM + i * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                b4[j] = *reinterpret_cast<const f32x4 *>(&Bs[(wn * WN + j * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
+                b4[j] = *reinterpret_cast<const f32x4 *>(&Bc[(wn * WN + j * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
+            if (kk == 0) {
+                load_tile();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (kk == BK / 8 - 1) store_tile(An, Bn);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -138,10 +148,6 @@ __global__ __launch_bounds__(256) void scan_emit_kernel(ScanParams p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][s], b4[j][s], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
-        if (kt + 1 < nk) {
-            store_tile();
-            __syncthreads();
-        }
     }
     // epilogue: threshold filter + append.  acc[i][j][r]: query row = (r&3)+8*(r>>2)+4*lhalf,
     // db row = lane&31 of the 32x32 tile.

@@ -181,6 +181,10 @@ class Engine:
                                                   self._stream()), "pfann_pcm16_to_mono")
         return out
 
+    def set_fused_layernorm(self, on=True):
+        """-> True if the LayerNorm-fused GEMM path is now active."""
+        return bool(self.lib.pfann_set_fused_layernorm(self.handle, 1 if on else 0))
+
     # ---- verification taps -----------------------------------------------------------
     def debug_keep(self, on=True):
         self.lib.pfann_debug_keep(self.handle, 1 if on else 0)

@@ -45,6 +45,8 @@ SYMBOLS = {
     "pfann_pcm16_to_mono": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "pfann_debug_activation": (c_int64, [c_void_p, c_int, c_int64, c_void_p, c_int64]),
     "pfann_debug_keep": (None, [c_void_p, c_int]),
+    "pfann_set_fused_layernorm": (c_int, [c_void_p, c_int]),
+    "pfann_set_streams": (c_int, [c_void_p, c_int]),
     "pfann_db_create": (c_void_p, [c_int, c_int]),
     "pfann_db_destroy": (None, [c_void_p]),
     "pfann_db_dim": (c_int, [c_void_p]),

@@ -112,10 +112,18 @@ def naf_style_params():
     return p
 
 
+def elu_full_params():
+    """full conv2 (fused-LayerNorm capable) with ELU and activation-before-LN."""
+    p = json.load(open(os.path.join(REPO, "configs/tiny.json")))
+    p["model"].update(conv_activation="ELU", relu_after_bn=False, fuller=True)
+    return p
+
+
 def gen_encoder():
     from model import FpNetwork
     cases = {k: json.load(open(os.path.join(REPO, v))) for k, v in ENCODER_CASES.items()}
     cases["nafstyle"] = naf_style_params()
+    cases["elu_full"] = elu_full_params()
     for name, params in cases.items():
         d, h, u, F, T = synth.model_dims(params)
         net = FpNetwork(d, h, u, F, T, params["model"])

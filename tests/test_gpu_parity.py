@@ -128,10 +128,12 @@ def test_pcm16_to_mono_and_segment_embed(torch_cuda):
 
 
 # ------------------------------------------------------------------------------- encoder
-@pytest.mark.parametrize("name", ["tiny", "nafstyle", "n640d64", "seg", "default"])
-def test_encoder_vs_reference_golden(torch_cuda, name):
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("name", ["tiny", "nafstyle", "n640d64", "seg", "default", "elu_full"])
+def test_encoder_vs_reference_golden(torch_cuda, name, fused):
     """a3-a5: embeddings within 1e-4 of the reference's own outputs (golden), and every one
-    of the 16 sub-layer activations against the oracle."""
+    of the 16 sub-layer activations against the oracle -- for both encoder paths
+    (LayerNorm fused into the GEMMs / separate LayerNorm kernels)."""
     from oracle import encoder as oe
     from pfann_amd.engine import Engine
     z = np.load(os.path.join(G, "encoder_%s.npz" % name))
@@ -140,6 +142,8 @@ def test_encoder_vs_reference_golden(torch_cuda, name):
     sd = synth.make_state_dict(params, seed=123)
     eng = Engine(params, 0, max_batch=8)
     eng.load_state_dict(sd)
+    if eng.set_fused_layernorm(fused) != fused:
+        pytest.skip("fused LayerNorm path needs full conv2 layers (fuller=true)")
     eng.debug_keep(True)
     x = mg.encoder_inputs(F, T)
     xt = torch_cuda.as_tensor(x).cuda()
