@@ -211,6 +211,20 @@ def main():
                     "avg_launch_us": round(kv["avg_us"], 1), "launches_per_step": kv["launches_per_step"],
                     "algorithmic_work_per_launch": kv["work_per_launch"],
                     "share_of_step_time": round(kv["ms_per_step"] / (1e3 * elapsed / args.steps), 3)}
+    # HBM-side traffic per launch of the dominant kernel, from the committed PMC passes of this
+    # same command (tools/profile_bench.sh -> tools/make_traffic_json.py -> profiles/traffic.json)
+    if roofline is not None:
+        try:
+            tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
+            key = ROOF[dom][0].split("<")[0].split(" ")[0]
+            tmpl = ROOF[dom][0].split(" ")[0].replace(",", ", ")
+            for name, rec in tj.items():
+                if name.replace("void ", "").startswith(tmpl.split(">")[0]) or (key in name and "<" not in tmpl):
+                    roofline["traffic"] = rec["hbm_bytes_per_launch"]
+                    roofline["traffic_source"] = "%s PMC FETCH_SIZE x2 + WRITE_SIZE (%s)" % (rec["source"], name[:60])
+                    break
+        except (OSError, ValueError, KeyError):
+            pass
     if "scan_topk" in kernels:
         ks = kernels["scan_topk"]
         gbs = (r_hi - r_lo) * d * 4 / (ks["avg_us"] * 1e-6) / 1e9

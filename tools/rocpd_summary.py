@@ -26,15 +26,18 @@ def main(path):
         print("%-86s %7d %12.1f %11.1f %11.1f %11.1f %6.2f %5d %7d" %
               (name[:86], n, s / 1e3, a / 1e3, mn / 1e3, mx / 1e3, 100.0 * s / tot, (vg or 0) + (av or 0), lds or 0))
     try:
-        pm = c.execute("select k.name, p.name, count(*), sum(e.value) from rocpd_pmc_event e "
+        w2 = where.replace("start", "k.start")
+        pm = c.execute("select k.name, p.name, count(distinct k.id), sum(e.value) from rocpd_pmc_event e "
                        "join rocpd_info_pmc p on e.pmc_id = p.id "
-                       "join kernels k on k.id = e.event_id group by k.name, p.name order by k.name").fetchall()
-    except sqlite3.Error:
+                       "join kernels k on k.id = e.event_id %s group by k.name, p.name order by k.name" % w2).fetchall()
+    except sqlite3.Error as x:
+        print("pmc query failed:", x)
         pm = []
     if pm:
-        print("\nPMC counters (sum over dispatches):")
+        print("\nPMC counters, summed over the counter's hardware instances; per-dispatch average over the "
+              "dispatches in the region:")
         for kn, pn, n, v in pm:
-            print("%-70s %-24s n=%-6d sum=%.6g avg=%.6g" % (kn[:70], pn, n, v, v / max(n, 1)))
+            print("%-70s %-26s dispatches=%-5d sum=%.6g per_dispatch=%.6g" % (kn[:70], pn, n, v, v / max(n, 1)))
 
 
 if __name__ == "__main__":
