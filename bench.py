@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--cpu-queries", type=int, default=12, help="bounded sample for the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
+    ap.add_argument("--dump-decisions", default=None, help="write (song, offset, score) per query as .npy (rank 0)")
     args = ap.parse_args()
 
     import torch
@@ -68,10 +69,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node = --gpus"
     plib.require_gpu()
+    # PFANN_FORCE_DEVICE / PFANN_DIST_BACKEND=gloo: debugging aid to run the N-rank path on a box
+    # with a single GPU (all ranks share it); the driver's multi-GPU runs use neither.
+    if "PFANN_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["PFANN_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("PFANN_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     params = read_config(os.path.join(REPO, "configs", "default.json"))
     d, k = params["model"]["d"], params["indexer"]["top_k"]
@@ -160,7 +169,7 @@ def main():
     if prof:
         lib.pfann_prof_enable(0)
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     n_seg = Q * QUERY_SEGS
@@ -265,17 +274,21 @@ def main():
                          % (nq_cpu, nq_cpu * QUERY_SEGS, n_rows, k, os.cpu_count())}
         parity = {"queries": nq_cpu, "identical_song_and_offset": int(agree)}
 
+    if rank == 0 and args.dump_decisions:
+        np.save(args.dump_decisions, np.stack([res["song"].astype(np.float64), res["offset"].astype(np.float64),
+                                               res["score"].astype(np.float64)], 1))
     if rank == 0:
         out = {
-            "metric": "query segments/sec, 10 s @ SNR 0 queries vs 1M-segment db (exact flat IP top-100 + sequence match)",
+            "metric": "query segments/sec, 10 s @ SNR %g queries vs %s-segment db (exact flat IP top-100 + sequence match)"
+                      % (args.snr, "1M" if n_rows == 1000050 else str(n_rows)),
             "value": round(value, 1), "unit": "segments/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "1M-seg db (%d songs x %d segs, %d real synthetic songs + unit-norm filler rows), "
+            "config": {"workload": "%d-segment db (%d songs x %d segs, %d real synthetic songs + unit-norm filler rows), "
                                    "%d x 10 s queries/step at SNR %g dB (%d segments), configs/default.json encoder "
                                    "(d=128,h=1024,u=32,fuller), top_k=100" %
-                                   (n_songs, SEG_PER_SONG, len(real_ids), Q, args.snr, n_seg),
+                                   (n_rows, n_songs, SEG_PER_SONG, len(real_ids), Q, args.snr, n_seg),
                        "db_rows": n_rows, "queries_per_step": Q, "segments_per_step": n_seg,
                        "parallelism": "song-sharded db x%d" % world, "max_batch": args.max_batch},
             "top1_hit_rate": round(hits / Q, 4), "top1_near_0.5s": round(near / Q, 4),

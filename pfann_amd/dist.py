@@ -49,6 +49,8 @@ def split_even(n, world):
 def all_gather_rows(x, group=None):
     """all_gather of equally shaped tensors -> [world, *x.shape]."""
     world = dist.get_world_size(group)
+    if x.is_cuda and dist.get_backend(group) == "gloo":       # debugging on one GPU: stage through host
+        return all_gather_rows(x.cpu(), group).to(x.device)
     out = torch.empty((world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
     dist.all_gather_into_tensor(out.view(-1), x.contiguous().view(-1), group=group)
     return out

@@ -1,0 +1,50 @@
+"""Query-embedding extractor, drop-in for the reference's extractemb.py:
+    python extractemb.py <query list> <database dir> <output embedding dir>
+Writes `query_embeddings` (raw float32 [*, d], unit-norm rows), `query_index` (int64 [n, 2] =
+start row, row count; a file that fails to load gets (pos, 0)), `queryList.txt`, `configs.json`
+(extractemb.py:57-95).  Embedding runs on the MI355X, many files per launch."""
+import os
+import shutil
+import sys
+
+import numpy as np
+import torch
+
+from .builder import embed_files
+from .engine import Engine
+from .musicdata import MusicDataset
+from .utils import StageTimer, read_config
+
+
+def main(argv=None):
+    argv = sys.argv if argv is None else argv
+    if len(argv) < 4:
+        print("Usage: python %s <query list> <database dir> <output embedding dir>" % argv[0])
+        return 1
+    file_list_for_query, dir_for_db, out_embed_dir = argv[1], argv[2], argv[3]
+    configs = os.path.join(dir_for_db, "configs.json")
+    params = read_config(configs)
+    print("loading model...")
+    engine = Engine(params, 0, max_batch=int(os.environ.get("PFANN_MAX_BATCH", "1024")))
+    engine.load_state_dict(torch.load(os.path.join(dir_for_db, "model.pt"), map_location="cpu"))
+    print("model loaded")
+    dataset = MusicDataset(file_list_for_query, params)
+    os.makedirs(out_embed_dir, exist_ok=True)
+    timer = StageTimer()
+    idx_pos = 0
+    index = np.zeros((len(dataset), 2), dtype=np.int64)
+    with open(os.path.join(out_embed_dir, "query_embeddings"), "wb") as fe:
+        for i, n_seg, emb in embed_files(engine, dataset, dataset.hop, timer=timer):
+            index[i] = (idx_pos, n_seg)
+            if n_seg:
+                fe.write(emb.cpu().numpy().tobytes())
+                idx_pos += n_seg
+    index.tofile(os.path.join(out_embed_dir, "query_index"))
+    print("total", idx_pos, "embeddings")
+    shutil.copyfile(file_list_for_query, os.path.join(out_embed_dir, "queryList.txt"))
+    shutil.copyfile(configs, os.path.join(out_embed_dir, "configs.json"))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

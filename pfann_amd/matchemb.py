@@ -1,0 +1,60 @@
+"""Matcher over pre-extracted embeddings, drop-in for the reference's matchemb.py:
+    python matchemb.py <query embedding dir> <database dir> <result file>
+Reads `query_embeddings` / `query_index` / `queryList.txt` (matchemb.py:33,47-51), searches and
+sequence-matches on the MI355X in batches, writes the matcher's three outputs.  A query with
+zero rows (load error at extraction) gets the matcher's `error` row."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from .database import Database
+from .matcher import ResultWriter
+from .utils import read_config, read_file_list
+
+
+def main(argv=None):
+    argv = sys.argv if argv is None else argv
+    if len(argv) < 4:
+        print("Usage: python %s <query embedding dir> <database dir> <result file>" % argv[0])
+        return 1
+    dir_for_query, dir_for_db, result_file = argv[1], argv[2], argv[3]
+    params = read_config(os.path.join(dir_for_db, "configs.json"))
+    file_list = read_file_list(os.path.join(dir_for_query, "queryList.txt"))
+    d = params["model"]["d"]
+    print("loading database...")
+    db = Database(dir_for_db, params["indexer"], params["hop_size"], device=0, d=d)
+    print("database loaded")
+    q = np.fromfile(os.path.join(dir_for_query, "query_embeddings"), dtype=np.float32).reshape([-1, d])
+    query_index = np.fromfile(os.path.join(dir_for_query, "query_index"), dtype=np.int64).reshape([-1, 2])
+    assert query_index.shape[0] == len(file_list)
+    tm_0 = time.time()
+    out = ResultWriter(result_file, len(db.songList))
+    group = int(os.environ.get("PFANN_QUERY_GROUP", "64"))
+    qdev = torch.as_tensor(q).to(db.index.device)
+    for g0 in range(0, len(file_list), group):
+        ids = list(range(g0, min(g0 + group, len(file_list))))
+        good = [i for i in ids if query_index[i, 1] > 0]
+        res = {}
+        if good:
+            rows = torch.cat([qdev[query_index[i, 0]: query_index[i, 0] + query_index[i, 1]] for i in good])
+            qlen = [int(query_index[i, 1]) for i in good]
+            qstart = np.concatenate([[0], np.cumsum(qlen)[:-1]])
+            for i, r in zip(good, db.query_batch(rows, qstart, qlen, want_song_scores=True)):
+                res[i] = r
+        for i in ids:
+            if i in res:
+                sco, (sid, tim), song_score = res[i]
+                out.write(file_list[i], db.songList[sid], sco, tim, song_score)
+            else:
+                out.write_error(file_list[i])
+        out.flush()
+    out.close()
+    print("total query time %.6fs" % (time.time() - tm_0))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -22,14 +22,41 @@ from .musicdata import MusicDataset
 from .utils import StageTimer, read_config
 
 
+class ResultWriter:
+    """The three matcher outputs (matcher.py:40-42,84,94-107,158-163; same in matchemb.py:27-29,55-78)."""
+
+    def __init__(self, result_file, n_songs):
+        self.fout = open(result_file, "w", encoding="utf8", newline="\n")
+        self.fout2 = open(os.path.splitext(result_file)[0] + "_detail.csv", "w", encoding="utf8", newline="\n")
+        self.fout_score = open(result_file + ".bin", "wb")
+        self.detail = csv.writer(self.fout2)
+        self.detail.writerow(["query", "answer", "score", "time", "part_scores"])
+        self.n_songs = n_songs
+
+    def write(self, name, ans, sco, tim, song_score):
+        self.fout.write("%s\t%s\n" % (name, ans))
+        self.detail.writerow([name, ans, sco, tim])
+        self.fout_score.write(song_score.tobytes())
+
+    def write_error(self, name):
+        self.write(name, "error", -1e999, 0, np.zeros([self.n_songs, 2], dtype=np.float32))
+
+    def flush(self):
+        self.fout.flush()
+        self.fout2.flush()
+
+    def close(self):
+        self.fout.close()
+        self.fout2.close()
+        self.fout_score.close()
+
+
 def main(argv=None):
     argv = sys.argv if argv is None else argv
     if len(argv) < 4:
         print("Usage: python %s <query list> <database dir> <result file>" % argv[0])
         return 1
     file_list_for_query, dir_for_db, result_file = argv[1], argv[2], argv[3]
-    result_file2 = os.path.splitext(result_file)[0] + "_detail.csv"
-    result_file_score = result_file + ".bin"
     params = read_config(os.path.join(dir_for_db, "configs.json"))
 
     print("loading model...")
@@ -44,49 +71,40 @@ def main(argv=None):
     timer = StageTimer()
     tm_0 = time.time()
     group = int(os.environ.get("PFANN_QUERY_GROUP", "64"))
-    with open(result_file, "w", encoding="utf8", newline="\n") as fout, \
-            open(result_file2, "w", encoding="utf8", newline="\n") as fout2, \
-            open(result_file_score, "wb") as fout_score:
-        detail_writer = csv.writer(fout2)
-        detail_writer.writerow(["query", "answer", "score", "time", "part_scores"])
-        n_songs = len(db.songList)
+    out = ResultWriter(result_file, len(db.songList))
 
-        def emit(items):
-            """items: list of (index, n_seg, emb) in list order."""
-            good = [(i, n, e) for i, n, e in items if n]
-            results = {}
-            if good:
-                with timer.stage("search+rerank"):
-                    emb = torch.cat([e for _, _, e in good])
-                    qlen = [n for _, n, _ in good]
-                    qstart = np.concatenate([[0], np.cumsum(qlen)[:-1]])
-                    out = db.query_batch(emb, qstart, qlen, want_song_scores=True)
-                for (i, _, _), r in zip(good, out):
-                    results[i] = r
-            with timer.stage("output answer"):
-                for i, n, _ in items:
-                    name = dataset.files[i]
-                    if n == 0:                                            # matcher.py:94-107
-                        ans, sco, tim = "error", -1e999, 0
-                        song_score = np.zeros([n_songs, 2], dtype=np.float32)
-                    else:
-                        sco, (sid, tim), song_score = results[i]
-                        ans = db.songList[sid]                            # sid == -1 -> last song (matcher.py:138)
-                    fout.write("%s\t%s\n" % (name, ans))
-                    detail_writer.writerow([name, ans, sco, tim])
-                    fout_score.write(song_score.tobytes())
-                fout.flush()
-                fout2.flush()
+    def emit(items):
+        """items: list of (index, n_seg, emb) in list order."""
+        good = [(i, n, e) for i, n, e in items if n]
+        results = {}
+        if good:
+            with timer.stage("search+rerank"):
+                emb = torch.cat([e for _, _, e in good])
+                qlen = [n for _, n, _ in good]
+                qstart = np.concatenate([[0], np.cumsum(qlen)[:-1]])
+                res = db.query_batch(emb, qstart, qlen, want_song_scores=True)
+            for (i, _, _), r in zip(good, res):
+                results[i] = r
+        with timer.stage("output answer"):
+            for i, n, _ in items:
+                name = dataset.files[i]
+                if n == 0:                                            # matcher.py:94-107
+                    out.write_error(name)
+                else:
+                    sco, (sid, tim), song_score = results[i]
+                    out.write(name, db.songList[sid], sco, tim, song_score)   # sid == -1 -> last song (matcher.py:138)
+            out.flush()
 
-        buf = []
-        # matcher.py:120-126 asks the model for norm=False and L2-normalises on the CPU;
-        # the same formula runs inside the projection kernel here.
-        for item in embed_files(engine, dataset, dataset.hop, batch_windows=group * 19, timer=timer):
-            buf.append(item)
-            if len(buf) >= group:
-                emit(buf)
-                buf = []
-        emit(buf)
+    buf = []
+    # matcher.py:120-126 asks the model for norm=False and L2-normalises on the CPU; the same
+    # formula runs inside the projection kernel here.
+    for item in embed_files(engine, dataset, dataset.hop, batch_windows=group * 19, timer=timer):
+        buf.append(item)
+        if len(buf) >= group:
+            emit(buf)
+            buf = []
+    emit(buf)
+    out.close()
     print("stages:", {k: round(v, 3) for k, v in timer.t.items()})
     print("total query time %.6fs" % (time.time() - tm_0))
     return 0

@@ -32,3 +32,27 @@ def test_bench_json_contract_small():
     par = out["oracle_decision_parity"]
     assert par["identical_song_and_offset"] == par["queries"]
     assert out["top1_hit_rate"] > 0.5
+
+
+def test_two_rank_sharded_path_matches_single_gpu(tmp_path):
+    """N>1 on the real kernels: 2 ranks sharing this box's GPU (gloo-staged collectives, debugging
+    aid) must reach exactly the single-GPU decisions."""
+    import numpy as np
+    common = ["--steps", "1", "--warmup", "0", "--queries", "24", "--db-songs", "600", "--real-songs", "8",
+              "--no-cpu-baseline", "--no-prof", "--max-batch", "512"]
+    one = str(tmp_path / "one.npy")
+    two = str(tmp_path / "two.npy")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + common + ["--dump-decisions", one],
+                       capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, PFANN_DIST_BACKEND="gloo", PFANN_FORCE_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29733", os.path.join(REPO, "bench.py"),
+                        "--gpus", "2"] + common + ["--dump-decisions", two],
+                       capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    a, b = np.load(one), np.load(two)
+    assert np.array_equal(a[:, :2], b[:, :2])
+    assert np.abs(a[:, 2] - b[:, 2]).max() < 1e-6
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong"

@@ -125,3 +125,53 @@ def test_builder_and_matcher_cli_vs_oracle(tmp_path, cfgname):
             hits += (song == truth[j][0] and abs(sec - truth[j][1]) <= 0.5)
     if cfgname == "default":
         assert hits >= 6          # random-weight encoder still identifies clean crops
+
+
+def test_extractemb_matchemb_seam_and_accuracy(tmp_path):
+    """extractemb -> matchemb reproduces matcher's outputs byte for byte,
+    and the accuracy evaluator reads them; synthetic dataset + SNR protocol of genquery/genall."""
+    import torch
+    params = json.load(open(os.path.join(REPO, "configs", "tiny.json")))
+    sd = synth.make_state_dict(params, seed=11)
+    mdir = tmp_path / "model"
+    mdir.mkdir()
+    torch.save({n: torch.from_numpy(v) for n, v in sd.items()}, str(mdir / "model.pt"))
+    shutil.copy(os.path.join(REPO, "configs", "tiny.json"), str(mdir / "configs.json"))
+    env = dict(os.environ, PYTHONPATH=REPO)
+    data = str(tmp_path / "data")
+
+    def run(*cmd):
+        r = subprocess.run([sys.executable] + list(cmd), capture_output=True, text=True, env=env,
+                           cwd=str(tmp_path), timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        return r.stdout
+
+    run(os.path.join(REPO, "tools", "gen_synth_dataset.py"), data, "--songs", "8", "--queries", "12",
+        "--seconds", "5", "--song-seconds", "12", "--snr", "20", "0")
+    open(os.path.join(data, "query_snr20", "list.txt"), "a").write(os.path.join(data, "nope.wav") + "\n")
+    db = str(tmp_path / "db")
+    run(os.path.join(REPO, "builder.py"), os.path.join(data, "music.txt"), db, str(mdir))
+    for snr in ("20", "0"):
+        qd = os.path.join(data, "query_snr" + snr)
+        r1, r2 = str(tmp_path / ("m%s.txt" % snr)), str(tmp_path / ("e%s.txt" % snr))
+        run(os.path.join(REPO, "matcher.py"), os.path.join(qd, "list.txt"), db, r1)
+        run(os.path.join(REPO, "extractemb.py"), os.path.join(qd, "list.txt"), db, str(tmp_path / ("emb" + snr)))
+        run(os.path.join(REPO, "matchemb.py"), str(tmp_path / ("emb" + snr)), db, r2)
+        for suffix in ("", ".bin"):
+            assert open(r1 + suffix, "rb").read() == open(r2 + suffix, "rb").read(), (snr, suffix)
+        d1 = open(os.path.splitext(r1)[0] + "_detail.csv", "rb").read()
+        d2 = open(os.path.splitext(r2)[0] + "_detail.csv", "rb").read()
+        assert d1 == d2
+        qi = np.fromfile(os.path.join(str(tmp_path / ("emb" + snr)), "query_index"), dtype=np.int64).reshape(-1, 2)
+        assert qi.shape[0] == (13 if snr == "20" else 12) and (qi[:12, 1] == 9).all()
+        if snr == "20":
+            assert qi[12, 1] == 0                                   # unreadable file: (pos, 0)
+            lines = [ln for ln in open(os.path.splitext(r1)[0] + "_detail.csv", newline="")]
+            assert lines[-1].split(",")[1:3] == ["error", "-inf"]
+            # evaluator over the 12 real queries
+            good = str(tmp_path / "good_detail.csv")
+            open(good, "w", newline="").write("".join(lines[:-1]))
+            out = run(os.path.join(REPO, "tools", "accuracy.py"), os.path.join(qd, "expected.csv"), good)
+            assert "song correct" in out and "near match correct" in out and "exact match correct" in out
+            acc = float(out.strip().splitlines()[-1].split()[-1])
+            assert acc >= 50.0          # tiny random-weight encoder at 20 dB: well above chance (12.5 %)

@@ -196,3 +196,17 @@ def test_sharded_search_world2_gloo(tmp_path, world):
            str(script), REPO]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=REPO)
     assert r.returncode == 0 and "DIST_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_accuracy_tool(tmp_path):
+    """tools/accuracy.py: the reference's three hit-rate definitions (tools/accuracy.py:34-45)."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import accuracy
+    gt = tmp_path / "expected.csv"
+    gt.write_text("query,answer,time,snr\n/a/q1.wav,/m/s1.wav,3.0,0\n/a/q2.wav,/m/s2.wav,5.1,0\n"
+                  "/a/q3.wav,/m/s3.wav,0.0,0\n/a/q4.wav,/m/s4.wav,9.0,0\n")
+    pr = tmp_path / "r_detail.csv"
+    pr.write_text("query,answer,score,time,part_scores\r\n/x/q1.wav,/y/s1.wav,0.9,3.2\r\n"
+                  "/x/q2.wav,/y/s2.wav,0.8,5.5\r\n/x/q3.wav,/y/s9.wav,0.7,0.0\r\n/x/q4.wav,/y/s4.wav,0.6,8.0\r\n")
+    r = accuracy.evaluate(str(gt), str(pr))
+    assert r == dict(total=4, song=3, near=2, exact=1)
