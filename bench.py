@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--queries", type=int, default=256, help="10 s queries per step (whole job)")
+    ap.add_argument("--queries", type=int, default=512, help="10 s queries per step (whole job)")
     ap.add_argument("--db-songs", type=int, default=16950, help="16950 x 59 = 1,000,050 segments")
     ap.add_argument("--real-songs", type=int, default=48)
     ap.add_argument("--snr", type=float, default=0.0)

@@ -61,10 +61,30 @@ __global__ __launch_bounds__(256) void conv_gemm_ln_kernel(FusedGemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int mt = L / p.n_tiles_n, nt = L - mt * p.n_tiles_n;
-    const int64_t m0 = (int64_t)mt * BM;
-    const int n0 = nt * BN;
     const int rps = p.rows_per_sample;
+    int64_t mt;
+    int nt;
+    if (rps >= 2 * BM) {
+        // several tiles per sample: run tile `ti` of GS neighbouring samples back to back, so the
+        // LayerNorm affine slice they all stream (identical for every sample) stays in this XCD's L2
+        constexpr int GS = 64;
+        const int tps = rps / BM;
+        const int64_t per_group = (int64_t)GS * tps * p.n_tiles_n;
+        const int64_t g = L / per_group;
+        const int64_t left = p.n_samples - g * GS;
+        const int gs = left < GS ? (int)left : GS;
+        const int r = (int)(L - g * per_group);
+        const int ti = r / (gs * p.n_tiles_n);
+        const int r2 = r - ti * (gs * p.n_tiles_n);
+        const int bi = r2 / p.n_tiles_n;
+        nt = r2 - bi * p.n_tiles_n;
+        mt = (g * GS + bi) * tps + ti;
+    } else {
+        mt = L / p.n_tiles_n;
+        nt = L - (int)mt * p.n_tiles_n;
+    }
+    const int64_t m0 = mt * BM;
+    const int n0 = nt * BN;
 
     // ---- (mean, rstd) of every input sample this tile touches -----------------------------
     const int64_t b_first = m0 / rps;
@@ -391,22 +411,29 @@ __global__ __launch_bounds__(256) void conv_first_stats_kernel(const float *__re
                                                                int pad_lo, int rps, int P, int act, int after_bn) {
     __shared__ float red[8];
     const int co4 = co >> 2;
-    const int64_t mb = (int64_t)blockIdx.x * 64;
+    const int64_t mb = (int64_t)blockIdx.x * 64;          // 64 rows of ONE sample (rps % 64 == 0)
     const int tid = threadIdx.x;
+    const int64_t b = mb / rps;
+    const int r0 = (int)(mb - b * rps);                   // row inside the sample: 32-bit from here on
+    const int F = rps / To;
+    const float *xs = x + b * (int64_t)F * T;
+    float *ys = y + mb * co;
     float s1 = 0.f, s2 = 0.f;
-    for (int e = tid; e < 64 * co4; e += 256) {
-        const int64_t m = mb + e / co4;
-        if (m >= M) break;
-        const int c = (e % co4) * 4;
-        const int64_t bf = m / To;
-        const int to = (int)(m - bf * To);
+    const int n_it = (64 * co4 + 255) / 256;
+    for (int it = 0; it < n_it; ++it) {
+        const int e = tid + it * 256;
+        const int rl = e / co4;
+        if (rl >= 64 || mb + rl >= M) break;
+        const int c = (e - rl * co4) * 4;
+        const int r = r0 + rl;
+        const int f = r / To, to = r - f * To;
         const int p0 = to * stride - pad_lo;
         f32x4 o = *reinterpret_cast<const f32x4 *>(bias + c);
 #pragma unroll
         for (int tap = 0; tap < 3; ++tap) {
             const int t = p0 + tap;
             if ((unsigned)t < (unsigned)T) {
-                const float xv = x[bf * T + t];
+                const float xv = xs[f * T + t];
                 const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + tap * co + c);
                 o += xv * wv;
             }
@@ -415,7 +442,7 @@ __global__ __launch_bounds__(256) void conv_first_stats_kernel(const float *__re
 #pragma unroll
             for (int q = 0; q < 4; ++q) o[q] = act_fn(o[q], act);
         }
-        *reinterpret_cast<f32x4 *>(y + m * co + c) = o;
+        *reinterpret_cast<f32x4 *>(ys + rl * co + c) = o;
         s1 += (o[0] + o[1]) + (o[2] + o[3]);
         s2 += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
     }
@@ -423,8 +450,7 @@ __global__ __launch_bounds__(256) void conv_first_stats_kernel(const float *__re
     if ((tid & 63) == 0) { red[tid >> 6] = s1; red[4 + (tid >> 6)] = s2; }
     __syncthreads();
     if (tid == 0 && mb < M) {
-        const int64_t b = mb / rps;
-        const int slot = (int)((mb - b * rps) / 64);
+        const int slot = r0 / 64;
         float *o = part + (b * P + slot) * 2;
         o[0] = (red[0] + red[1]) + (red[2] + red[3]);
         o[1] = (red[4] + red[5]) + (red[6] + red[7]);

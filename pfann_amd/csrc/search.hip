@@ -48,40 +48,44 @@ struct ScanParams {
     int n_tiles_m;
 };
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void scan_emit_kernel(ScanParams p) {
+// One workgroup owns one db tile (BN rows) and a run of QT consecutive query tiles, walked with a
+// single software pipeline: tile (q, kt+1) -- or (q+1, 0) -- is prefetched while (q, kt) is on the
+// matrix cores, so with K = d = 128 (4 K-tiles) the exposed first load and the pipeline drain are
+// paid once per QT*4 K-tiles instead of once per 4.  The db tile is re-read from L1/L2 (64 KB).
+template <int BM, int BN, int WM, int WN, int QT>
+__global__ __launch_bounds__(256, 2) void scan_emit_kernel(ScanParams p) {
     constexpr int BK = 32, LDK = BK + 4;
     constexpr int WAVES_N = BN / WN;
     static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int AR = (BM + 31) / 32, BR = BN / 32;
+    static_assert(BM % 32 == 0 && BN % 32 == 0, "tiles are whole 32-row MFMA blocks");
+    constexpr int AR = BM / 32, BR = BN / 32;
     __shared__ __attribute__((aligned(16))) float As[2 * BM * LDK];
     __shared__ __attribute__((aligned(16))) float Bs[2 * BN * LDK];
-    __shared__ float thr_s[BM];
+    __shared__ __attribute__((aligned(16))) float thr_s[QT * BM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int nt = L / p.n_tiles_m, mt = L - nt * p.n_tiles_m;   // query tiles fastest: db tile stays in L2
-    const int64_t m0 = (int64_t)mt * BM, n0 = (int64_t)nt * BN;
+    const int n_mg = (p.n_tiles_m + QT - 1) / QT;                // query-tile groups
+    const int nt = L / n_mg, mg = L - nt * n_mg;                 // groups fastest: db tile stays in L2
+    const int mt0 = mg * QT;
+    const int n_q = min(QT, p.n_tiles_m - mt0);                  // query tiles this block really has
+    const int64_t n0 = (int64_t)nt * BN;
     const int col4 = tid & 7, rowq = tid >> 3;
 
-    if (tid < BM) {
-        const int64_t m = m0 + tid;
-        thr_s[tid] = (p.thr != nullptr && m < p.nq) ? p.thr[m] : -INFINITY;
+    for (int i = tid; i < QT * BM; i += 256) {
+        const int64_t m = (int64_t)mt0 * BM + i;
+        thr_s[i] = (p.thr != nullptr && m < p.nq) ? p.thr[m] : -INFINITY;
     }
 
-    // bounds-checked buffer loads (OOB lanes read 0); the db window starts at this tile's first row
-    const __amdgpu_buffer_rsrc_t srd_q = make_srd(p.q + m0 * p.d, (unsigned long long)(p.nq - m0) * p.d * 4ull);
+    // bounds-checked buffer loads (OOB lanes read 0); windows start at this block's first rows
+    const int64_t mq0 = (int64_t)mt0 * BM;
+    const __amdgpu_buffer_rsrc_t srd_q = make_srd(p.q + mq0 * p.d, (unsigned long long)(p.nq - mq0) * p.d * 4ull);
     const int64_t row0 = n0 * p.row_stride;
-    const int64_t rows_left = (p.nrows - n0 - 1) * p.row_stride + 1;      // db rows from row0 to the last sampled one
+    const int64_t rows_left = (p.nrows - n0 - 1) * p.row_stride + 1;
     const __amdgpu_buffer_rsrc_t srd_db = make_srd(p.db + row0 * p.d, (unsigned long long)rows_left * p.d * 4ull);
-    unsigned qoff[AR], doff[BR];
-#pragma unroll
-    for (int i = 0; i < AR; ++i) {
-        const int rl = rowq + 32 * i;
-        qoff[i] = (rl < BM && m0 + rl < p.nq) ? (unsigned)rl * (unsigned)p.d * 4u : BUF_OOB;
-    }
+    unsigned doff[BR];
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
         const int64_t rl = rowq + 32 * j;
@@ -89,88 +93,126 @@ __global__ __launch_bounds__(256) void scan_emit_kernel(ScanParams p) {
         doff[j] = (n0 + rl < p.nrows && off < 0x7FFF0000ull) ? (unsigned)off : BUF_OOB;
     }
     f32x4 ra[AR], rb[BR];
-    int kap = col4 * 4;
+    // load cursor of the NEXT tile to fetch, all in 32-bit byte offsets inside the two windows
+    const int q_rows_left = (int)((p.nq - mq0) < (int64_t)QT * BM ? (p.nq - mq0) : (int64_t)QT * BM);
+    const unsigned tile_bytes = (unsigned)BM * (unsigned)p.d * 4u;
+    unsigned aoff[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) aoff[i] = (unsigned)(rowq + 32 * i) * (unsigned)p.d * 4u;
+    int lkap = col4 * 4, lrow = rowq;        // lrow: row (inside the run) of this thread's first A row
+    unsigned lbase = 0;                      // byte offset of the cursor's query tile
     auto load_tile = [&]() {
-        const bool kok = kap < p.d;
+        const bool kok = lkap < p.d;
 #pragma unroll
-        for (int i = 0; i < AR; ++i) ra[i] = buf_load4(srd_q, kok ? qoff[i] + (unsigned)kap * 4u : BUF_OOB);
+        for (int i = 0; i < AR; ++i)
+            ra[i] = buf_load4(srd_q, (kok && lrow + 32 * i < q_rows_left) ? lbase + aoff[i] + (unsigned)lkap * 4u : BUF_OOB);
 #pragma unroll
-        for (int j = 0; j < BR; ++j) rb[j] = buf_load4(srd_db, kok ? doff[j] + (unsigned)kap * 4u : BUF_OOB);
-        kap += BK;
+        for (int j = 0; j < BR; ++j) rb[j] = buf_load4(srd_db, kok ? doff[j] + (unsigned)lkap * 4u : BUF_OOB);
+        lkap += BK;
+        const bool wrap = lkap >= p.d;
+        lkap = wrap ? col4 * 4 : lkap;
+        lrow += wrap ? BM : 0;
+        lbase += wrap ? tile_bytes : 0u;
     };
     auto store_tile = [&](float *Ad, float *Bd) {
 #pragma unroll
         for (int i = 0; i < AR; ++i)
-            if ((rowq + 32 * i) < BM)
-                *reinterpret_cast<f32x4 *>(&Ad[(rowq + 32 * i) * LDK + col4 * 4]) = ra[i];
+            *reinterpret_cast<f32x4 *>(&Ad[(rowq + 32 * i) * LDK + col4 * 4]) = ra[i];
 #pragma unroll
         for (int j = 0; j < BR; ++j)
             *reinterpret_cast<f32x4 *>(&Bd[(rowq + 32 * j) * LDK + col4 * 4]) = rb[j];
     };
 
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // LDS double buffer, one barrier per K-tile, prefetch pinned ahead of the MFMAs
     const int nk = (p.d + BK - 1) / BK;
     load_tile();
     store_tile(As, Bs);
     __syncthreads();
     const int l31 = lane & 31, lhalf = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const float *Ac = As + (kt & 1) * (BM * LDK), *Bc = Bs + (kt & 1) * (BN * LDK);
-        float *An = As + ((kt + 1) & 1) * (BM * LDK), *Bn = Bs + ((kt + 1) & 1) * (BN * LDK);
+    int it = 0;                               // running K-tile counter: LDS buffer = it & 1
+#pragma unroll 1
+    for (int q = 0; q < n_q; ++q) {
+        const int64_t m0 = mq0 + (int64_t)q * BM;
+        f32x16 acc[TM][TN];
 #pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            f32x4 a4[TM], b4[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                a4[i] = *reinterpret_cast<const f32x4 *>(&Ac[(wm * WM + i * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                b4[j] = *reinterpret_cast<const f32x4 *>(&Bc[(wn * WN + j * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
-            if (kk == 0) {
-                load_tile();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (kk == BK / 8 - 1) store_tile(An, Bn);
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll 1
+        for (int kt = 0; kt < nk; ++kt, ++it) {
+            const float *Ac = As + (it & 1) * (BM * LDK), *Bc = Bs + (it & 1) * (BN * LDK);
+            float *An = As + ((it + 1) & 1) * (BM * LDK), *Bn = Bs + ((it + 1) & 1) * (BN * LDK);
+#pragma unroll
+            for (int kk = 0; kk < BK / 8; ++kk) {
+                f32x4 a4[TM], b4[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
+                    a4[i] = *reinterpret_cast<const f32x4 *>(&Ac[(wm * WM + i * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][s], b4[j][s], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j)
+                    b4[j] = *reinterpret_cast<const f32x4 *>(&Bc[(wn * WN + j * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
+                if (kk == 0) {
+                    load_tile();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (kk == BK / 8 - 1) store_tile(An, Bn);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][s], b4[j][s], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
         }
-        __syncthreads();
-    }
-    // epilogue: threshold filter + append.  acc[i][j][r]: query row = (r&3)+8*(r>>2)+4*lhalf,
-    // db row = lane&31 of the 32x32 tile.
+        // epilogue: threshold filter + append.  acc[i][j][r]: query row = (r&3)+8*(r>>2)+4*lhalf,
+        // db row = lane&31 of the 32x32 tile.  A wave-level branch costs ~50 cycles and survivors
+        // are rare (~1.6e-3 per score), so survival is tested per GROUP of 4 slots (one branch),
+        // and only groups with a survivor fall into the per-slot append code.
+        const float *thr_c = thr_s + q * BM;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int64_t n = n0 + wn * WN + j * 32 + l31;
-        const bool nok = n < p.nrows;
-        const unsigned row = (unsigned)(n * p.row_stride);
+        for (int j = 0; j < TN; ++j) {
+            const int64_t n = n0 + wn * WN + j * 32 + l31;
+            const bool nok = n < p.nrows;
+            const unsigned row = (unsigned)(n * p.row_stride);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+            for (int i = 0; i < TM; ++i) {
+                if (p.thr == nullptr) {          // top sampling level: nrows <= CAP, no filter, no atomics
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ml = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-                const int64_t m = m0 + ml;
-                const float sc = acc[i][j][r];
-                if (p.thr == nullptr) {      // top sampling level: nrows <= CAP, no filter, no atomics
-                    if (nok && m < p.nq) p.keys[m * CAP + n] = pack_key(sc, row);
-                } else if (nok && m < p.nq && sc >= thr_s[ml]) {
-                    const int pos = atomicAdd(&p.cnt[m], 1);
-                    if (pos < CAP) p.keys[m * CAP + pos] = pack_key(sc, row);
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                        if (nok && m < p.nq) p.keys[m * CAP + n] = pack_key(acc[i][j][r], row);
+                    }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        // rows (r&3)+8g+4*lhalf for r&3 = 0..3: four consecutive query rows
+                        const int mlg = wm * WM + i * 32 + 8 * g + 4 * lhalf;
+                        const f32x4 th = *reinterpret_cast<const f32x4 *>(thr_c + mlg);
+                        bool sv[4];
+                        bool any = false;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            sv[e] = nok && (m0 + mlg + e) < p.nq && acc[i][j][4 * g + e] >= th[e];
+                            any |= sv[e];
+                        }
+                        if (__any(any)) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if (sv[e]) {
+                                    const int64_t m = m0 + mlg + e;
+                                    const int pos = atomicAdd(&p.cnt[m], 1);
+                                    if (pos < CAP) p.keys[m * CAP + pos] = pack_key(acc[i][j][4 * g + e], row);
+                                }
+                            }
+                        }
+                    }
                 }
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -253,16 +295,20 @@ static int launch_scan(const float *db, int64_t n, int d, int64_t stride, const 
     ProfScope ps(stride == 1 ? "scan_topk" : "scan_topk_sample", s, 2.0 * (double)nq * p.nrows * d);
     if (nq <= 32) {
         p.n_tiles_m = 1;
-        const int64_t blocks = cdiv(p.nrows, 128);
-        hipLaunchKernelGGL((scan_emit_kernel<32, 128, 32, 32>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((scan_emit_kernel<32, 128, 32, 32, 1>), dim3((unsigned)cdiv(p.nrows, 128)), dim3(256), 0, s, p);
     } else if (nq <= 64) {
         p.n_tiles_m = 1;
-        const int64_t blocks = cdiv(p.nrows, 64);
-        hipLaunchKernelGGL((scan_emit_kernel<64, 64, 32, 32>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((scan_emit_kernel<64, 64, 32, 32, 1>), dim3((unsigned)cdiv(p.nrows, 64)), dim3(256), 0, s, p);
     } else {
         p.n_tiles_m = cdiv(nq, 128);
-        const int64_t blocks = (int64_t)cdiv(p.nrows, 128) * p.n_tiles_m;
-        hipLaunchKernelGGL((scan_emit_kernel<128, 128, 64, 64>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        const int64_t db_tiles = cdiv(p.nrows, 128);
+        // long runs of query tiles per block only when the grid still fills the chip many times over
+        if (db_tiles * cdiv(p.n_tiles_m, 4) >= 4096)
+            hipLaunchKernelGGL((scan_emit_kernel<128, 128, 64, 64, 4>), dim3((unsigned)(db_tiles * cdiv(p.n_tiles_m, 4))),
+                               dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((scan_emit_kernel<128, 128, 64, 64, 1>), dim3((unsigned)(db_tiles * p.n_tiles_m)),
+                               dim3(256), 0, s, p);
     }
     PF_HIP(hipGetLastError());
     return 0;
