@@ -16,6 +16,8 @@
 //   (PRE, POST) = (identity, act) for relu_after_bn, (act, identity) otherwise.
 //
 // No atomics: results are bit-reproducible run to run.  The normalised tensor never exists in HBM.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace pfann {
@@ -42,21 +44,24 @@ struct FusedGemmParams {
     float *out_part; int out_P;
     int act, after_bn;
     int64_t n_samples;
+    int dbg;                     // timing ablations only (PFANN_DBG): 1 = no W/B loads, 2 = no LN math
 };
 
 // RELU_BN = true: the default model (ReLU applied after LayerNorm) with the activation folded
 // into straight-line code; false: generic (ELU and/or activation before LayerNorm).
 template <int BM, int BN, int WM, int WN, bool RELU_BN>
-__global__ __launch_bounds__(256) void conv_gemm_ln_kernel(FusedGemmParams p) {
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_ln_kernel(FusedGemmParams p) {
     constexpr int BK = 32, LDK = BK + 4;
     constexpr int WAVES_N = BN / WN;
-    static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
+    constexpr int NWAVES = (BM / WM) * WAVES_N, NT = 64 * NWAVES;
+    static_assert(NWAVES == 4 || NWAVES == 8, "4 or 8 waves per block");
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int AR = BM / 32, BR = BN / 32;
+    constexpr int RPT = NT / 8;                        // tile rows covered per loader pass
+    constexpr int AR = BM / RPT, BR = BN / RPT;
     __shared__ __attribute__((aligned(16))) float As[2 * BM * LDK];
     __shared__ __attribute__((aligned(16))) float Bs[2 * BN * LDK];
     __shared__ float s_mu[BM], s_rs[BM];
-    __shared__ double s_red[8];
+    __shared__ double s_red[2 * NWAVES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -92,13 +97,13 @@ __global__ __launch_bounds__(256) void conv_gemm_ln_kernel(FusedGemmParams p) {
     if (ns == 1) {
         double s1 = 0, s2 = 0;
         const float *pp = p.in_part + b_first * p.in_P * 2;
-        for (int i = tid; i < p.in_P; i += 256) { s1 += (double)pp[2 * i]; s2 += (double)pp[2 * i + 1]; }
+        for (int i = tid; i < p.in_P; i += NT) { s1 += (double)pp[2 * i]; s2 += (double)pp[2 * i + 1]; }
         s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
-        if (lane == 0) { s_red[wave] = s1; s_red[4 + wave] = s2; }
+        if (lane == 0) { s_red[wave] = s1; s_red[NWAVES + wave] = s2; }
         __syncthreads();
         if (tid == 0) {
-            const double t1 = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-            const double t2 = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+            double t1 = 0, t2 = 0;
+            for (int w = 0; w < NWAVES; ++w) { t1 += s_red[w]; t2 += s_red[NWAVES + w]; }
             const double mean = t1 * p.inv_n_in;
             double var = t2 * p.inv_n_in - mean * mean;
             if (var < 0) var = 0;
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256) void conv_gemm_ln_kernel(FusedGemmParams p) {
     float amu[AR], ars[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-        const int64_t m = m0 + rowq + 32 * i;
+        const int64_t m = m0 + rowq + RPT * i;
         if (m < p.M) {
             const int64_t b = m / rps;
             const int r = (int)(m - b * rps);
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(256) void conv_gemm_ln_kernel(FusedGemmParams p) {
     unsigned boff[BR];
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
-        const int n = n0 + rowq + 32 * j;
+        const int n = n0 + rowq + RPT * j;
         boff[j] = n < p.N ? (unsigned)n * (unsigned)p.K * 4u : BUF_OOB;
     }
     int kap = p.k_begin + col4 * 4;
@@ -168,8 +173,10 @@ __global__ __launch_bounds__(256) void conv_gemm_ln_kernel(FusedGemmParams p) {
             const bool ok = kok && (unsigned)(ap0[i] + tap) < (unsigned)p.in_len;
             okmask |= ok ? (1u << i) : 0u;
             ra[i] = buf_load4(srd_a, ok ? (unsigned)(aoff[i] + toff) * 4u : BUF_OOB);
-            rw[i] = buf_load4(srd_w, ok ? (unsigned)(arel[i] + toff) * 4u : BUF_OOB);
-            rbb[i] = buf_load4(srd_lb, ok ? (unsigned)(arel[i] + toff) * 4u : BUF_OOB);
+            if (!(p.dbg & 1)) {
+                rw[i] = buf_load4(srd_w, ok ? (unsigned)(arel[i] + toff) * 4u : BUF_OOB);
+                rbb[i] = buf_load4(srd_lb, ok ? (unsigned)(arel[i] + toff) * 4u : BUF_OOB);
+            } else { rw[i] = f32x4{1.f, 1.f, 1.f, 1.f}; rbb[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         }
 #pragma unroll
         for (int j = 0; j < BR; ++j) rb[j] = buf_load4(srd_b, kok ? boff[j] + (unsigned)kap * 4u : BUF_OOB);
@@ -186,16 +193,16 @@ __global__ __launch_bounds__(256) void conv_gemm_ln_kernel(FusedGemmParams p) {
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float t = (ra[i][e] - amu[i]) * ars[i] * rw[i][e] + rbb[i][e];
+                float t = (p.dbg & 2) ? ra[i][e] : (ra[i][e] - amu[i]) * ars[i] * rw[i][e] + rbb[i][e];
                 if (RELU_BN) t = fmaxf(t, 0.f);
                 else t = p.after_bn ? act_fn(t, p.act) : t;
                 v[e] = ok ? t : 0.f;
             }
-            *reinterpret_cast<f32x4 *>(&Ad[(rowq + 32 * i) * LDK + col4 * 4]) = v;
+            *reinterpret_cast<f32x4 *>(&Ad[(rowq + RPT * i) * LDK + col4 * 4]) = v;
         }
 #pragma unroll
         for (int j = 0; j < BR; ++j)
-            *reinterpret_cast<f32x4 *>(&Bd[(rowq + 32 * j) * LDK + col4 * 4]) = rb[j];
+            *reinterpret_cast<f32x4 *>(&Bd[(rowq + RPT * j) * LDK + col4 * 4]) = rb[j];
     };
 
     f32x16 acc[TM][TN];
@@ -378,15 +385,18 @@ int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, 
     p.out_part = out_part; p.out_P = fused_out_slots(L, B);
     p.act = act; p.after_bn = after_bn;
     p.n_samples = B;
+    p.dbg = getenv("PFANN_DBG") ? atoi(getenv("PFANN_DBG")) : 0;
     const double flops = 2.0 * (double)p.M * p.N * (p.k_end - p.k_begin);
     if (gemm_tile(L, B) == 128) {
         p.n_tiles_n = cdiv(p.N, 128);
         const int64_t blocks = (int64_t)cdiv(p.M, 128) * p.n_tiles_n;
         ProfScope ps("conv_gemm_ln_128", s, flops);
+        // 8 waves (512 threads), each a 64x32 tile: half the prefetch registers per thread and four
+        // waves per SIMD with two resident blocks
         if (act == 0 && after_bn)
-            hipLaunchKernelGGL((conv_gemm_ln_kernel<128, 128, 64, 64, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+            hipLaunchKernelGGL((conv_gemm_ln_kernel<128, 128, 64, 32, true>), dim3((unsigned)blocks), dim3(512), 0, s, p);
         else
-            hipLaunchKernelGGL((conv_gemm_ln_kernel<128, 128, 64, 64, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+            hipLaunchKernelGGL((conv_gemm_ln_kernel<128, 128, 64, 32, false>), dim3((unsigned)blocks), dim3(512), 0, s, p);
     } else {
         p.n_tiles_n = cdiv(p.N, 64);
         const int64_t blocks = (int64_t)cdiv(p.M, 64) * p.n_tiles_n;

@@ -14,6 +14,8 @@
 //     LDS is exact;
 //   * a list overflow on the final level (pathological ties / duplicates) raises tau from
 //     the captured survivors and rescans; it never degrades to an approximate answer.
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace pfann {
@@ -46,6 +48,7 @@ struct ScanParams {
     int *cnt;                // [nq]
     unsigned long long *keys;  // [nq][CAP]
     int n_tiles_m;
+    int nsub;                // survivor sub-lists per query row (small-batch kernel: 32), else 1
 };
 
 // One workgroup owns one db tile (BN rows) and a run of QT consecutive query tiles, walked with a
@@ -217,6 +220,110 @@ __global__ __launch_bounds__(256, 2) void scan_emit_kernel(ScanParams p) {
 }
 
 // ------------------------------------------------------------------------------------
+// Small-batch scan (nq <= 32, d = 128 or 64): the HBM-bound regime (one 10 s query = 19 rows;
+// intensity Q/2 flop/byte).  Streaming design:
+//   * the query block lives in registers as MFMA A-fragments for the whole kernel;
+//   * every wave owns whole 32-row db tiles (16 KB contiguous at d = 128) and reads them with
+//     fully contiguous 1 KB-per-instruction buffer loads (HBM-friendly bursts, each byte once);
+//   * the tile is transposed to the MFMA B-fragment layout through a WAVE-PRIVATE padded LDS tile
+//     (pitch d+4 dwords: conflict-free ds_write_b128 / ds_read_b128), so there are no workgroup
+//     barriers at all; the next tile is already in flight in registers while the current one is
+//     on the matrix cores;
+//   * a persistent grid (2 workgroups per CU) walks the tiles: no per-tile pipeline fill.
+// K order: MFMA step s of half h uses k = 8*(s>>2) + 4*h + (s&3)  (same map for both operands).
+// ------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256, 2) void scan_small_kernel(ScanParams p) {
+    constexpr int KS = D / 8;                 // float4 fragment pieces per lane
+    constexpr int LD = D + 4;                 // LDS row pitch (dwords)
+    constexpr int RPI = 256 / D;              // db rows covered by one 1 KB wave instruction (2 or 4)
+    constexpr int NI = 32 / RPI;              // load instructions per 32-row tile (16 or 8)
+    __shared__ __attribute__((aligned(16))) float tile_s[4 * 32 * LD];
+    __shared__ __attribute__((aligned(16))) float thr_s[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhalf = lane >> 5;
+    const int64_t n_tiles = (p.nrows + 31) / 32;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wave, nw = (int64_t)gridDim.x * 4;
+    if (tid < 32) thr_s[tid] = tid < p.nq ? (p.thr != nullptr ? p.thr[tid] : -INFINITY) : INFINITY;
+    __syncthreads();
+    float *ts = tile_s + wave * 32 * LD;
+    constexpr int NSUB = 32;
+    const int sub = blockIdx.x & (NSUB - 1);
+
+    f32x4 qa[KS];
+#pragma unroll
+    for (int j = 0; j < KS; ++j)
+        qa[j] = l31 < p.nq ? *reinterpret_cast<const f32x4 *>(p.q + (int64_t)l31 * p.d + 8 * j + 4 * lhalf)
+                           : f32x4{0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t srd_db =
+        make_srd(p.db, (unsigned long long)((p.nrows - 1) * p.row_stride + 1) * p.d * 4ull);
+    const unsigned row_bytes = (unsigned)(p.row_stride * p.d * 4);
+    // lane -> (row inside the instruction's RPI rows, float4 column)
+    const int lrow = lane / (D / 4), lcol = lane % (D / 4);
+
+    f32x4 st[NI];                              // next tile, in flight
+    auto load_tile = [&](int64_t t) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int64_t n = t * 32 + j * RPI + lrow;
+            const bool ok = t < n_tiles && n < p.nrows;
+            st[j] = buf_load4(srd_db, ok ? (unsigned)n * row_bytes + (unsigned)lcol * 16u : BUF_OOB);
+        }
+    };
+    load_tile(gw);
+    for (int64_t t = gw; t < n_tiles; t += nw) {
+        // registers -> wave-private LDS tile (previous tile's fragment reads are complete:
+        // their results fed MFMAs already issued), then put the next tile in flight
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+            *reinterpret_cast<f32x4 *>(&ts[(j * RPI + lrow) * LD + lcol * 4]) = st[j];
+        load_tile(t + nw);                     // past the end: all lanes out of range, reads zeros
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            const f32x4 xb = *reinterpret_cast<const f32x4 *>(&ts[l31 * LD + 8 * j + 4 * lhalf]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[j][e], xb[e], acc, 0, 0, 0);
+        }
+        // acc[r]: query row (r&3)+8*(r>>2)+4*lhalf, db row t*32 + l31
+        const int64_t n = t * 32 + l31;
+        const bool nok = n < p.nrows;
+        const unsigned row = (unsigned)(n * p.row_stride);
+        if (p.thr == nullptr) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                if (nok && m < p.nq) p.keys[(int64_t)m * CAP + n] = pack_key(acc[r], row);
+            }
+        } else {
+            bool any = false;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 th = *reinterpret_cast<const f32x4 *>(thr_s + 8 * g + 4 * lhalf);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) any |= acc[4 * g + e] >= th[e];
+            }
+            if (__any(any && nok)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                    if (nok && acc[r] >= thr_s[m]) {
+                        // same-address returning atomics serialise (~0.2 us each): with <= 32 query
+                        // rows one counter per row would take ~1600 hits, so each row has NSUB
+                        // sub-lists (CAP/NSUB slots each) picked by workgroup id
+                        const int pos = atomicAdd(&p.cnt[m * NSUB + sub], 1);
+                        if (pos < CAP / NSUB) p.keys[(int64_t)m * CAP + sub * (CAP / NSUB) + pos] = pack_key(acc[r], row);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // Per-query exact select: bitonic sort of the (<= CAP) packed survivors in LDS.
 //   mode 0: write thr[m] = k-th best score (or -inf when fewer than k survivors)
 //   mode 1: write D[m][k], I[m][k] (+label_base); pad with -FLT_MAX / -1
@@ -242,18 +349,35 @@ __global__ __launch_bounds__(1024) void select_kernel(const unsigned long long *
                                                       const int *__restrict__ cnt, int k, int mode,
                                                       float *__restrict__ thr, float *__restrict__ D,
                                                       int64_t *__restrict__ I, int64_t label_base,
-                                                      int *overflow) {
+                                                      int *overflow, int nsub) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
+    __shared__ int s_off[130];
     const int64_t m = blockIdx.x;
     const int tid = threadIdx.x;
-    int n = cnt[m];
-    if (n > CAP) {
-        if (mode == 1 && tid == 0) atomicExch(overflow, 1);
-        n = CAP;
+    const int subcap = CAP / nsub;
+    bool over = false;
+    if (tid == 0) {
+        int run = 0;
+        for (int g = 0; g < nsub; ++g) {
+            int c = cnt[m * nsub + g];
+            if (c > subcap) { c = subcap; over = true; }
+            s_off[g] = run;
+            run += c;
+        }
+        s_off[nsub] = run;
+        s_off[129] = over ? 1 : 0;
+        if (over && mode == 1) atomicExch(overflow, 1);
     }
+    __syncthreads();
+    const int n = s_off[nsub];
+    over = s_off[129] != 0;
     int P = 1;
     while (P < n) P <<= 1;
-    for (int i = tid; i < P; i += 1024) skeys[i] = i < n ? keys[m * CAP + i] : ~0ull;
+    for (int g = 0; g < nsub; ++g) {
+        const int o = s_off[g], c = s_off[g + 1] - o;
+        for (int i = tid; i < c; i += 1024) skeys[o + i] = keys[m * CAP + g * subcap + i];
+    }
+    for (int i = n + tid; i < P; i += 1024) skeys[i] = ~0ull;
     __syncthreads();
     bitonic_sort_u64(skeys, P, tid, 1024);
     if (mode == 0) {
@@ -270,7 +394,7 @@ __global__ __launch_bounds__(1024) void select_kernel(const unsigned long long *
             }
         }
         // on overflow, publish the raised threshold for the rescan
-        if (cnt[m] > CAP && tid == 0 && thr != nullptr) thr[m] = ord2f(~(unsigned)(skeys[k - 1] >> 32));
+        if (over && tid == 0 && thr != nullptr && n >= k) thr[m] = ord2f(~(unsigned)(skeys[k - 1] >> 32));
     }
 }
 
@@ -280,20 +404,29 @@ __global__ void fill_int_kernel(int *p, int v, int64_t n) {
 }
 
 static int launch_scan(const float *db, int64_t n, int d, int64_t stride, const float *q, int64_t nq,
-                       const float *thr, SearchWorkspace &ws, hipStream_t s) {
+                       const float *thr, SearchWorkspace &ws, int *nsub_out, hipStream_t s) {
     ScanParams p;
     p.q = q; p.db = db; p.nq = nq; p.d = d;
     p.row_stride = stride;
     p.nrows = (n + stride - 1) / stride;
     p.thr = thr; p.cnt = ws.cnt; p.keys = reinterpret_cast<unsigned long long *>(ws.cl);
+    const bool small = nq <= 32 && (d == 128 || d == 64) && (uint64_t)p.nrows * stride * d * 4 < 0x7FFF0000ull;
+    p.nsub = (small && thr != nullptr) ? 32 : 1;
+    *nsub_out = p.nsub;
     if (thr == nullptr) {
         if (p.nrows > CAP) { set_error("scan: dense level with %lld rows > %d", (long long)p.nrows, CAP); return -1; }
         hipLaunchKernelGGL(fill_int_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, s, ws.cnt, (int)p.nrows, nq);
     } else {
-        PF_HIP(hipMemsetAsync(ws.cnt, 0, sizeof(int) * nq, s));
+        PF_HIP(hipMemsetAsync(ws.cnt, 0, sizeof(int) * nq * p.nsub, s));
     }
     ProfScope ps(stride == 1 ? "scan_topk" : "scan_topk_sample", s, 2.0 * (double)nq * p.nrows * d);
-    if (nq <= 32) {
+    if (small) {
+        // HBM-bound regime: persistent streaming kernel, 2 blocks per CU
+        const int64_t tiles = (p.nrows + 31) / 32;
+        const unsigned grid = (unsigned)std::min<int64_t>(512, (tiles + 3) / 4);
+        if (d == 128) hipLaunchKernelGGL((scan_small_kernel<128>), dim3(grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((scan_small_kernel<64>), dim3(grid), dim3(256), 0, s, p);
+    } else if (nq <= 32) {
         p.n_tiles_m = 1;
         hipLaunchKernelGGL((scan_emit_kernel<32, 128, 32, 32, 1>), dim3((unsigned)cdiv(p.nrows, 128)), dim3(256), 0, s, p);
     } else if (nq <= 64) {
@@ -315,7 +448,7 @@ static int launch_scan(const float *db, int64_t n, int d, int64_t stride, const 
 }
 
 static int launch_select(SearchWorkspace &ws, int64_t nq, int k, int mode, float *D, int64_t *I,
-                         int64_t label_base, hipStream_t s) {
+                         int64_t label_base, int nsub, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         PF_HIP(hipFuncSetAttribute((const void *)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -325,7 +458,7 @@ static int launch_select(SearchWorkspace &ws, int64_t nq, int k, int mode, float
     ProfScope ps("topk_select", s);
     hipLaunchKernelGGL(select_kernel, dim3((unsigned)nq), dim3(1024), CAP * 8, s,
                        reinterpret_cast<const unsigned long long *>(ws.cl), ws.cnt, k, mode, ws.thr, D, I,
-                       label_base, ws.overflow);
+                       label_base, ws.overflow, nsub);
     PF_HIP(hipGetLastError());
     return 0;
 }
@@ -336,7 +469,7 @@ static int ensure_ws(SearchWorkspace &ws, int64_t nq) {
     if (!ws.overflow) PF_HIP(hipMalloc(&ws.overflow, sizeof(int)));
     const int64_t cap = nq < 64 ? 64 : nq;
     PF_HIP(hipMalloc(&ws.thr, sizeof(float) * cap));
-    PF_HIP(hipMalloc(&ws.cnt, sizeof(int) * cap));
+    PF_HIP(hipMalloc(&ws.cnt, sizeof(int) * (cap < 2048 ? 2048 : cap)));
     PF_HIP(hipMalloc(&ws.cl, sizeof(unsigned long long) * cap * CAP));
     ws.cap_q = cap;
     ws.cap_c = CAP;
@@ -368,14 +501,16 @@ int search_topk(const float *db, int64_t n, int d, int64_t label_base, const flo
     PF_HIP(hipMemsetAsync(ws.overflow, 0, sizeof(int), s));
     const float *thr = nullptr;
     for (int lev = levels; lev >= 1; --lev) {
-        if (launch_scan(db, n, d, stride, q, nq, thr, ws, s)) return -1;
-        if (launch_select(ws, nq, k, 0, nullptr, nullptr, 0, s)) return -1;
+        int nsub = 1;
+        if (launch_scan(db, n, d, stride, q, nq, thr, ws, &nsub, s)) return -1;
+        if (launch_select(ws, nq, k, 0, nullptr, nullptr, 0, nsub, s)) return -1;
         thr = ws.thr;
         stride /= R;
     }
     for (int attempt = 0; attempt < 4; ++attempt) {
-        if (launch_scan(db, n, d, 1, q, nq, thr, ws, s)) return -1;
-        if (launch_select(ws, nq, k, 1, D, I, label_base, s)) return -1;
+        int nsub = 1;
+        if (launch_scan(db, n, d, 1, q, nq, thr, ws, &nsub, s)) return -1;
+        if (launch_select(ws, nq, k, 1, D, I, label_base, nsub, s)) return -1;
         int ovf = 0;
         PF_HIP(hipMemcpyAsync(&ovf, ws.overflow, sizeof(int), hipMemcpyDeviceToHost, s));
         PF_HIP(hipStreamSynchronize(s));
