@@ -239,6 +239,30 @@ def main():
         gbs = (r_hi - r_lo) * d * 4 / (ks["avg_us"] * 1e-6) / 1e9
         ks.update({"db_GBps": gbs, "db_hbm_frac": gbs / PEAK_HBM})
 
+    # ---------------------------------- single-query scan regime (HBM-bound; SURVEY §8d note)
+    single = None
+    if prof and world == 1:
+        import ctypes
+        q19 = emb[:QUERY_SEGS].contiguous()
+        for _ in range(3):
+            index.search(q19, k)
+        lib.pfann_prof_reset()
+        lib.pfann_prof_enable(1)
+        t1 = time.perf_counter()
+        for _ in range(20):
+            index.search(q19, k)
+        torch.cuda.synchronize()
+        call_us = 1e6 * (time.perf_counter() - t1) / 20
+        lib.pfann_prof_enable(0)
+        cnt = ctypes.c_int64(0)
+        ms = lib.pfann_prof_elapsed_ms(b"scan_topk", ctypes.byref(cnt))
+        us = 1e3 * ms / max(cnt.value, 1)
+        gbs = (r_hi - r_lo) * d * 4 / (us * 1e-6) / 1e9
+        single = {"kernel": "pfann::scan_small_kernel<128> (one 19-row query vs the whole shard, full pass)",
+                  "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM, "unit": "GB/s",
+                  "frac": round(gbs / PEAK_HBM, 4), "pass_us": round(us, 1),
+                  "algorithmic_bytes": (r_hi - r_lo) * d * 4, "search_call_us": round(call_us, 1)}
+
     # ------------------------------------------------------------------------- hit-rate
     hits = near = exact = 0
     for j in range(Q):
@@ -293,7 +317,7 @@ def main():
                        "parallelism": "song-sharded db x%d" % world, "max_batch": args.max_batch},
             "top1_hit_rate": round(hits / Q, 4), "top1_near_0.5s": round(near / Q, 4),
             "top1_exact_0.25s": round(exact / Q, 4),
-            "roofline": roofline, "cpu_baseline": cpu, "oracle_decision_parity": parity,
+            "roofline": roofline, "single_query_scan_roofline": single, "cpu_baseline": cpu, "oracle_decision_parity": parity,
             "kernels": {t: {kk: (float("%.4g" % vv) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                         for t, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
         }

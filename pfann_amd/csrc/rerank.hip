@@ -38,10 +38,11 @@ __device__ __forceinline__ Cand unpack_cand(int mode, unsigned long long key) {
     return c;
 }
 
+template <int NT>
 __device__ void bitonic_sort_keys(unsigned long long *sk, int P, int tid) {
     for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < P; i += 256) {
+            for (int i = tid; i < P; i += NT) {
                 const int ixj = i ^ j;
                 if (ixj > i) {
                     const unsigned long long x = sk[i], y = sk[ixj];
@@ -54,7 +55,8 @@ __device__ void bitonic_sort_keys(unsigned long long *sk, int P, int tid) {
     }
 }
 
-__global__ __launch_bounds__(256) void match_kernel(RerankArgs a) {
+template <int NT>
+__global__ __launch_bounds__(NT) void match_kernel(RerankArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long sk[];   // [P] keys
     __shared__ int s_nc;
     const int64_t qi = blockIdx.x;
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256) void match_kernel(RerankArgs a) {
     float *score = reinterpret_cast<float *>(sk + P);                        // [P] candidate sums
 
     // ---- candidates (database.py:133-138 / seqscore.cpp:49-60)
-    for (int i = tid; i < P; i += 256) {
+    for (int i = tid; i < P; i += NT) {
         unsigned long long key = SENT;
         if (i < ntot) {
             const int t = i / a.k;
@@ -94,22 +96,22 @@ __global__ __launch_bounds__(256) void match_kernel(RerankArgs a) {
     }
     __syncthreads();
     // ---- sort ascending (== lexicographic candidate order of the reference)
-    bitonic_sort_keys(sk, P, tid);
+    bitonic_sort_keys<NT>(sk, P, tid);
     // ---- dedup (np.unique / std::unique): blank repeats, re-sort, count survivors
     int *dupf = reinterpret_cast<int *>(score);
-    for (int i = tid; i < P; i += 256) dupf[i] = (i > 0 && sk[i] == sk[i - 1]) ? 1 : 0;
+    for (int i = tid; i < P; i += NT) dupf[i] = (i > 0 && sk[i] == sk[i - 1]) ? 1 : 0;
     __syncthreads();
-    for (int i = tid; i < P; i += 256) if (dupf[i]) sk[i] = SENT;
+    for (int i = tid; i < P; i += NT) if (dupf[i]) sk[i] = SENT;
     if (tid == 0) s_nc = 0;
     __syncthreads();
-    bitonic_sort_keys(sk, P, tid);
-    for (int i = tid; i < P; i += 256)
+    bitonic_sort_keys<NT>(sk, P, tid);
+    for (int i = tid; i < P; i += NT)
         if (sk[i] != SENT && (i + 1 == P || sk[i + 1] == SENT)) s_nc = i + 1;
     __syncthreads();
     const int nc = s_nc;
 
     // ---- score every unique candidate: one wave each
-    for (int c = wave; c < nc; c += 4) {
+    for (int c = wave; c < nc; c += NT / 64) {
         const Cand cd = unpack_cand(a.mode, sk[c]);
         const int64_t start = a.song_pos[cd.song];
         const int slen = (int)(a.song_pos[cd.song + 1] - start);
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256) void match_kernel(RerankArgs a) {
         float *ss = a.song_scores + (int64_t)qi * a.n_songs * 2;
         if (a.mode == 1 || a.fsm == 1) {
             // one song = one contiguous run of the sorted list: the run's first max wins
-            for (int c = tid; c < nc; c += 256) {
+            for (int c = tid; c < nc; c += NT) {
                 const Cand cd = unpack_cand(a.mode, sk[c]);
                 if (c > 0 && unpack_cand(a.mode, sk[c - 1]).song == cd.song) continue;   // not a run head
                 double best = 0.0;   // slots start at 0: only scores > 0 are recorded
@@ -215,7 +217,7 @@ int launch_match(const RerankArgs &a, hipStream_t s) {
     if (a.n_songs >= (1 << 30)) { set_error("match: too many songs"); return -1; }
     static bool attr_set = false;
     if (!attr_set) {
-        PF_HIP(hipFuncSetAttribute((const void *)match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        PF_HIP(hipFuncSetAttribute((const void *)match_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    MAXC * 12));
         attr_set = true;
     }
@@ -224,7 +226,9 @@ int launch_match(const RerankArgs &a, hipStream_t s) {
         return -1;
     }
     ProfScope ps("seq_match", s);
-    hipLaunchKernelGGL(match_kernel, dim3((unsigned)a.nQ), dim3(256), (size_t)a.pmax * 12, s, a);
+    // 16 waves per query: candidate scoring is a latency-bound gather (<= 19 dependent-free row loads
+    // per candidate), so more waves in flight per query is what shortens it
+    hipLaunchKernelGGL(match_kernel<1024>, dim3((unsigned)a.nQ), dim3(1024), (size_t)a.pmax * 12, s, a);
     PF_HIP(hipGetLastError());
     return 0;
 }
