@@ -166,8 +166,9 @@ typedef struct pfann_match_result {
  * results_dev[nQ]; song_scores_dev[nQ][n_songs][2] may be NULL; when given it must be
  * zeroed by the caller and receives (score, offset-in-frames) of songs owned by the shard.
  * only_owned=1 restricts candidates to songs of this shard (multi-GPU rerank).
- * max_qlen = largest qlen[j] (sizes the LDS candidate buffer: max_qlen*k <= 8192);
- * a query that exceeds it gets song=-2. */
+ * max_qlen = largest qlen[j]: candidate lists of up to 8192 (qlen*k) entries are sorted in LDS,
+ * longer ones (e.g. a 60 s query at k=100) in a per-query HBM slab the handle grows on demand;
+ * a query longer than max_qlen gets song=-2. */
 int pfann_match(pfann_db *db, const float *q_dev, const int64_t *labels_dev, int k,
                 const int64_t *qstart_dev, const int32_t *qlen_dev, int64_t nQ, int max_qlen,
                 int frame_shift_mul, float score_alpha, int mode, int only_owned,

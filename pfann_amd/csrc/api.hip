@@ -478,6 +478,8 @@ struct pfann_db {
     std::vector<int64_t> song_pos_h;
     int n_songs = 0, song_lo = 0, song_hi = 0;
     SearchWorkspace ws;
+    void *match_scratch = nullptr;      // long-query candidate slab (keys + sums), grown on demand
+    size_t match_scratch_bytes = 0;
 };
 
 extern "C" {
@@ -498,6 +500,7 @@ void pfann_db_destroy(pfann_db *db) {
     if (db->song_pos) (void)hipFree(db->song_pos);
     if (db->ws.thr) { (void)hipFree(db->ws.thr); (void)hipFree(db->ws.cnt); (void)hipFree(db->ws.cl); }
     if (db->ws.overflow) (void)hipFree(db->ws.overflow);
+    if (db->match_scratch) (void)hipFree(db->match_scratch);
     delete db;
 }
 
@@ -538,7 +541,15 @@ int pfann_db_load(pfann_db *db, const float *emb, int emb_is_device, int64_t n, 
 
 int pfann_search_topk(pfann_db *db, const float *q, int64_t nq, int k, float *D, int64_t *I, void *stream) {
     PF_HIP(hipSetDevice(db->device));
-    return search_topk(db->emb, db->n, db->d, db->label_base, q, nq, k, D, I, db->ws, (hipStream_t)stream);
+    // the survivor workspace is 64 KB per query row: bound it by walking big batches in chunks
+    const int64_t chunk = 16384;
+    for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
+        const int64_t n = std::min(chunk, nq - q0);
+        const int rc = search_topk(db->emb, db->n, db->d, db->label_base, q + q0 * db->d, n, k, D + q0 * k,
+                                   I + q0 * k, db->ws, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 int pfann_topk_merge(pfann_db *db, const float *S, const int64_t *L, int64_t nq, int m, int k, float *D,
@@ -559,6 +570,20 @@ int pfann_match(pfann_db *db, const float *q, const int64_t *labels, int k, cons
     int P = 1;
     while (P < (int64_t)max_qlen * k) P <<= 1;
     a.pmax = P;
+    a.gkeys = nullptr; a.gscore = nullptr;
+    if (P > 8192) {     // longer than the LDS candidate buffer: per-query slabs in HBM
+        if ((int64_t)max_qlen * k > (1 << 22)) { set_error("match: query of %d rows x top_k %d is too long", max_qlen, k); return -1; }
+        const size_t need = (size_t)nQ * P * 12;
+        if (db->match_scratch_bytes < need) {
+            PF_HIP(hipStreamSynchronize((hipStream_t)stream));
+            if (db->match_scratch) (void)hipFree(db->match_scratch);
+            db->match_scratch = nullptr; db->match_scratch_bytes = 0;
+            PF_HIP(hipMalloc(&db->match_scratch, need));
+            db->match_scratch_bytes = need;
+        }
+        a.gkeys = reinterpret_cast<unsigned long long *>(db->match_scratch);
+        a.gscore = reinterpret_cast<float *>(a.gkeys + (size_t)nQ * P);
+    }
     a.results = results; a.song_scores = song_scores;
     return launch_match(a, (hipStream_t)stream);
 }

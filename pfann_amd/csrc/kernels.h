@@ -67,6 +67,7 @@ struct RerankArgs {
     const int64_t *qstart; const int32_t *qlen; int64_t nQ;
     int fsm; float alpha; int mode; int only_owned;
     int pmax;               // next pow2 >= max_qlen * k (LDS sizing)
+    unsigned long long *gkeys; float *gscore;   // HBM scratch [nQ][pmax] used instead of LDS when pmax > 8192
     pfann_match_result *results; float *song_scores;
 };
 int launch_match(const RerankArgs &a, hipStream_t s);

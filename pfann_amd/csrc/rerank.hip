@@ -57,7 +57,7 @@ __device__ void bitonic_sort_keys(unsigned long long *sk, int P, int tid) {
 
 template <int NT>
 __global__ __launch_bounds__(NT) void match_kernel(RerankArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long sk[];   // [P] keys
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sk_lds[];   // [P] keys
     __shared__ int s_nc;
     const int64_t qi = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -66,11 +66,14 @@ __global__ __launch_bounds__(NT) void match_kernel(RerankArgs a) {
     const int ntot = qlen * a.k;
     int P = 1;
     while (P < ntot) P <<= 1;
-    if (P > a.pmax) {   // host sized the LDS for max_qlen: refuse rather than overrun
+    if (P > a.pmax) {   // host sized the buffers for max_qlen: refuse rather than overrun
         if (tid == 0) { pfann_match_result r; r.song = -2; r.offset = 0; r.shift = 0; r.n_cand = -1; r.score = -INFINITY; a.results[qi] = r; }
         return;
     }
-    float *score = reinterpret_cast<float *>(sk + P);                        // [P] candidate sums
+    // candidate keys + sums live in LDS for ordinary queries and in an HBM scratch slab for very
+    // long ones (same code: a workgroup's global stores are visible to it after __syncthreads)
+    unsigned long long *sk = a.gkeys ? a.gkeys + qi * (int64_t)a.pmax : sk_lds;
+    float *score = a.gkeys ? a.gscore + qi * (int64_t)a.pmax : reinterpret_cast<float *>(sk_lds + P);
 
     // ---- candidates (database.py:133-138 / seqscore.cpp:49-60)
     for (int i = tid; i < P; i += NT) {
@@ -221,11 +224,16 @@ int launch_match(const RerankArgs &a, hipStream_t s) {
                                    MAXC * 12));
         attr_set = true;
     }
-    if (a.pmax > MAXC) {
-        set_error("match: max_qlen*top_k needs %d candidate slots > %d", a.pmax, MAXC);
+    if (a.pmax > MAXC && a.gkeys == nullptr) {
+        set_error("match: max_qlen*top_k needs %d candidate slots > %d and no scratch was given", a.pmax, MAXC);
         return -1;
     }
     ProfScope ps("seq_match", s);
+    if (a.gkeys != nullptr) {
+        hipLaunchKernelGGL(match_kernel<1024>, dim3((unsigned)a.nQ), dim3(1024), 64, s, a);
+        PF_HIP(hipGetLastError());
+        return 0;
+    }
     // 16 waves per query: candidate scoring is a latency-bound gather (<= 19 dependent-free row loads
     // per candidate), so more waves in flight per query is what shortens it
     hipLaunchKernelGGL(match_kernel<1024>, dim3((unsigned)a.nQ), dim3(1024), (size_t)a.pmax * 12, s, a);

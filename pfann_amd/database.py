@@ -108,7 +108,7 @@ class DeviceIndex:
                        ("score", "<f8")])
         out = np.frombuffer(res.cpu().numpy().tobytes(), dtype=dt)
         if (out["song"] == -2).any():
-            raise _l.PfannError("query longer than the matcher's candidate buffer (qlen*top_k > 8192)")
+            raise _l.PfannError("matcher refused a query (candidate buffer sizing error)")
         return out, ss
 
 

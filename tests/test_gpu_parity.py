@@ -364,3 +364,52 @@ def test_match_batched_random_vs_oracle(torch_cuda):
         score, (song, sec), _ = osq.query_embeddings_base(q[sl], In[sl], db, pos, 0.5, 1)
         assert int(res[j]["song"]) == song and int(res[j]["offset"]) * 0.5 == sec, j
         assert abs(float(res[j]["score"]) - score) < 1e-6
+
+
+def test_match_long_query_uses_hbm_scratch(torch_cuda):
+    """A 60 s query (119 rows x top-100 = 11900 candidates) exceeds the LDS candidate buffer and
+    goes through the HBM scratch path; decisions still equal the python-path oracle.  Mixed with a
+    short query in the same launch."""
+    from oracle import seqscore as osq
+    from pfann_amd.database import DeviceIndex
+    d = 64
+    key = [150 + 7 * (i % 9) for i in range(120)]
+    db = synth.unit_rows(61, "t/longdb", sum(key), d)
+    pos = osq.song_pos_from_key(key)
+    idx = DeviceIndex(d, 0)
+    idx.load(db, pos, 0)
+    ql = [119, 9, 119]
+    starts = [(33, 10), (70, 3), (5, 20)]
+    qs = []
+    for j, (s, off) in enumerate(starts):
+        qq = db[pos[s] + off: pos[s] + off + ql[j]] + 0.5 * synth.unit_rows(200 + j, "t/longq", ql[j], d)
+        qs.append(qq / np.linalg.norm(qq, axis=1, keepdims=True))
+    q = np.concatenate(qs).astype(np.float32)
+    qstart = [0, 119, 128]
+    qt = torch_cuda.as_tensor(q).cuda()
+    D, I = idx.search(qt, 100)
+    res, ss = idx.match(qt, I, qstart, ql, 1, 0.0, 0, False, True)
+    In = I.cpu().numpy()
+    for j in range(3):
+        sl = slice(qstart[j], qstart[j] + ql[j])
+        score, (song, sec), ss_ref = osq.query_embeddings_base(q[sl], In[sl], db, pos, 1.0, 1)
+        assert int(res[j]["song"]) == song == starts[j][0] and int(res[j]["offset"]) == int(sec) == starts[j][1]
+        assert abs(float(res[j]["score"]) - score) < 1e-6
+        got = ss.cpu().numpy()[j]
+        assert np.allclose(got, ss_ref, atol=1e-6) and np.array_equal(got[:, 1], ss_ref[:, 1])
+
+
+def test_search_chunks_large_query_batches(torch_cuda):
+    """pfann_search_topk walks batches above 16384 rows in chunks (bounded survivor workspace)."""
+    from oracle import search as osr
+    from pfann_amd.database import DeviceIndex
+    d, n, nq = 16, 3000, 16384 + 700
+    db = synth.unit_rows(71, "t/cdb", n, d)
+    q = synth.unit_rows(72, "t/cq", nq, d)
+    idx = DeviceIndex(d, 0)
+    idx.load(db, np.array([0, n], np.int64), 0)
+    D, I = idx.search(torch_cuda.as_tensor(q).cuda(), 5)
+    I = I.cpu().numpy()
+    rows = [0, 1, 16383, 16384, 16385, nq - 1]
+    Dr, Ir = osr.flat_ip_topk(q[rows], db, 5)
+    assert np.array_equal(I[rows], Ir)
