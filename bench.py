@@ -197,18 +197,22 @@ def main():
             "conv_gemm_128": ("pfann::conv_gemm_kernel<128,128,64,64>", "mfma"),
             "conv_gemm_64": ("pfann::conv_gemm_kernel<64,64,32,32>", "mfma"),
             "scan_topk": ("pfann::scan_emit_kernel (full-db pass)", "mfma"),
+            "scan_topk_f16": ("pfann::scan_f16_kernel (fp16 pre-filter pass; exact fp32 re-scoring follows)", "mfma16"),
             "ln_act": ("pfann::ln_act_kernel", "hbm"), "conv_first": ("pfann::conv_first_kernel", "hbm")}
     for tag, kv in kernels.items():
         if tag in ROOF and kv["work_per_launch"] > 0:
             rate = kv["work_per_launch"] / (kv["avg_us"] * 1e-6)
-            if ROOF[tag][1] == "mfma":
+            if ROOF[tag][1] == "mfma16":
+                kv["TFLOPs"] = rate / 1e12
+                kv["frac_of_peak"] = rate / 1e12 / 2500.0
+            elif ROOF[tag][1] == "mfma":
                 kv["TFLOPs"] = rate / 1e12
                 kv["frac_of_peak"] = rate / 1e12 / PEAK_F32_MFMA
             else:
                 kv["GBps"] = rate / 1e9
                 kv["frac_of_peak"] = rate / 1e9 / PEAK_HBM
     roofline = None
-    cands = [t for t in kernels if t in ROOF and kernels[t]["work_per_launch"] > 0]
+    cands = [t for t in kernels if t in ROOF and ROOF[t][1] != "mfma16" and kernels[t]["work_per_launch"] > 0]
     if cands:
         dom = max(cands, key=lambda t: kernels[t]["ms_per_step"])
         kv = kernels[dom]
@@ -234,8 +238,10 @@ def main():
                     break
         except (OSError, ValueError, KeyError):
             pass
-    if "scan_topk" in kernels:
-        ks = kernels["scan_topk"]
+    for stag in ("scan_topk", "scan_topk_f16"):
+        if stag not in kernels:
+            continue
+        ks = kernels[stag]
         gbs = (r_hi - r_lo) * d * 4 / (ks["avg_us"] * 1e-6) / 1e9
         ks.update({"db_GBps": gbs, "db_hbm_frac": gbs / PEAK_HBM})
 

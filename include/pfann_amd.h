@@ -140,6 +140,11 @@ int64_t pfann_db_ntotal(pfann_db *db);
 int pfann_db_load(pfann_db *db, const float *emb, int emb_is_device, int64_t n,
                   const int64_t *song_pos_host, int n_songs, int64_t label_base);
 
+/* Batches of more than 64 query rows are scanned on the fp16 matrix cores with a rigorous error
+ * margin and re-scored in exact fp32 (csrc/search_f16.hip): the result is the exact fp32 top-k
+ * either way.  on=0 forces the all-fp32 scan.  Returns 1 if the pre-filter is now in use. */
+int pfann_db_set_prefilter(pfann_db *db, int on);
+
 /* Exact inner-product top-k of q_dev[nq][d] over the shard: D_dev[nq][k] descending,
  * I_dev[nq][k] int64 labels (+label_base); unfilled slots D=-FLT_MAX, I=-1. */
 int pfann_search_topk(pfann_db *db, const float *q_dev, int64_t nq, int k, float *D_dev,

@@ -10,6 +10,8 @@
 
 #include "kernels.h"
 
+namespace pfann { int launch_rows_to_half(const float *x, int64_t n, int d, void *xh, float *norm_max_dev, hipStream_t s); }
+
 namespace pfann {
 
 static thread_local char g_err[1024] = "";
@@ -478,6 +480,9 @@ struct pfann_db {
     std::vector<int64_t> song_pos_h;
     int n_songs = 0, song_lo = 0, song_hi = 0;
     SearchWorkspace ws;
+    void *emb_h = nullptr;              // fp16 copy of the rows (pre-filter of the batched scan)
+    float xnorm_max = 0.f;
+    bool prefilter = true;
     void *match_scratch = nullptr;      // long-query candidate slab (keys + sums), grown on demand
     size_t match_scratch_bytes = 0;
 };
@@ -500,10 +505,17 @@ void pfann_db_destroy(pfann_db *db) {
     if (db->song_pos) (void)hipFree(db->song_pos);
     if (db->ws.thr) { (void)hipFree(db->ws.thr); (void)hipFree(db->ws.cnt); (void)hipFree(db->ws.cl); }
     if (db->ws.overflow) (void)hipFree(db->ws.overflow);
+    if (db->ws.thr_adj) { (void)hipFree(db->ws.thr_adj); (void)hipFree(db->ws.eps); }
+    if (db->ws.qh) (void)hipFree(db->ws.qh);
     if (db->match_scratch) (void)hipFree(db->match_scratch);
+    if (db->emb_h) (void)hipFree(db->emb_h);
     delete db;
 }
 
+int pfann_db_set_prefilter(pfann_db *db, int on) {
+    db->prefilter = on != 0;
+    return (db->prefilter && db->emb_h != nullptr) ? 1 : 0;
+}
 int pfann_db_dim(pfann_db *db) { return db->d; }
 int64_t pfann_db_ntotal(pfann_db *db) { return db->n; }
 int64_t pfann_db_bytes(pfann_db *db) { return db->n * db->d * (int64_t)sizeof(float); }
@@ -520,6 +532,22 @@ int pfann_db_load(pfann_db *db, const float *emb, int emb_is_device, int64_t n, 
         PF_HIP(hipMalloc(&db->emb, (size_t)n * db->d * sizeof(float)));
         PF_HIP(hipMemcpy(db->emb, emb, (size_t)n * db->d * sizeof(float),
                          emb_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    }
+    // fp16 copy + largest row norm for the batched scan's pre-filter (search_f16.hip)
+    if (db->emb_h) { (void)hipFree(db->emb_h); db->emb_h = nullptr; }
+    db->xnorm_max = 0.f;
+    if (n > 0 && db->d % 8 == 0 && getenv("PFANN_NO_F16_PREFILTER") == nullptr) {
+        float *nm = nullptr;
+        PF_HIP(hipMalloc(&db->emb_h, (size_t)n * db->d * 2));
+        PF_HIP(hipMalloc(&nm, sizeof(float)));
+        PF_HIP(hipMemset(nm, 0, sizeof(float)));
+        if (launch_rows_to_half(db->emb, n, db->d, db->emb_h, nm, 0)) return -1;
+        PF_HIP(hipMemcpy(&db->xnorm_max, nm, sizeof(float), hipMemcpyDeviceToHost));
+        (void)hipFree(nm);
+        if (!(db->xnorm_max < 1.0e4f)) {       // fp16 range / NaN guard: keep the exact-fp32 scan only
+            (void)hipFree(db->emb_h);
+            db->emb_h = nullptr;
+        }
     }
     db->song_pos_h.assign(song_pos, song_pos + n_songs + 1);
     PF_HIP(hipMalloc(&db->song_pos, (size_t)(n_songs + 1) * sizeof(int64_t)));
@@ -545,8 +573,9 @@ int pfann_search_topk(pfann_db *db, const float *q, int64_t nq, int k, float *D,
     const int64_t chunk = 16384;
     for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
         const int64_t n = std::min(chunk, nq - q0);
-        const int rc = search_topk(db->emb, db->n, db->d, db->label_base, q + q0 * db->d, n, k, D + q0 * k,
-                                   I + q0 * k, db->ws, (hipStream_t)stream);
+        const int rc = search_topk(db->emb, db->prefilter ? db->emb_h : nullptr, db->xnorm_max, db->n, db->d,
+                                   db->label_base, q + q0 * db->d, n, k, D + q0 * k, I + q0 * k, db->ws,
+                                   (hipStream_t)stream);
         if (rc) return rc;
     }
     return 0;
@@ -577,6 +606,7 @@ int pfann_match(pfann_db *db, const float *q, const int64_t *labels, int k, cons
         if (db->match_scratch_bytes < need) {
             PF_HIP(hipStreamSynchronize((hipStream_t)stream));
             if (db->match_scratch) (void)hipFree(db->match_scratch);
+    if (db->emb_h) (void)hipFree(db->emb_h);
             db->match_scratch = nullptr; db->match_scratch_bytes = 0;
             PF_HIP(hipMalloc(&db->match_scratch, need));
             db->match_scratch_bytes = need;
@@ -639,7 +669,7 @@ done:
 
 // ---- profiling ------------------------------------------------------------------------
 void pfann_prof_marker(void *stream) {
-    hipLaunchKernelGGL(pfann_bench_region_marker, dim3(1), dim3(64), 0, (hipStream_t)stream);
+    PF_LAUNCH(pfann_bench_region_marker, dim3(1), dim3(64), 0, (hipStream_t)stream);
 }
 void pfann_prof_enable(int on) { g_prof = on != 0; }
 void pfann_prof_reset(void) {

@@ -22,6 +22,15 @@ void set_error(const char *fmt, ...);
         }                                                                                 \
     } while (0)
 
+// Kernel launch with a clean error slate: other libraries in the process (PyTorch probes host
+// pointers with hipPointerGetAttributes) leave stale errors in HIP's per-thread last-error slot,
+// which the post-launch hipGetLastError() check must not inherit.
+#define PF_LAUNCH(...)                 \
+    do {                               \
+        (void)hipGetLastError();       \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
+
 // ---- per-kernel HIP-event profiling (bench.py roofline leg) -----------------------------
 bool prof_on();
 void prof_begin(const char *tag, hipStream_t s);

@@ -200,13 +200,13 @@ int launch_conv_gemm(const SubLayer &L, const float *x, float *y, int64_t B, hip
     if (p.N >= 128 && blocks128 >= 512) {
         p.n_tiles_n = cdiv(p.N, 128);
         ProfScope ps("conv_gemm_128", s, flops);
-        hipLaunchKernelGGL((conv_gemm_kernel<128, 128, 64, 64>), dim3((unsigned)blocks128), dim3(256),
+        PF_LAUNCH((conv_gemm_kernel<128, 128, 64, 64>), dim3((unsigned)blocks128), dim3(256),
                            0, s, p);
     } else {
         p.n_tiles_n = cdiv(p.N, 64);
         const int64_t blocks = (int64_t)cdiv(p.M, 64) * p.n_tiles_n;
         ProfScope ps("conv_gemm_64", s, flops);
-        hipLaunchKernelGGL((conv_gemm_kernel<64, 64, 32, 32>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        PF_LAUNCH((conv_gemm_kernel<64, 64, 32, 32>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     }
     PF_HIP(hipGetLastError());
     return 0;
@@ -246,7 +246,7 @@ int launch_conv_first(const SubLayer &L, const float *x, float *y, int64_t B, hi
     const int64_t M = B * L.Fo * L.To;
     const int64_t n = M * (L.co / 4);
     ProfScope ps("conv_first", s, 4.0 * ((double)M * L.co + (double)B * L.F * L.T));
-    hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, x, L.w, L.bias,
+    PF_LAUNCH(conv_first_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, x, L.w, L.bias,
                        y, M, L.co, L.To, L.T, L.stride, L.pad_lo);
     PF_HIP(hipGetLastError());
     return 0;
@@ -290,7 +290,7 @@ int launch_conv_depthwise(const SubLayer &L, const float *x, float *y, int64_t B
     const int64_t M = B * L.Fo * L.To;
     const int64_t n = M * (L.co / 4);
     ProfScope ps("conv_depthwise", s);
-    hipLaunchKernelGGL(conv_dw_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, x, L.w, L.bias, y, M,
+    PF_LAUNCH(conv_dw_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, x, L.w, L.bias, y, M,
                        L.co, L.Fo, L.To, L.F, L.T, L.axis, L.stride, L.pad_lo);
     PF_HIP(hipGetLastError());
     return 0;
@@ -352,10 +352,10 @@ int launch_ln_act(const SubLayer &L, float *xy, int64_t B, int activation, int r
     const int n = L.co * L.Fo * L.To;
     ProfScope ps("ln_act", s, 4.0 * (double)B * n * 3.0);
     if (n >= 65536)
-        hipLaunchKernelGGL((ln_act_kernel<1024>), dim3((unsigned)B), dim3(1024), 0, s, xy, L.ln_w, L.ln_b, n,
+        PF_LAUNCH((ln_act_kernel<1024>), dim3((unsigned)B), dim3(1024), 0, s, xy, L.ln_w, L.ln_b, n,
                            activation, relu_after_bn);
     else
-        hipLaunchKernelGGL((ln_act_kernel<256>), dim3((unsigned)B), dim3(256), 0, s, xy, L.ln_w, L.ln_b, n,
+        PF_LAUNCH((ln_act_kernel<256>), dim3((unsigned)B), dim3(256), 0, s, xy, L.ln_w, L.ln_b, n,
                            activation, relu_after_bn);
     PF_HIP(hipGetLastError());
     return 0;
@@ -403,7 +403,7 @@ int launch_myg(const float *x, const float *w1, const float *b1, const float *w2
     const int nt = ((d + 63) / 64) * 64;
     if (nt > 1024) { set_error("MyG: d = %d > 1024 unsupported", d); return -1; }
     ProfScope ps("myg", s);
-    hipLaunchKernelGGL(myg_kernel, dim3((unsigned)B), dim3(nt), 0, s, x, w1, b1, w2, b2, d, u, v, emb,
+    PF_LAUNCH(myg_kernel, dim3((unsigned)B), dim3(nt), 0, s, x, w1, b1, w2, b2, d, u, v, emb,
                        normalize);
     PF_HIP(hipGetLastError());
     return 0;
@@ -421,7 +421,7 @@ __global__ void cl_to_nchw_kernel(const float *__restrict__ x, float *__restrict
 }
 int launch_cl_to_nchw(const float *x, float *y, int64_t B, int C, int HW, hipStream_t s) {
     const int64_t total = B * C * HW;
-    hipLaunchKernelGGL(cl_to_nchw_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, x, y, total, C, HW);
+    PF_LAUNCH(cl_to_nchw_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, x, y, total, C, HW);
     PF_HIP(hipGetLastError());
     return 0;
 }

@@ -394,17 +394,17 @@ int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, 
         // 8 waves (512 threads), each a 64x32 tile: half the prefetch registers per thread and four
         // waves per SIMD with two resident blocks
         if (act == 0 && after_bn)
-            hipLaunchKernelGGL((conv_gemm_ln_kernel<128, 128, 64, 32, true>), dim3((unsigned)blocks), dim3(512), 0, s, p);
+            PF_LAUNCH((conv_gemm_ln_kernel<128, 128, 64, 32, true>), dim3((unsigned)blocks), dim3(512), 0, s, p);
         else
-            hipLaunchKernelGGL((conv_gemm_ln_kernel<128, 128, 64, 32, false>), dim3((unsigned)blocks), dim3(512), 0, s, p);
+            PF_LAUNCH((conv_gemm_ln_kernel<128, 128, 64, 32, false>), dim3((unsigned)blocks), dim3(512), 0, s, p);
     } else {
         p.n_tiles_n = cdiv(p.N, 64);
         const int64_t blocks = (int64_t)cdiv(p.M, 64) * p.n_tiles_n;
         ProfScope ps("conv_gemm_ln_64", s, flops);
         if (act == 0 && after_bn)
-            hipLaunchKernelGGL((conv_gemm_ln_kernel<64, 64, 32, 32, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+            PF_LAUNCH((conv_gemm_ln_kernel<64, 64, 32, 32, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
         else
-            hipLaunchKernelGGL((conv_gemm_ln_kernel<64, 64, 32, 32, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+            PF_LAUNCH((conv_gemm_ln_kernel<64, 64, 32, 32, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     }
     PF_HIP(hipGetLastError());
     return 0;
@@ -472,7 +472,7 @@ int launch_conv_first_stats(const SubLayer &L, const float *x, float *y, float *
     const int rps = L.Fo * L.To;
     const int64_t M = B * rps;
     ProfScope ps("conv_first_stats", s, 4.0 * ((double)M * L.co + (double)B * L.F * L.T));
-    hipLaunchKernelGGL(conv_first_stats_kernel, dim3((unsigned)cdiv(M, 64)), dim3(256), 0, s, x, L.w, L.bias, y,
+    PF_LAUNCH(conv_first_stats_kernel, dim3((unsigned)cdiv(M, 64)), dim3(256), 0, s, x, L.w, L.bias, y,
                        part, M, L.co, L.To, L.T, L.stride, L.pad_lo, rps, fused_out_slots(L, B), act, after_bn);
     PF_HIP(hipGetLastError());
     return 0;
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) void ln_apply_kernel(const float *__restrict__
 int launch_ln_apply(const SubLayer &L, const float *z, const float *part, int P, float *out, int64_t B, int act,
                     int after_bn, hipStream_t s) {
     const int n = L.co * L.Fo * L.To;
-    hipLaunchKernelGGL(ln_apply_kernel, dim3((unsigned)B), dim3(256), 0, s, z, part, P, L.ln_w, L.ln_b, out, n, act,
+    PF_LAUNCH(ln_apply_kernel, dim3((unsigned)B), dim3(256), 0, s, z, part, P, L.ln_w, L.ln_b, out, n, act,
                        after_bn);
     PF_HIP(hipGetLastError());
     return 0;
@@ -581,7 +581,7 @@ int launch_myg_ln(const SubLayer &Llast, const float *z, const float *part, int 
     const int nt = ((d + 63) / 64) * 64;
     if (nt > 1024) { set_error("MyG: d = %d > 1024 unsupported", d); return -1; }
     ProfScope ps("myg_ln", s);
-    hipLaunchKernelGGL(myg_ln_kernel, dim3((unsigned)B), dim3(nt), 0, s, z, part, P, Llast.ln_w, Llast.ln_b, act,
+    PF_LAUNCH(myg_ln_kernel, dim3((unsigned)B), dim3(nt), 0, s, z, part, P, Llast.ln_w, Llast.ln_b, act,
                        after_bn, w1, b1, w2, b2, d, u, v, emb, normalize);
     PF_HIP(hipGetLastError());
     return 0;

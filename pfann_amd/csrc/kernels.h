@@ -53,9 +53,16 @@ struct SearchWorkspace {
     float *cs = nullptr;    // [cap_q][cap_c]
     int64_t *cl = nullptr;  // [cap_q][cap_c]
     int *overflow = nullptr;
+    // fp16 pre-filter path (search_f16.hip)
+    float *thr_adj = nullptr;  // [cap_q] tau - eps
+    float *eps = nullptr;      // [cap_q] per-row bound of |s16 - s|
+    void *qh = nullptr;        // [cap_q][d] fp16 query rows
+    int64_t qh_elems = 0;
 };
-int search_topk(const float *db, int64_t n, int d, int64_t label_base, const float *q, int64_t nq,
-                int k, float *D, int64_t *I, SearchWorkspace &ws, hipStream_t s);
+// dbh != nullptr: fp16 copy of the rows for the pre-filter path (used for batches > 64 rows);
+// xnorm_max = largest row norm of db.
+int search_topk(const float *db, const void *dbh, float xnorm_max, int64_t n, int d, int64_t label_base,
+                const float *q, int64_t nq, int k, float *D, int64_t *I, SearchWorkspace &ws, hipStream_t s);
 int topk_merge(const float *S, const int64_t *L, int64_t nq, int m, int k, float *D, int64_t *I,
                hipStream_t s);
 

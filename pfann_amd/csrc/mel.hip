@@ -182,7 +182,7 @@ int launch_melspec(const MelPlan &mp, const float *segs, int64_t B, int64_t seg_
         attr_set = true;
     }
     ProfScope ps("melspec", s);
-    hipLaunchKernelGGL(melspec_kernel, dim3((unsigned)B), dim3(256), lds, s, a);
+    PF_LAUNCH(melspec_kernel, dim3((unsigned)B), dim3(256), lds, s, a);
     PF_HIP(hipGetLastError());
     return 0;
 }
@@ -222,9 +222,9 @@ int launch_pcm16_to_mono(const int16_t *pcm, int64_t n_frames, int n_ch, float *
     ProfScope ps("pcm16_to_mono", s);
     if (n_ch == 2) {
         PF_HIP(hipMemsetAsync(pw, 0, 2 * sizeof(double), s));
-        hipLaunchKernelGGL(stereo_power_kernel, dim3(512), dim3(256), 0, s, pcm, n_frames, pw);
+        PF_LAUNCH(stereo_power_kernel, dim3(512), dim3(256), 0, s, pcm, n_frames, pw);
     }
-    hipLaunchKernelGGL(pcm_to_mono_kernel, dim3((unsigned)cdiv(n_frames, 256)), dim3(256), 0, s, pcm, n_frames,
+    PF_LAUNCH(pcm_to_mono_kernel, dim3((unsigned)cdiv(n_frames, 256)), dim3(256), 0, s, pcm, n_frames,
                        n_ch, pw, wav);
     PF_HIP(hipGetLastError());
     return 0;

@@ -230,13 +230,13 @@ int launch_match(const RerankArgs &a, hipStream_t s) {
     }
     ProfScope ps("seq_match", s);
     if (a.gkeys != nullptr) {
-        hipLaunchKernelGGL(match_kernel<1024>, dim3((unsigned)a.nQ), dim3(1024), 64, s, a);
+        PF_LAUNCH(match_kernel<1024>, dim3((unsigned)a.nQ), dim3(1024), 64, s, a);
         PF_HIP(hipGetLastError());
         return 0;
     }
     // 16 waves per query: candidate scoring is a latency-bound gather (<= 19 dependent-free row loads
     // per candidate), so more waves in flight per query is what shortens it
-    hipLaunchKernelGGL(match_kernel<1024>, dim3((unsigned)a.nQ), dim3(1024), (size_t)a.pmax * 12, s, a);
+    PF_LAUNCH(match_kernel<1024>, dim3((unsigned)a.nQ), dim3(1024), (size_t)a.pmax * 12, s, a);
     PF_HIP(hipGetLastError());
     return 0;
 }

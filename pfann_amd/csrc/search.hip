@@ -16,40 +16,9 @@
 //     the captured survivors and rescans; it never degrades to an approximate answer.
 #include <algorithm>
 
-#include "kernels.h"
+#include "search_common.h"
 
 namespace pfann {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-static constexpr int CAP = 8192;   // survivor slots per query row
-
-__device__ __forceinline__ unsigned f2ord(float f) {   // monotone float -> uint
-    const unsigned u = __float_as_uint(f);
-    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
-}
-__device__ __forceinline__ float ord2f(unsigned o) {
-    const unsigned u = o ^ ((o >> 31) ? 0x80000000u : 0xFFFFFFFFu);
-    return __uint_as_float(u);
-}
-// ascending sort of packed keys == descending score, ascending row
-__device__ __forceinline__ unsigned long long pack_key(float score, unsigned row) {
-    return ((unsigned long long)(~f2ord(score)) << 32) | row;
-}
-
-
-struct ScanParams {
-    const float *q, *db;
-    int64_t nq, nrows;       // nrows = rows scanned at this level = ceil(N / stride)
-    int64_t row_stride;      // db row step (level stride)
-    int d;
-    const float *thr;        // [nq] or nullptr (= emit everything, densely: slot = row index)
-    int *cnt;                // [nq]
-    unsigned long long *keys;  // [nq][CAP]
-    int n_tiles_m;
-    int nsub;                // survivor sub-lists per query row (small-batch kernel: 32), else 1
-};
 
 // One workgroup owns one db tile (BN rows) and a run of QT consecutive query tiles, walked with a
 // single software pipeline: tile (q, kt+1) -- or (q+1, 0) -- is prefetched while (q, kt) is on the
@@ -329,22 +298,6 @@ __global__ __launch_bounds__(256, 2) void scan_small_kernel(ScanParams p) {
 //   mode 1: write D[m][k], I[m][k] (+label_base); pad with -FLT_MAX / -1
 // overflow[0] is set when a final-level list overflowed.
 // ------------------------------------------------------------------------------------
-__device__ void bitonic_sort_u64(unsigned long long *s, int P, int tid, int nt) {
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < P; i += nt) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned long long a = s[i], b = s[ixj];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { s[i] = b; s[ixj] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
 __global__ __launch_bounds__(1024) void select_kernel(const unsigned long long *__restrict__ keys,
                                                       const int *__restrict__ cnt, int k, int mode,
                                                       float *__restrict__ thr, float *__restrict__ D,
@@ -415,7 +368,7 @@ static int launch_scan(const float *db, int64_t n, int d, int64_t stride, const 
     *nsub_out = p.nsub;
     if (thr == nullptr) {
         if (p.nrows > CAP) { set_error("scan: dense level with %lld rows > %d", (long long)p.nrows, CAP); return -1; }
-        hipLaunchKernelGGL(fill_int_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, s, ws.cnt, (int)p.nrows, nq);
+        PF_LAUNCH(fill_int_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, s, ws.cnt, (int)p.nrows, nq);
     } else {
         PF_HIP(hipMemsetAsync(ws.cnt, 0, sizeof(int) * nq * p.nsub, s));
     }
@@ -424,23 +377,23 @@ static int launch_scan(const float *db, int64_t n, int d, int64_t stride, const 
         // HBM-bound regime: persistent streaming kernel, 2 blocks per CU
         const int64_t tiles = (p.nrows + 31) / 32;
         const unsigned grid = (unsigned)std::min<int64_t>(512, (tiles + 3) / 4);
-        if (d == 128) hipLaunchKernelGGL((scan_small_kernel<128>), dim3(grid), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((scan_small_kernel<64>), dim3(grid), dim3(256), 0, s, p);
+        if (d == 128) PF_LAUNCH((scan_small_kernel<128>), dim3(grid), dim3(256), 0, s, p);
+        else PF_LAUNCH((scan_small_kernel<64>), dim3(grid), dim3(256), 0, s, p);
     } else if (nq <= 32) {
         p.n_tiles_m = 1;
-        hipLaunchKernelGGL((scan_emit_kernel<32, 128, 32, 32, 1>), dim3((unsigned)cdiv(p.nrows, 128)), dim3(256), 0, s, p);
+        PF_LAUNCH((scan_emit_kernel<32, 128, 32, 32, 1>), dim3((unsigned)cdiv(p.nrows, 128)), dim3(256), 0, s, p);
     } else if (nq <= 64) {
         p.n_tiles_m = 1;
-        hipLaunchKernelGGL((scan_emit_kernel<64, 64, 32, 32, 1>), dim3((unsigned)cdiv(p.nrows, 64)), dim3(256), 0, s, p);
+        PF_LAUNCH((scan_emit_kernel<64, 64, 32, 32, 1>), dim3((unsigned)cdiv(p.nrows, 64)), dim3(256), 0, s, p);
     } else {
         p.n_tiles_m = cdiv(nq, 128);
         const int64_t db_tiles = cdiv(p.nrows, 128);
         // long runs of query tiles per block only when the grid still fills the chip many times over
         if (db_tiles * cdiv(p.n_tiles_m, 4) >= 4096)
-            hipLaunchKernelGGL((scan_emit_kernel<128, 128, 64, 64, 4>), dim3((unsigned)(db_tiles * cdiv(p.n_tiles_m, 4))),
+            PF_LAUNCH((scan_emit_kernel<128, 128, 64, 64, 4>), dim3((unsigned)(db_tiles * cdiv(p.n_tiles_m, 4))),
                                dim3(256), 0, s, p);
         else
-            hipLaunchKernelGGL((scan_emit_kernel<128, 128, 64, 64, 1>), dim3((unsigned)(db_tiles * p.n_tiles_m)),
+            PF_LAUNCH((scan_emit_kernel<128, 128, 64, 64, 1>), dim3((unsigned)(db_tiles * p.n_tiles_m)),
                                dim3(256), 0, s, p);
     }
     PF_HIP(hipGetLastError());
@@ -456,7 +409,7 @@ static int launch_select(SearchWorkspace &ws, int64_t nq, int k, int mode, float
         attr_set = true;
     }
     ProfScope ps("topk_select", s);
-    hipLaunchKernelGGL(select_kernel, dim3((unsigned)nq), dim3(1024), CAP * 8, s,
+    PF_LAUNCH(select_kernel, dim3((unsigned)nq), dim3(1024), CAP * 8, s,
                        reinterpret_cast<const unsigned long long *>(ws.cl), ws.cnt, k, mode, ws.thr, D, I,
                        label_base, ws.overflow, nsub);
     PF_HIP(hipGetLastError());
@@ -468,6 +421,9 @@ static int ensure_ws(SearchWorkspace &ws, int64_t nq) {
     if (ws.thr) { (void)hipFree(ws.thr); (void)hipFree(ws.cnt); (void)hipFree(ws.cl); }
     if (!ws.overflow) PF_HIP(hipMalloc(&ws.overflow, sizeof(int)));
     const int64_t cap = nq < 64 ? 64 : nq;
+    if (ws.thr_adj) { (void)hipFree(ws.thr_adj); (void)hipFree(ws.eps); }
+    PF_HIP(hipMalloc(&ws.thr_adj, sizeof(float) * cap));
+    PF_HIP(hipMalloc(&ws.eps, sizeof(float) * cap));
     PF_HIP(hipMalloc(&ws.thr, sizeof(float) * cap));
     PF_HIP(hipMalloc(&ws.cnt, sizeof(int) * (cap < 2048 ? 2048 : cap)));
     PF_HIP(hipMalloc(&ws.cl, sizeof(unsigned long long) * cap * CAP));
@@ -481,14 +437,14 @@ __global__ void fill_empty_kernel(float *D, int64_t *I, int64_t total) {
     if (i < total) { D[i] = -3.4028234663852886e38f; I[i] = -1; }
 }
 
-int search_topk(const float *db, int64_t n, int d, int64_t label_base, const float *q, int64_t nq, int k,
-                float *D, int64_t *I, SearchWorkspace &ws, hipStream_t s) {
+int search_topk(const float *db, const void *dbh, float xnorm_max, int64_t n, int d, int64_t label_base,
+                const float *q, int64_t nq, int k, float *D, int64_t *I, SearchWorkspace &ws, hipStream_t s) {
     if (nq <= 0) return 0;
     if (k < 1 || k > 1024) { set_error("search_topk: k=%d outside 1..1024", k); return -1; }
     if (d % 4 != 0) { set_error("search_topk: d=%d must be a multiple of 4", d); return -1; }
     if (n >= (1ll << 32)) { set_error("search_topk: shard rows %lld >= 2^32", (long long)n); return -1; }
     if (n == 0) {
-        hipLaunchKernelGGL(fill_empty_kernel, dim3((unsigned)cdiv(nq * k, 256)), dim3(256), 0, s, D, I, nq * k);
+        PF_LAUNCH(fill_empty_kernel, dim3((unsigned)cdiv(nq * k, 256)), dim3(256), 0, s, D, I, nq * k);
         PF_HIP(hipGetLastError());
         return 0;
     }
@@ -498,6 +454,36 @@ int search_topk(const float *db, int64_t n, int d, int64_t label_base, const flo
     int levels = 0;
     int64_t stride = 1;
     while ((n + stride - 1) / stride > CAP) { stride *= R; ++levels; }
+    PF_HIP(hipMemsetAsync(ws.overflow, 0, sizeof(int), s));
+    if (dbh != nullptr && nq > 64) {
+        // ---- fp16 pre-filter + exact fp32 re-scoring (search_f16.hip): same levels, same exact result
+        if (ws.qh_elems < nq * d) {
+            if (ws.qh) (void)hipFree(ws.qh);
+            ws.qh = nullptr; ws.qh_elems = 0;
+            PF_HIP(hipMalloc(&ws.qh, (size_t)nq * d * 2));
+            ws.qh_elems = nq * d;
+        }
+        if (launch_q_prep(q, nq, d, xnorm_max, ws.qh, ws.eps, s)) return -1;
+        const float *ta = nullptr;
+        for (int lev = levels; lev >= 1; --lev) {
+            if (launch_scan_f16(dbh, n, d, stride, ws.qh, nq, ta, ws, s)) return -1;
+            if (launch_select_rescore(ws, nq, k, 0, nullptr, nullptr, 0, q, db, d, s)) return -1;
+            ta = ws.thr_adj;
+            stride /= R;
+        }
+        for (int attempt = 0; attempt < 4; ++attempt) {
+            if (launch_scan_f16(dbh, n, d, 1, ws.qh, nq, ta, ws, s)) return -1;
+            if (launch_select_rescore(ws, nq, k, 1, D, I, label_base, q, db, d, s)) return -1;
+            int ovf = 0;
+            PF_HIP(hipMemcpyAsync(&ovf, ws.overflow, sizeof(int), hipMemcpyDeviceToHost, s));
+            PF_HIP(hipStreamSynchronize(s));
+            if (!ovf) return 0;
+            if (ta == nullptr) { set_error("search_topk: survivor list overflow without threshold"); return -1; }
+            PF_HIP(hipMemsetAsync(ws.overflow, 0, sizeof(int), s));
+        }
+        set_error("search_topk: survivor lists keep overflowing (more than %d rows tie at the k-th score?)", CAP);
+        return -4;
+    }
     PF_HIP(hipMemsetAsync(ws.overflow, 0, sizeof(int), s));
     const float *thr = nullptr;
     for (int lev = levels; lev >= 1; --lev) {
@@ -566,7 +552,7 @@ int topk_merge(const float *S, const int64_t *L, int64_t nq, int m, int k, float
         attr_set = true;
     }
     ProfScope ps("topk_merge", s);
-    hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(1024), (size_t)P * 8, s, S, L, m, k, D, I);
+    PF_LAUNCH(merge_kernel, dim3((unsigned)nq), dim3(1024), (size_t)P * 8, s, S, L, m, k, D, I);
     PF_HIP(hipGetLastError());
     return 0;
 }

@@ -1,0 +1,371 @@
+// fp16 pre-filter for the batched exact top-k (gfx950).
+//
+// With thousands of query rows per pass the exact-fp32 scan is bound by the fp32 MFMA rate
+// (1/16 of the fp16 rate).  This path keeps the RESULT exact while moving the O(Q*N*d) work to
+// v_mfma_f32_32x32x16_f16:
+//
+//   1. db rows and query rows are rounded to fp16 once (db at load, queries per call);
+//      s16 = sum fl16(q_i) * fl16(x_i) with exact products and fp32 accumulation;
+//   2. |s16 - s| <= eps_m := 1.05e-3 * ||q_m|| * max_n ||x_n|| + 1e-6   (2 * 2^-11 relative per
+//      product from the two roundings, subnormal and accumulation terms included, Cauchy-Schwarz);
+//   3. the scan emits row n for query m iff  s16 >= tau_m - eps_m,  tau_m being a lower bound of
+//      the query's k-th best EXACT score (from the sampled levels, as in search.hip): every row
+//      of the true top-k survives;
+//   4. the select kernel sorts the survivors by s16, re-scores in exact fp32 only those with
+//      s16 >= (k-th best s16) - 2 eps  (k rows have s16 >= a, hence exact >= a - eps, so the true
+//      k-th best is >= a - eps and every true top-k row has s16 >= a - 2 eps), sorts that handful
+//      by exact score and emits the top k.  Thresholds handed to the next level are exact scores.
+//
+// The answer is the exact fp32 top-k; only the arithmetic that cannot change it runs in fp16.
+// Reference precedent for fp16 search: faiss GpuMultipleClonerOptions.useFloat16
+// (database.py:102-104), there without re-scoring, i.e. approximate.
+#include "search_common.h"
+
+namespace pfann {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// ---------------------------------------------------------------------------- conversions
+__global__ void rows_to_half_kernel(const float *__restrict__ x, int64_t n, int d, _Float16 *__restrict__ xh,
+                                    float *norm_max) {
+    // one wave per row: convert, and fold the row's L2 norm into a global max (non-negative
+    // floats order like their bit patterns)
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float ss = 0.f;
+    for (int e = lane; e < d; e += 64) {
+        const float v = x[row * d + e];
+        xh[row * d + e] = (_Float16)v;
+        ss = fmaf(v, v, ss);
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(norm_max), __float_as_uint(sqrtf(ss)));
+}
+
+int launch_rows_to_half(const float *x, int64_t n, int d, void *xh, float *norm_max_dev, hipStream_t s) {
+    if (n <= 0) return 0;
+    PF_LAUNCH(rows_to_half_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, s, x, n, d,
+                       reinterpret_cast<_Float16 *>(xh), norm_max_dev);
+    PF_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void q_prep_kernel(const float *__restrict__ q, int64_t nq, int d, float xnorm_max,
+                              _Float16 *__restrict__ qh, float *__restrict__ eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= nq) return;
+    float ss = 0.f;
+    for (int e = lane; e < d; e += 64) {
+        const float v = q[row * d + e];
+        qh[row * d + e] = (_Float16)v;
+        ss = fmaf(v, v, ss);
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) eps[row] = 1.05e-3f * sqrtf(ss) * xnorm_max + 1e-6f;
+}
+
+int launch_q_prep(const float *q, int64_t nq, int d, float xnorm_max, void *qh, float *eps, hipStream_t s) {
+    PF_LAUNCH(q_prep_kernel, dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, s, q, nq, d, xnorm_max,
+                       reinterpret_cast<_Float16 *>(qh), eps);
+    PF_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// fp16 scan: same tiling/pipeline as scan_emit_kernel<128,128,64,64,QT> (search.hip) with the
+// operands stored as halves: a 128-byte K-tile holds 64 k (vs 32 floats), the 16-byte fragment a
+// lane reads feeds ONE v_mfma_f32_32x32x16_f16 (lane half h holds k = 8h..8h+7 of the 16-step).
+// p.q / p.db point to fp16 rows, p.thr holds tau - eps (or nullptr on the dense top level).
+// ------------------------------------------------------------------------------------
+template <int QT>
+__global__ __launch_bounds__(256, 2) void scan_f16_kernel(ScanParams p) {
+    constexpr int BM = 128, BN = 128, WM = 64, WN = 64;
+    constexpr int LDK = 36;                   // LDS row pitch in dwords (128 B of k + 16 B pad)
+    constexpr int WAVES_N = BN / WN, TM = WM / 32, TN = WN / 32, AR = BM / 32, BR = BN / 32;
+    __shared__ __attribute__((aligned(16))) float As[2 * BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BN * LDK];
+    __shared__ __attribute__((aligned(16))) float thr_s[QT * BM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int n_mg = (p.n_tiles_m + QT - 1) / QT;
+    const int nt = L / n_mg, mg = L - nt * n_mg;
+    const int mt0 = mg * QT;
+    const int n_q = min(QT, p.n_tiles_m - mt0);
+    const int64_t n0 = (int64_t)nt * BN;
+    const int col4 = tid & 7, rowq = tid >> 3;
+    const unsigned row_bytes = (unsigned)p.d * 2u;             // one fp16 row
+
+    for (int i = tid; i < QT * BM; i += 256) {
+        const int64_t m = (int64_t)mt0 * BM + i;
+        thr_s[i] = (p.thr != nullptr && m < p.nq) ? p.thr[m] : -INFINITY;
+    }
+    const char *qb = reinterpret_cast<const char *>(p.q), *dbb = reinterpret_cast<const char *>(p.db);
+    const int64_t mq0 = (int64_t)mt0 * BM;
+    const __amdgpu_buffer_rsrc_t srd_q = make_srd(qb + mq0 * row_bytes, (unsigned long long)(p.nq - mq0) * row_bytes);
+    const int64_t row0 = n0 * p.row_stride;
+    const int64_t rows_left = (p.nrows - n0 - 1) * p.row_stride + 1;
+    const __amdgpu_buffer_rsrc_t srd_db = make_srd(dbb + row0 * row_bytes, (unsigned long long)rows_left * row_bytes);
+    unsigned doff[BR];
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+        const int64_t rl = rowq + 32 * j;
+        const unsigned long long off = (unsigned long long)rl * p.row_stride * row_bytes;
+        doff[j] = (n0 + rl < p.nrows && off < 0x7FFF0000ull) ? (unsigned)off : BUF_OOB;
+    }
+    f32x4 ra[AR], rb[BR];
+    const int q_rows_left = (int)((p.nq - mq0) < (int64_t)QT * BM ? (p.nq - mq0) : (int64_t)QT * BM);
+    const unsigned tile_bytes = (unsigned)BM * row_bytes;
+    unsigned aoff[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) aoff[i] = (unsigned)(rowq + 32 * i) * row_bytes;
+    unsigned lkb = (unsigned)col4 * 16u;     // byte offset of this thread's 16-byte piece inside the row
+    int lrow = rowq;
+    unsigned lbase = 0;
+    auto load_tile = [&]() {
+        const bool kok = lkb < row_bytes;
+#pragma unroll
+        for (int i = 0; i < AR; ++i)
+            ra[i] = buf_load4(srd_q, (kok && lrow + 32 * i < q_rows_left) ? lbase + aoff[i] + lkb : BUF_OOB);
+#pragma unroll
+        for (int j = 0; j < BR; ++j) rb[j] = buf_load4(srd_db, kok ? doff[j] + lkb : BUF_OOB);
+        lkb += 128u;
+        const bool wrap = lkb >= row_bytes;
+        lkb = wrap ? (unsigned)col4 * 16u : lkb;
+        lrow += wrap ? BM : 0;
+        lbase += wrap ? tile_bytes : 0u;
+    };
+    auto store_tile = [&](float *Ad, float *Bd) {
+#pragma unroll
+        for (int i = 0; i < AR; ++i)
+            *reinterpret_cast<f32x4 *>(&Ad[(rowq + 32 * i) * LDK + col4 * 4]) = ra[i];
+#pragma unroll
+        for (int j = 0; j < BR; ++j)
+            *reinterpret_cast<f32x4 *>(&Bd[(rowq + 32 * j) * LDK + col4 * 4]) = rb[j];
+    };
+
+    const int nk = (int)((row_bytes + 127u) / 128u);
+    load_tile();
+    store_tile(As, Bs);
+    __syncthreads();
+    const int l31 = lane & 31, lhalf = lane >> 5;
+    int it = 0;
+#pragma unroll 1
+    for (int q = 0; q < n_q; ++q) {
+        const int64_t m0 = mq0 + (int64_t)q * BM;
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll 1
+        for (int kt = 0; kt < nk; ++kt, ++it) {
+            const float *Ac = As + (it & 1) * (BM * LDK), *Bc = Bs + (it & 1) * (BN * LDK);
+            float *An = As + ((it + 1) & 1) * (BM * LDK), *Bn = Bs + ((it + 1) & 1) * (BN * LDK);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {          // 4 MFMA steps of 16 k per 128-byte K-tile
+                f16x8 a8[TM], b8[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    a8[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(
+                                                          &Ac[(wm * WM + i * 32 + l31) * LDK + kk * 8 + lhalf * 4]));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    b8[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(
+                                                          &Bc[(wn * WN + j * 32 + l31) * LDK + kk * 8 + lhalf * 4]));
+                if (kk == 0) {
+                    load_tile();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (kk == 3) store_tile(An, Bn);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8[i], b8[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+        const float *thr_c = thr_s + q * BM;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int64_t n = n0 + wn * WN + j * 32 + l31;
+            const bool nok = n < p.nrows;
+            const unsigned row = (unsigned)(n * p.row_stride);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (p.thr == nullptr) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                        if (nok && m < p.nq) p.keys[m * CAP + n] = pack_key(acc[i][j][r], row);
+                    }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int mlg = wm * WM + i * 32 + 8 * g + 4 * lhalf;
+                        const f32x4 th = *reinterpret_cast<const f32x4 *>(thr_c + mlg);
+                        bool sv[4];
+                        bool any = false;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            sv[e] = nok && (m0 + mlg + e) < p.nq && acc[i][j][4 * g + e] >= th[e];
+                            any |= sv[e];
+                        }
+                        if (__any(any)) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if (sv[e]) {
+                                    const int64_t m = m0 + mlg + e;
+                                    const int pos = atomicAdd(&p.cnt[m], 1);
+                                    if (pos < CAP) p.keys[m * CAP + pos] = pack_key(acc[i][j][4 * g + e], row);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__global__ void fill_int2_kernel(int *p, int v, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+int launch_scan_f16(const void *dbh, int64_t n, int d, int64_t stride, const void *qh, int64_t nq,
+                    const float *thr_adj, SearchWorkspace &ws, hipStream_t s) {
+    ScanParams p;
+    p.q = reinterpret_cast<const float *>(qh);
+    p.db = reinterpret_cast<const float *>(dbh);
+    p.nq = nq; p.d = d;
+    p.row_stride = stride;
+    p.nrows = (n + stride - 1) / stride;
+    p.thr = thr_adj; p.cnt = ws.cnt; p.keys = reinterpret_cast<unsigned long long *>(ws.cl);
+    p.nsub = 1;
+    if (thr_adj == nullptr) {
+        if (p.nrows > CAP) { set_error("scan: dense level with %lld rows > %d", (long long)p.nrows, CAP); return -1; }
+        PF_LAUNCH(fill_int2_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, s, ws.cnt, (int)p.nrows, nq);
+    } else {
+        PF_HIP(hipMemsetAsync(ws.cnt, 0, sizeof(int) * nq, s));
+    }
+    ProfScope ps(stride == 1 ? "scan_topk_f16" : "scan_topk_f16_sample", s, 2.0 * (double)nq * p.nrows * d);
+    p.n_tiles_m = cdiv(nq, 128);
+    const int64_t db_tiles = cdiv(p.nrows, 128);
+    if (db_tiles * cdiv(p.n_tiles_m, 4) >= 4096)
+        PF_LAUNCH((scan_f16_kernel<4>), dim3((unsigned)(db_tiles * cdiv(p.n_tiles_m, 4))), dim3(256), 0, s, p);
+    else
+        PF_LAUNCH((scan_f16_kernel<1>), dim3((unsigned)(db_tiles * p.n_tiles_m)), dim3(256), 0, s, p);
+    PF_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// Select with exact re-scoring (step 4 above).  One 1024-thread workgroup per query row.
+//   mode 0: thr[m] = exact k-th best (or -inf), thr_adj[m] = thr[m] - eps[m]
+//   mode 1: D, I = exact top-k;  list overflow -> overflow flag (+ raised thresholds)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void select_rescore_kernel(const unsigned long long *__restrict__ keys,
+                                                              const int *__restrict__ cnt, int k, int mode,
+                                                              float *__restrict__ thr, float *__restrict__ thr_adj,
+                                                              const float *__restrict__ eps, float *__restrict__ D,
+                                                              int64_t *__restrict__ I, int64_t label_base,
+                                                              int *overflow, const float *__restrict__ q32,
+                                                              const float *__restrict__ db32, int d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
+    __shared__ int s_n2;
+    const int64_t m = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int n = cnt[m];
+    const bool over = n > CAP;
+    if (over) {
+        if (mode == 1 && tid == 0) atomicExch(overflow, 1);
+        n = CAP;
+    }
+    int P = 1;
+    while (P < n) P <<= 1;
+    for (int i = tid; i < P; i += 1024) skeys[i] = i < n ? keys[m * CAP + i] : ~0ull;
+    __syncthreads();
+    bitonic_sort_u64(skeys, P, tid, 1024);          // by approximate score, descending
+    // candidates that can still belong to the exact top-k
+    const float e2 = 2.0f * eps[m];
+    if (tid == 0) {
+        int n2 = n;
+        if (n > k) {
+            const float cut = ord2f(~(unsigned)(skeys[k - 1] >> 32)) - e2;
+            int lo = k, hi = n;                   // first index whose score < cut
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (ord2f(~(unsigned)(skeys[mid] >> 32)) >= cut) lo = mid + 1; else hi = mid;
+            }
+            n2 = lo;
+        }
+        s_n2 = n2;
+    }
+    __syncthreads();
+    const int n2 = s_n2;
+    // exact fp32 scores: one wave per candidate, coalesced row reads, fixed reduction order
+    const float *qv = q32 + m * d;
+    for (int c = wave; c < n2; c += 16) {
+        const unsigned row = (unsigned)(skeys[c] & 0xFFFFFFFFull);
+        const float *xv = db32 + (int64_t)row * d;
+        float part = 0.f;
+        for (int e = lane; e < d; e += 64) part = fmaf(xv[e], qv[e], part);
+        part = wave_sum(part);
+        if (lane == 0) skeys[c] = pack_key(part, row);
+    }
+    __syncthreads();
+    int P2 = 1;
+    while (P2 < n2) P2 <<= 1;
+    for (int i = n2 + tid; i < P2; i += 1024) skeys[i] = ~0ull;     // entries beyond n2 can no longer matter
+    __syncthreads();
+    bitonic_sort_u64(skeys, P2, tid, 1024);         // by exact score, descending
+    if (mode == 0) {
+        if (tid == 0) {
+            const float t = n2 >= k ? ord2f(~(unsigned)(skeys[k - 1] >> 32)) : -INFINITY;
+            thr[m] = t;
+            thr_adj[m] = t - eps[m];
+        }
+    } else {
+        for (int i = tid; i < k; i += 1024) {
+            if (i < n2) {
+                const unsigned long long key = skeys[i];
+                D[m * k + i] = ord2f(~(unsigned)(key >> 32));
+                I[m * k + i] = (int64_t)(unsigned)(key & 0xFFFFFFFFu) + label_base;
+            } else {
+                D[m * k + i] = -3.4028234663852886e38f;
+                I[m * k + i] = -1;
+            }
+        }
+        if (over && tid == 0 && n2 >= k) {          // raised threshold for the rescan
+            const float t = ord2f(~(unsigned)(skeys[k - 1] >> 32));
+            thr[m] = t;
+            thr_adj[m] = t - eps[m];
+        }
+    }
+}
+
+int launch_select_rescore(SearchWorkspace &ws, int64_t nq, int k, int mode, float *D, int64_t *I, int64_t label_base,
+                          const float *q32, const float *db32, int d, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        PF_HIP(hipFuncSetAttribute((const void *)select_rescore_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   CAP * 8));
+        attr_set = true;
+    }
+    ProfScope ps("topk_select_rescore", s);
+    PF_LAUNCH(select_rescore_kernel, dim3((unsigned)nq), dim3(1024), CAP * 8, s,
+                       reinterpret_cast<const unsigned long long *>(ws.cl), ws.cnt, k, mode, ws.thr, ws.thr_adj, ws.eps, D,
+                       I, label_base, ws.overflow, q32, db32, d);
+    PF_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace pfann

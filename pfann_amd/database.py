@@ -61,6 +61,10 @@ class DeviceIndex:
         self.ntotal = n
         self.label_base = label_base
 
+    def set_prefilter(self, on=True):
+        """fp16 pre-filter of the batched scan (exact result either way) -> True if in use."""
+        return bool(self.lib.pfann_db_set_prefilter(self.handle, 1 if on else 0))
+
     def _stream(self):
         return _l.current_stream_ptr(self.device)
 

@@ -193,13 +193,14 @@ def test_missing_weights_fail_loudly(torch_cuda):
 
 
 # -------------------------------------------------------------------------------- search
-def _check_topk(torch, db, q, k):
+def _check_topk(torch, db, q, k, prefilter=True):
     from oracle import search as osr
     from pfann_amd.database import DeviceIndex
     d = q.shape[1]
     idx = DeviceIndex(d, 0)
     pos = np.array([0, db.shape[0]], np.int64)
     idx.load(db, pos, 0)
+    idx.set_prefilter(prefilter)        # fp16 pre-filter + exact re-scoring vs all-fp32 scan: same answer
     D, I = idx.search(torch.as_tensor(q).cuda(), k)
     D, I = D.cpu().numpy(), I.cpu().numpy()
     Dr, Ir = osr.flat_ip_topk(q, db, k)
@@ -228,13 +229,14 @@ def _check_topk(torch, db, q, k):
     (0, 128, 3, 10), (7, 128, 19, 100), (5000, 128, 19, 100), (8192, 64, 5, 1), (8193, 16, 33, 20),
     (100000, 128, 19, 100), (300000, 128, 130, 100), (140000, 128, 64, 300), (200000, 64, 40, 1000),
 ])
-def test_search_topk_exact(torch_cuda, n, d, nq, k):
+@pytest.mark.parametrize("prefilter", [True, False])
+def test_search_topk_exact(torch_cuda, n, d, nq, k, prefilter):
     db = synth.unit_rows(11, "t/db%d" % n, max(n, 1), d)[:n]
     q = synth.unit_rows(12, "t/q%d" % n, nq, d)
     if n > 100:                      # plant near-duplicates of db rows so real matches exist
         q[::3] = db[(np.arange(0, nq, 3) * 7919) % n] * 0.8 + 0.2 * q[::3]
         q /= np.linalg.norm(q, axis=1, keepdims=True)
-    _check_topk(torch_cuda, db, q.astype(np.float32), k)
+    _check_topk(torch_cuda, db, q.astype(np.float32), k, prefilter)
 
 
 def test_search_topk_clustered_and_duplicate_rows(torch_cuda):
@@ -248,6 +250,30 @@ def test_search_topk_clustered_and_duplicate_rows(torch_cuda):
     base /= np.linalg.norm(base, axis=1, keepdims=True)
     q = np.concatenate([c, base[70000:70001], synth.unit_rows(23, "t/q", 17, d)]).astype(np.float32)
     _check_topk(torch_cuda, base.astype(np.float32), q, 100)
+    # batched (fp16 pre-filter) form of the same, both ways
+    qb = np.concatenate([q, synth.unit_rows(24, "t/qb", 120, d)]).astype(np.float32)
+    _check_topk(torch_cuda, base.astype(np.float32), qb, 100, True)
+    _check_topk(torch_cuda, base.astype(np.float32), qb, 100, False)
+
+
+def test_search_prefilter_near_ties_stay_exact(torch_cuda):
+    """Adversarial for the fp16 pre-filter: thousands of rows whose exact scores differ by ~1e-6
+    (far below fp16 resolution, 1e-3) around the k-th best.  The re-scoring window (2 eps below
+    the k-th best approximate score) must hand the exact fp32 order to the final sort."""
+    d, n, nq = 128, 60000, 96
+    base = synth.unit_rows(31, "t/tie", n, d).astype(np.float64)
+    c = synth.unit_rows(32, "t/tiec", 1, d).astype(np.float64)[0]
+    for lo, cnt, amp in ((1000, 3000, 0.02), (20000, 500, 0.002)):
+        base[lo:lo + cnt] = c + amp * base[lo:lo + cnt]
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    q = synth.unit_rows(33, "t/tieq", nq, d).astype(np.float64)
+    q[:40] = c + 0.05 * q[:40]
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    D, I = _check_topk(torch_cuda, base.astype(np.float32), q.astype(np.float32), 100, True)
+    # the interesting rows really are inside the fp16 ambiguity: k-th and (k+50)-th exact scores
+    s = np.sort((q[:1].astype(np.float32) @ base.astype(np.float32).T)[0])[::-1]
+    assert s[99] - s[149] < 1e-3
+
 
 
 def test_topk_merge(torch_cuda):
