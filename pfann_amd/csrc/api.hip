@@ -67,6 +67,9 @@ struct pfann_ctx {
     int64_t buf_elems[2] = {0, 0};  // per sample
     float *mel_buf = nullptr;
     double *scratch = nullptr;
+    std::vector<float> w1_host, b1_host;   // first conv [3][co] / [co] (Gram-form LayerNorm statistics)
+    float gram[14] = {};
+    bool gram_ready = false;
     bool fused = false;             // LayerNorm fused into the GEMMs (encoder_fused.hip)
     int n_streams = 1;              // sub-batches run on this many internal streams (MFMA-bound GEMMs of one
                                     // sub-batch overlap the HBM-bound LayerNorm passes of another)
@@ -243,6 +246,7 @@ int pfann_load_weight(pfann_ctx *c, const char *name, const float *host, int64_t
             if (!is_w) {
                 if (numel != L.co) { set_error("%s: numel %lld != %d", name, (long long)numel, L.co); return -3; }
                 if (upload(&L.bias, host, numel)) return -1;
+                if (blk == 0 && !second) { c->b1_host.assign(host, host + numel); c->gram_ready = false; }
             } else {
                 const int ci = L.depthwise ? 1 : L.ci;
                 if (numel != (int64_t)L.co * ci * 3) { set_error("%s: numel %lld != %lld", name, (long long)numel, (long long)L.co * ci * 3); return -3; }
@@ -257,6 +261,7 @@ int pfann_load_weight(pfann_ctx *c, const char *name, const float *host, int64_t
                                 w[((size_t)o * 3 + t) * ci + i] = host[((size_t)o * ci + i) * 3 + t];
                 }
                 if (upload(&L.w, w.data(), numel)) return -1;
+                if (blk == 0 && !second) { c->w1_host = w; c->gram_ready = false; }
             }
         } else if (strncmp(mod, "ln", 2) == 0) {
             const int64_t hw = (int64_t)L.Fo * L.To;
@@ -329,17 +334,46 @@ static int keep_tap_fused(pfann_ctx *c, int idx, const float *z, const float *pa
     return launch_ln_apply(L, z, part, P, c->dbg[idx], nb, c->cfg.activation, c->cfg.relu_after_bn, s);
 }
 
+// Gram form of the first conv's LayerNorm statistics (see conv_first_gram_stats_kernel), in fp64
+static void build_gram(pfann_ctx *c) {
+    const int co = c->sub[0].co;
+    const std::vector<float> &w = c->w1_host, &b = c->b1_host;      // w: [3][co]
+    double Bsum = 0, Ws[3] = {0, 0, 0}, bb = 0, h[3] = {0, 0, 0}, G[3][3] = {};
+    for (int o = 0; o < co; ++o) {
+        Bsum += b[o];
+        bb += (double)b[o] * b[o];
+        for (int t = 0; t < 3; ++t) {
+            Ws[t] += w[t * co + o];
+            h[t] += (double)b[o] * w[t * co + o];
+            for (int u = 0; u < 3; ++u) G[t][u] += (double)w[t * co + o] * w[u * co + o];
+        }
+    }
+    const double v[14] = {Bsum, Ws[0], Ws[1], Ws[2], bb, h[0], h[1], h[2], G[0][0], G[0][1], G[0][2], G[1][1], G[1][2], G[2][2]};
+    for (int i = 0; i < 14; ++i) c->gram[i] = (float)v[i];
+    c->gram_ready = true;
+}
+
 static int encode_chunk_fused(pfann_ctx *c, const float *mel, int64_t B, float *emb, int normalize, hipStream_t s,
                               int64_t slot0) {
     const pfann_config &g = c->cfg;
     float *buf[2] = {c->buf[0] + slot0 * c->buf_elems[0], c->buf[1] + slot0 * c->buf_elems[1]};
     float *part[2] = {c->part[0] + slot0 * c->part_slots * 2, c->part[1] + slot0 * c->part_slots * 2};
-    if (launch_conv_first_stats(c->sub[0], mel, buf[0], part[0], B, g.activation, g.relu_after_bn, s)) return -1;
+    // Sub-layer 0 (C_in = 1 conv): normally only its LayerNorm statistics are computed here and the
+    // conv itself is folded into sub-layer 1's A-loader; the 2 MiB/segment tensor is materialised
+    // only when verification taps are requested.
+    const bool fold_first = !c->keep && c->sub[1].axis == 1 && c->sub[0].stride * 1 > 0 && getenv("PFANN_NO_FOLD_FIRST") == nullptr;
+    if (fold_first && g.relu_after_bn && (int)c->w1_host.size() == 3 * c->sub[0].co && (int)c->b1_host.size() == c->sub[0].co) {
+        if (!c->gram_ready) build_gram(c);
+        if (launch_conv_first_gram_stats(c->sub[0], mel, part[0], B, c->gram, s)) return -1;
+    } else if (launch_conv_first_stats(c->sub[0], mel, fold_first ? nullptr : buf[0], part[0], B, g.activation, g.relu_after_bn, s)) {
+        return -1;
+    }
     int P = fused_out_slots(c->sub[0], B);
     if (c->keep && keep_tap_fused(c, 0, buf[0], part[0], P, B, s)) return -1;
     for (int i = 1; i < 16; ++i) {
-        if (launch_conv_gemm_ln(c->sub[i], c->sub[i - 1], buf[(i - 1) & 1], part[(i - 1) & 1], P, buf[i & 1],
-                                part[i & 1], B, g.activation, g.relu_after_bn, s)) return -1;
+        const bool first = fold_first && i == 1;
+        if (launch_conv_gemm_ln(c->sub[i], c->sub[i - 1], first ? mel : buf[(i - 1) & 1], part[(i - 1) & 1], P, buf[i & 1],
+                                part[i & 1], B, g.activation, g.relu_after_bn, first ? &c->sub[0] : nullptr, s)) return -1;
         P = fused_out_slots(c->sub[i], B);
         if (c->keep && keep_tap_fused(c, i, buf[i & 1], part[i & 1], P, B, s)) return -1;
     }

@@ -79,6 +79,9 @@ __device__ __forceinline__ f32x4_t buf_load4(__amdgpu_buffer_rsrc_t r, unsigned 
     return __builtin_bit_cast(f32x4_t, v);
 }
 
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
 __device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)byte_off, 0, 0);
 }

@@ -44,12 +44,18 @@ struct FusedGemmParams {
     float *out_part; int out_P;
     int act, after_bn;
     int64_t n_samples;
-    int dbg;                     // timing ablations only (PFANN_DBG): 1 = no W/B loads, 2 = no LN math
+    // FIRST variant: the input is the C_in = 1 first conv computed on the fly from the log-mel
+    const float *w1, *b1;        // first conv weights [3][Ci] and bias [Ci]
+    int T0, s1, pad1;            // mel frames, first conv stride and left pad along T
 };
 
 // RELU_BN = true: the default model (ReLU applied after LayerNorm) with the activation folded
 // into straight-line code; false: generic (ELU and/or activation before LayerNorm).
-template <int BM, int BN, int WM, int WN, bool RELU_BN>
+// FIRST = true: sub-layer 1 with sub-layer 0 (the C_in = 1 conv, model.py:20 with i = 1) folded into
+// the A-loader: z1 = b1 + sum_tap1 w1[tap1] * mel[f][2t + tap1] is recomputed per element (3 FMAs, same
+// order as conv_first_stats_kernel, so bit-identical) instead of streaming the 2 MiB/segment
+// tensor through HBM; p.x is then the log-mel batch [B][F][T0].
+template <int BM, int BN, int WM, int WN, bool RELU_BN, bool FIRST = false>
 __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_ln_kernel(FusedGemmParams p) {
     constexpr int BK = 32, LDK = BK + 4;
     constexpr int WAVES_N = BN / WN;
@@ -125,12 +131,15 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_ln_kerne
     const int col4 = tid & 7, rowq = tid >> 3;
     // bounds-checked buffer loads (OOB lanes read 0): activation window from the first sample of
     // the tile, LayerNorm affine tensors addressed sample-relative, weights by output channel
+    const int64_t x_elems = FIRST ? (int64_t)p.F * p.T0 : p.in_elems;       // per-sample size of p.x
     const __amdgpu_buffer_rsrc_t srd_a =
-        make_srd(p.x + b_first * p.in_elems, (unsigned long long)(p.n_samples - b_first) * p.in_elems * 4ull);
+        make_srd(p.x + b_first * x_elems, (unsigned long long)(p.n_samples - b_first) * x_elems * 4ull);
+    const __amdgpu_buffer_rsrc_t srd_w1 = make_srd(p.w1, FIRST ? (unsigned long long)3 * p.Ci * 4ull : 0ull);
+    const __amdgpu_buffer_rsrc_t srd_b1 = make_srd(p.b1, FIRST ? (unsigned long long)p.Ci * 4ull : 0ull);
     const __amdgpu_buffer_rsrc_t srd_w = make_srd(p.ln_w, (unsigned long long)p.in_elems * 4ull);
     const __amdgpu_buffer_rsrc_t srd_lb = make_srd(p.ln_b, (unsigned long long)p.in_elems * 4ull);
     const __amdgpu_buffer_rsrc_t srd_b = make_srd(p.w, (unsigned long long)p.N * p.K * 4ull);
-    int aoff[AR], arel[AR], ap0[AR];
+    int aoff[AR], arel[AR], ap0[AR], atq[AR];
     float amu[AR], ars[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
@@ -145,11 +154,15 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_ln_kerne
             const int sl = (int)(b - b_first);
             arel[i] = rel;
             aoff[i] = sl * (int)p.in_elems + rel;
+            if (FIRST) {   // mel element of tap2 = 0, tap1 = 0:  ((b*F + f_in) * T0 + to*s1 - pad1)
+                atq[i] = to * p.s1 - p.pad1;
+                aoff[i] = (sl * p.F + ap0[i]) * p.T0 + atq[i];
+            }
             amu[i] = s_mu[sl];
             ars[i] = s_rs[sl];
         } else {
             ap0[i] = -(1 << 20);
-            aoff[i] = 0; arel[i] = 0; amu[i] = 0.f; ars[i] = 0.f;
+            aoff[i] = 0; arel[i] = 0; amu[i] = 0.f; ars[i] = 0.f; atq[i] = 0;
         }
     }
     unsigned boff[BR];
@@ -163,6 +176,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_ln_kerne
     const int tap_stride = (int)p.tap_stride;
 
     f32x4 ra[AR], rw[AR], rbb[AR], rb[BR];
+    f32x4 w1v[3], b1v;
     unsigned okmask = 0;
     auto load_tile = [&]() {
         const bool kok = kap < p.k_end;
@@ -172,11 +186,22 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_ln_kerne
         for (int i = 0; i < AR; ++i) {
             const bool ok = kok && (unsigned)(ap0[i] + tap) < (unsigned)p.in_len;
             okmask |= ok ? (1u << i) : 0u;
-            ra[i] = buf_load4(srd_a, ok ? (unsigned)(aoff[i] + toff) * 4u : BUF_OOB);
-            if (!(p.dbg & 1)) {
-                rw[i] = buf_load4(srd_w, ok ? (unsigned)(arel[i] + toff) * 4u : BUF_OOB);
-                rbb[i] = buf_load4(srd_lb, ok ? (unsigned)(arel[i] + toff) * 4u : BUF_OOB);
-            } else { rw[i] = f32x4{1.f, 1.f, 1.f, 1.f}; rbb[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            if (FIRST) {
+                // three neighbouring log-mel frames of input row f_in = ap0 + tap (tap = tap2)
+#pragma unroll
+                for (int t1 = 0; t1 < 3; ++t1)
+                    ra[i][t1] = buf_load1(srd_a, (ok && (unsigned)(atq[i] + t1) < (unsigned)p.T0)
+                                                     ? (unsigned)(aoff[i] + tap * p.T0 + t1) * 4u : BUF_OOB);
+            } else {
+                ra[i] = buf_load4(srd_a, ok ? (unsigned)(aoff[i] + toff) * 4u : BUF_OOB);
+            }
+            rw[i] = buf_load4(srd_w, ok ? (unsigned)(arel[i] + toff) * 4u : BUF_OOB);
+            rbb[i] = buf_load4(srd_lb, ok ? (unsigned)(arel[i] + toff) * 4u : BUF_OOB);
+        }
+        if (FIRST) {
+#pragma unroll
+            for (int t1 = 0; t1 < 3; ++t1) w1v[t1] = buf_load4(srd_w1, kok ? (unsigned)(t1 * p.Ci + c) * 4u : BUF_OOB);
+            b1v = buf_load4(srd_b1, kok ? (unsigned)c * 4u : BUF_OOB);
         }
 #pragma unroll
         for (int j = 0; j < BR; ++j) rb[j] = buf_load4(srd_b, kok ? boff[j] + (unsigned)kap * 4u : BUF_OOB);
@@ -193,7 +218,14 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_ln_kerne
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float t = (p.dbg & 2) ? ra[i][e] : (ra[i][e] - amu[i]) * ars[i] * rw[i][e] + rbb[i][e];
+                float z = ra[i][e];
+                if (FIRST) {   // same FMA order as conv_first_stats_kernel: bias, then taps 0, 1, 2
+                    z = b1v[e];
+#pragma unroll
+                    for (int t1 = 0; t1 < 3; ++t1) z += ra[i][t1] * w1v[t1][e];
+                }
+                if (FIRST && !RELU_BN && !p.after_bn) z = act_fn(z, p.act);   // PRE of sub-layer 0
+                float t = (z - amu[i]) * ars[i] * rw[i][e] + rbb[i][e];
                 if (RELU_BN) t = fmaxf(t, 0.f);
                 else t = p.after_bn ? act_fn(t, p.act) : t;
                 v[e] = ok ? t : 0.f;
@@ -366,8 +398,10 @@ bool fused_supported(const SubLayer *sub, int n) {
     return true;
 }
 
+// Lfirst != nullptr: x is the log-mel batch and Lfirst (= Lin, the C_in = 1 conv) is folded into the A-loader
 int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, const float *in_part, int in_P,
-                        float *y, float *out_part, int64_t B, int act, int after_bn, hipStream_t s) {
+                        float *y, float *out_part, int64_t B, int act, int after_bn, const SubLayer *Lfirst,
+                        hipStream_t s) {
     FusedGemmParams p;
     p.x = x; p.w = L.w; p.bias = L.bias; p.y = y;
     p.rows_per_sample = L.Fo * L.To;
@@ -385,7 +419,11 @@ int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, 
     p.out_part = out_part; p.out_P = fused_out_slots(L, B);
     p.act = act; p.after_bn = after_bn;
     p.n_samples = B;
-    p.dbg = getenv("PFANN_DBG") ? atoi(getenv("PFANN_DBG")) : 0;
+    p.w1 = nullptr; p.b1 = nullptr; p.T0 = 0; p.s1 = 1; p.pad1 = 0;
+    if (Lfirst != nullptr) {
+        p.w1 = Lfirst->w; p.b1 = Lfirst->bias;
+        p.T0 = Lfirst->T; p.s1 = Lfirst->stride; p.pad1 = Lfirst->pad_lo;
+    }
     const double flops = 2.0 * (double)p.M * p.N * (p.k_end - p.k_begin);
     if (gemm_tile(L, B) == 128) {
         p.n_tiles_n = cdiv(p.N, 128);
@@ -393,7 +431,11 @@ int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, 
         ProfScope ps("conv_gemm_ln_128", s, flops);
         // 8 waves (512 threads), each a 64x32 tile: half the prefetch registers per thread and four
         // waves per SIMD with two resident blocks
-        if (act == 0 && after_bn)
+        if (Lfirst != nullptr && act == 0 && after_bn)
+            PF_LAUNCH((conv_gemm_ln_kernel<128, 128, 64, 32, true, true>), dim3((unsigned)blocks), dim3(512), 0, s, p);
+        else if (Lfirst != nullptr)
+            PF_LAUNCH((conv_gemm_ln_kernel<128, 128, 64, 32, false, true>), dim3((unsigned)blocks), dim3(512), 0, s, p);
+        else if (act == 0 && after_bn)
             PF_LAUNCH((conv_gemm_ln_kernel<128, 128, 64, 32, true>), dim3((unsigned)blocks), dim3(512), 0, s, p);
         else
             PF_LAUNCH((conv_gemm_ln_kernel<128, 128, 64, 32, false>), dim3((unsigned)blocks), dim3(512), 0, s, p);
@@ -401,7 +443,11 @@ int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, 
         p.n_tiles_n = cdiv(p.N, 64);
         const int64_t blocks = (int64_t)cdiv(p.M, 64) * p.n_tiles_n;
         ProfScope ps("conv_gemm_ln_64", s, flops);
-        if (act == 0 && after_bn)
+        if (Lfirst != nullptr && act == 0 && after_bn)
+            PF_LAUNCH((conv_gemm_ln_kernel<64, 64, 32, 32, true, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        else if (Lfirst != nullptr)
+            PF_LAUNCH((conv_gemm_ln_kernel<64, 64, 32, 32, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        else if (act == 0 && after_bn)
             PF_LAUNCH((conv_gemm_ln_kernel<64, 64, 32, 32, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
         else
             PF_LAUNCH((conv_gemm_ln_kernel<64, 64, 32, 32, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
@@ -452,7 +498,7 @@ __global__ __launch_bounds__(256) void conv_first_stats_kernel(const float *__re
 #pragma unroll
             for (int q = 0; q < 4; ++q) o[q] = act_fn(o[q], act);
         }
-        *reinterpret_cast<f32x4 *>(ys + rl * co + c) = o;
+        if (y != nullptr) *reinterpret_cast<f32x4 *>(ys + rl * co + c) = o;
         s1 += (o[0] + o[1]) + (o[2] + o[3]);
         s2 += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
     }
@@ -471,9 +517,70 @@ int launch_conv_first_stats(const SubLayer &L, const float *x, float *y, float *
                             int after_bn, hipStream_t s) {
     const int rps = L.Fo * L.To;
     const int64_t M = B * rps;
-    ProfScope ps("conv_first_stats", s, 4.0 * ((double)M * L.co + (double)B * L.F * L.T));
+    ProfScope ps(y != nullptr ? "conv_first_stats" : "conv_first_stats_only", s,
+                 y != nullptr ? 4.0 * ((double)M * L.co + (double)B * L.F * L.T) : 4.0 * (double)B * L.F * L.T);
     PF_LAUNCH(conv_first_stats_kernel, dim3((unsigned)cdiv(M, 64)), dim3(256), 0, s, x, L.w, L.bias, y,
                        part, M, L.co, L.To, L.T, L.stride, L.pad_lo, rps, fused_out_slots(L, B), act, after_bn);
+    PF_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// LayerNorm statistics of the first conv WITHOUT computing it (PRE = identity, i.e. ReLU after
+// LayerNorm): with x = the three log-mel taps of an output position,
+//   sum_c z_c   = Bsum + sum_t Wsum[t] x_t
+//   sum_c z_c^2 = bb + 2 sum_t h[t] x_t + sum_{t,u} G[t][u] x_t x_u ,   G = W W^T (3x3), h = W b.
+// One lane per output position, one wave per 64-row partial slot: a few flops per position
+// instead of 3*Co FMAs.  gram = {Bsum, Wsum[3], bb, h[3], G00, G01, G02, G11, G12, G22}.
+// ------------------------------------------------------------------------------------
+struct GramParams { float v[14]; };
+
+__global__ __launch_bounds__(256) void conv_first_gram_stats_kernel(const float *__restrict__ x, float *__restrict__ part,
+                                                                    int64_t M, int To, int T, int stride, int pad_lo,
+                                                                    int rps, int P, GramParams g) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    float s1 = 0.f, s2 = 0.f;
+    int64_t b = 0;
+    int r = 0;
+    if (m < M) {
+        b = m / rps;
+        r = (int)(m - b * rps);
+        const int f = r / To, to = r - f * To;
+        const int F = rps / To;
+        const float *xs = x + (b * F + f) * (int64_t)T;
+        float xt[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int ti = to * stride - pad_lo + t;
+            xt[t] = (unsigned)ti < (unsigned)T ? xs[ti] : 0.f;
+        }
+        s1 = g.v[0] + g.v[1] * xt[0] + g.v[2] * xt[1] + g.v[3] * xt[2];
+        s2 = g.v[4] + 2.f * (g.v[5] * xt[0] + g.v[6] * xt[1] + g.v[7] * xt[2]) +
+             g.v[8] * xt[0] * xt[0] + g.v[11] * xt[1] * xt[1] + g.v[13] * xt[2] * xt[2] +
+             2.f * (g.v[9] * xt[0] * xt[1] + g.v[10] * xt[0] * xt[2] + g.v[12] * xt[1] * xt[2]);
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const int64_t m_wave = m - lane;                      // first row of this wave's 64-row slot
+    if (lane == 0 && m_wave < M) {
+        const int64_t bw = m_wave / rps;
+        const int slot = (int)((m_wave - bw * rps) / 64);
+        float *o = part + (bw * P + slot) * 2;
+        o[0] = s1;
+        o[1] = s2;
+    }
+}
+
+int launch_conv_first_gram_stats(const SubLayer &L, const float *x, float *part, int64_t B, const float *gram14,
+                                 hipStream_t s) {
+    const int rps = L.Fo * L.To;
+    const int64_t M = B * rps;
+    GramParams g;
+    for (int i = 0; i < 14; ++i) g.v[i] = gram14[i];
+    ProfScope ps("conv_first_gram_stats", s, 4.0 * (double)B * L.F * L.T);
+    PF_LAUNCH(conv_first_gram_stats_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, s, x, part, M, L.To, L.T,
+              L.stride, L.pad_lo, rps, fused_out_slots(L, B), g);
     PF_HIP(hipGetLastError());
     return 0;
 }
