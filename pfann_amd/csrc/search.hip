@@ -453,7 +453,10 @@ int search_topk(const float *db, const void *dbh, float xnorm_max, int64_t n, in
     const int R = k <= 128 ? 16 : (k <= 512 ? 4 : 2);
     int levels = 0;
     int64_t stride = 1;
-    while ((n + stride - 1) / stride > CAP) { stride *= R; ++levels; }
+    // the coarsest level is scanned densely and fully sorted per query row: keep it <= 4096 rows (a
+    // 1/8 shard of 1 M rows would otherwise sort 8192 keys per row); it still holds > 4096/R >= k rows
+    const int64_t DENSE_CAP = 4096;
+    while ((n + stride - 1) / stride > DENSE_CAP) { stride *= R; ++levels; }
     PF_HIP(hipMemsetAsync(ws.overflow, 0, sizeof(int), s));
     if (dbh != nullptr && nq > 64) {
         // ---- fp16 pre-filter + exact fp32 re-scoring (search_f16.hip): same levels, same exact result

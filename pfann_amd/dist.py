@@ -98,24 +98,32 @@ class ShardedIndex:
         res, _ = self.b.match(q, I, qstart, qlen, self.fsm, self.alpha, 0, True, False)
         nQ = len(qlen)
         dev = q.device
-        pack = torch.empty((nQ, 4), dtype=torch.float64, device=dev)
-        pack[:, 0] = torch.as_tensor(res["score"].copy(), device=dev)
-        pack[:, 1] = torch.as_tensor(res["song"].astype(np.float64), device=dev)
-        pack[:, 2] = torch.as_tensor(res["offset"].astype(np.float64), device=dev)
-        pack[:, 3] = torch.as_tensor(res["shift"].astype(np.float64), device=dev)
+        pack_h = np.stack([res["score"], res["song"].astype(np.float64), res["offset"].astype(np.float64),
+                           res["shift"].astype(np.float64)], axis=1)
+        pack = torch.as_tensor(pack_h).to(dev)                       # one small H2D copy
         allp = all_gather_rows(pack, self.group).cpu().numpy()     # [G, nQ, 4]
-        out = np.zeros(nQ, dtype=[("song", "<i4"), ("offset", "<i4"), ("shift", "<i4"), ("score", "<f8")])
-        for j in range(nQ):
-            best = None
-            for r in range(self.world):
-                sc, song, off, sh = allp[r, j]
-                if song < 0:
-                    continue
-                key = (-sc, sh, song, off)                        # max score, then loop order
-                if best is None or key < best[0]:
-                    best = (key, int(song), int(off), int(sh), sc)
-            if best is None:
-                out[j] = (-1, 0, 0, -np.inf)
-            else:
-                out[j] = (best[1], best[2], best[3], best[4])
-        return out
+        return pick_best(allp)
+
+
+def pick_best(allp):
+    """allp [G, nQ, 4] = per-rank (score, song, offset, shift), song < 0 = no candidate on that rank.
+    -> structured array of the winner per query: highest score, ties -> the reference's candidate
+    order (shift, song, offset) ascending (database.py:129,140,158-163)."""
+    G, nQ, _ = allp.shape
+    sc, song, off, sh = (allp[..., i].T for i in range(4))       # each [nQ, G]
+    valid = song >= 0
+    key_sc = np.where(valid, -sc, np.inf)
+    big = np.float64(1 << 40)
+    # lexicographic argmin over (−score, shift, song, offset) per query, vectorised
+    order = np.lexsort((np.where(valid, off, big).ravel(), np.where(valid, song, big).ravel(),
+                        np.where(valid, sh, big).ravel(), key_sc.ravel(),
+                        np.repeat(np.arange(nQ), G)))
+    first = order.reshape(nQ, G)[:, 0] - np.arange(nQ) * G          # winning rank per query
+    rows = np.arange(nQ)
+    out = np.zeros(nQ, dtype=[("song", "<i4"), ("offset", "<i4"), ("shift", "<i4"), ("score", "<f8")])
+    ok = valid[rows, first]
+    out["song"] = np.where(ok, song[rows, first], -1).astype(np.int32)
+    out["offset"] = np.where(ok, off[rows, first], 0).astype(np.int32)
+    out["shift"] = np.where(ok, sh[rows, first], 0).astype(np.int32)
+    out["score"] = np.where(ok, sc[rows, first], -np.inf)
+    return out
