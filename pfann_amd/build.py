@@ -15,7 +15,7 @@ LIB = os.path.join(HERE, "libpfann_amd.so")
 SOURCES = ["api.hip", "mel.hip", "encoder.hip", "encoder_fused.hip", "search.hip", "search_f16.hip", "rerank.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "search_common.h"),
            os.path.join(HERE, "..", "include", "pfann_amd.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"] + os.environ.get("PFANN_HIPCC_FLAGS", "").split()
 
 
 def _hipcc():

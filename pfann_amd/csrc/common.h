@@ -74,8 +74,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void *base, uns
     const unsigned n = bytes > 0x7FFFFFF0ull ? 0x7FFFFFF0u : (unsigned)bytes;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)n, 0x00020000);
 }
-__device__ __forceinline__ f32x4_t buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+// soff: wave-uniform byte offset (SGPR), added to the address but not part of the range check
+__device__ __forceinline__ f32x4_t buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off, int soff = 0) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, soff, 0);
     return __builtin_bit_cast(f32x4_t, v);
 }
 

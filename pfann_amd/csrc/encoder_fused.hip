@@ -23,6 +23,7 @@
 namespace pfann {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct FusedGemmParams {
@@ -55,7 +56,8 @@ struct FusedGemmParams {
 // the A-loader: z1 = b1 + sum_tap1 w1[tap1] * mel[f][2t + tap1] is recomputed per element (3 FMAs, same
 // order as conv_first_stats_kernel, so bit-identical) instead of streaming the 2 MiB/segment
 // tensor through HBM; p.x is then the log-mel batch [B][F][T0].
-template <int BM, int BN, int WM, int WN, bool RELU_BN, bool FIRST = false>
+// UNI = true: Ci % 32 == 0, see "Operand addressing" below.
+template <int BM, int BN, int WM, int WN, bool RELU_BN, bool FIRST, bool UNI>
 __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_ln_kernel(FusedGemmParams p) {
     constexpr int BK = 32, LDK = BK + 4;
     constexpr int WAVES_N = BN / WN;
@@ -165,76 +167,129 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_ln_kerne
             aoff[i] = 0; arel[i] = 0; amu[i] = 0.f; ars[i] = 0.f; atq[i] = 0;
         }
     }
-    unsigned boff[BR];
+    // Operand addressing.  UNI (Ci % BK == 0): every thread of the block is in the same filter tap
+    // for a whole K-tile, so the K position lives in a scalar register (the buffer instruction's
+    // soffset) and the per-thread byte offsets (with the row-validity test folded in as an
+    // out-of-range offset) only change when the tap does: no vector ALU work per K-tile, which
+    // matters because every VALU instruction issued here displaces MFMA issue on the same SIMD
+    // (measured: the loop without staging runs at 97 % of the fp32 MFMA peak).
+    // !UNI: generic per-thread (tap, channel) cursor, offsets recomputed for every tile.
+    constexpr int NA = FIRST ? 3 : 1;
+    unsigned va[AR][NA], vr[AR], vb[BR], vw1[3];
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
         const int n = n0 + rowq + RPT * j;
-        boff[j] = n < p.N ? (unsigned)n * (unsigned)p.K * 4u : BUF_OOB;
+        vb[j] = n < p.N ? (unsigned)n * (unsigned)p.K * 4u + (UNI ? (unsigned)col4 * 16u : 0u) : BUF_OOB;
     }
-    int kap = p.k_begin + col4 * 4;
-    int tap = kap / p.Ci, c = kap - tap * p.Ci;
+#pragma unroll
+    for (int t1 = 0; t1 < 3; ++t1) vw1[t1] = (unsigned)(t1 * p.Ci + (UNI ? col4 * 4 : 0)) * 4u;
     const int tap_stride = (int)p.tap_stride;
-
-    f32x4 ra[AR], rw[AR], rbb[AR], rb[BR];
-    f32x4 w1v[3], b1v;
-    unsigned okmask = 0;
-    auto load_tile = [&]() {
-        const bool kok = kap < p.k_end;
-        const int toff = tap * tap_stride + c;
-        okmask = 0;
+    int kap = p.k_begin + (UNI ? 0 : col4 * 4);          // UNI: uniform (scalar) cursor
+    int tap = kap / p.Ci, c = kap - tap * p.Ci;
+    // byte offsets of this thread's operands for filter tap `tp`, channel offset `cc`
+    auto set_offsets = [&](int tp, int cc, bool kok) {
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            const bool ok = kok && (unsigned)(ap0[i] + tap) < (unsigned)p.in_len;
-            okmask |= ok ? (1u << i) : 0u;
+            const bool ok = kok && (unsigned)(ap0[i] + tp) < (unsigned)p.in_len;
+            const int toff = tp * tap_stride + cc;
+            vr[i] = ok ? (unsigned)(arel[i] + toff) * 4u : BUF_OOB;
             if (FIRST) {
-                // three neighbouring log-mel frames of input row f_in = ap0 + tap (tap = tap2)
+                // three neighbouring log-mel frames of input row f_in = ap0 + tp (tp = tap2)
 #pragma unroll
-                for (int t1 = 0; t1 < 3; ++t1)
-                    ra[i][t1] = buf_load1(srd_a, (ok && (unsigned)(atq[i] + t1) < (unsigned)p.T0)
-                                                     ? (unsigned)(aoff[i] + tap * p.T0 + t1) * 4u : BUF_OOB);
+                for (int t1 = 0; t1 < NA; ++t1)
+                    va[i][t1] = (ok && (unsigned)(atq[i] + t1) < (unsigned)p.T0)
+                                    ? (unsigned)(aoff[i] + tp * p.T0 + t1) * 4u : BUF_OOB;
             } else {
-                ra[i] = buf_load4(srd_a, ok ? (unsigned)(aoff[i] + toff) * 4u : BUF_OOB);
+                va[i][0] = ok ? (unsigned)(aoff[i] + toff) * 4u : BUF_OOB;
             }
-            rw[i] = buf_load4(srd_w, ok ? (unsigned)(arel[i] + toff) * 4u : BUF_OOB);
-            rbb[i] = buf_load4(srd_lb, ok ? (unsigned)(arel[i] + toff) * 4u : BUF_OOB);
+        }
+    };
+    if (UNI) set_offsets(tap, col4 * 4, true);
+
+    struct Stage {                       // one K-tile of prefetched operands, in registers
+        f32x4 ra[AR], rw[AR], rbb[AR], rb[BR];
+        f32x4 w1v[3], b1v;
+    };
+    auto load_tile = [&](Stage &S) {
+        int so_c = 0, so_k = 0;          // scalar byte offsets (UNI)
+        bool kok = true;
+        if (UNI) {
+            so_c = c * 4;
+            so_k = kap * 4;
+        } else {
+            kok = kap < p.k_end;
+            set_offsets(tap, c, kok);
+        }
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            if (FIRST) {
+#pragma unroll
+                for (int t1 = 0; t1 < NA; ++t1) S.ra[i][t1] = buf_load1(srd_a, va[i][t1]);
+            } else {
+                S.ra[i] = buf_load4(srd_a, va[i][0], so_c);
+            }
+            S.rw[i] = buf_load4(srd_w, vr[i], so_c);
+            S.rbb[i] = buf_load4(srd_lb, vr[i], so_c);
         }
         if (FIRST) {
 #pragma unroll
-            for (int t1 = 0; t1 < 3; ++t1) w1v[t1] = buf_load4(srd_w1, kok ? (unsigned)(t1 * p.Ci + c) * 4u : BUF_OOB);
-            b1v = buf_load4(srd_b1, kok ? (unsigned)c * 4u : BUF_OOB);
+            for (int t1 = 0; t1 < 3; ++t1)
+                S.w1v[t1] = buf_load4(srd_w1, kok ? vw1[t1] + (UNI ? 0u : (unsigned)c * 4u) : BUF_OOB, so_c);
+            S.b1v = buf_load4(srd_b1, kok ? (unsigned)(UNI ? col4 * 4 : c) * 4u : BUF_OOB, so_c);
         }
 #pragma unroll
-        for (int j = 0; j < BR; ++j) rb[j] = buf_load4(srd_b, kok ? boff[j] + (unsigned)kap * 4u : BUF_OOB);
+        for (int j = 0; j < BR; ++j)
+            S.rb[j] = buf_load4(srd_b, (UNI || vb[j] == BUF_OOB) ? vb[j] : (kok ? vb[j] + (unsigned)kap * 4u : BUF_OOB), so_k);
         kap += BK;
         c += BK;
+        if (UNI) {
+            if (c >= p.Ci) {             // uniform branch: next filter tap
+                c = 0;
+                ++tap;
+#ifdef PF_EXP_KREP
+                if (kap >= p.k_end) { kap = p.k_begin; tap = kap / p.Ci; }
+#endif
+                set_offsets(tap, col4 * 4, true);
+            }
+        } else {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) { const bool w = c >= p.Ci; c -= w ? p.Ci : 0; tap += w ? 1 : 0; }
+            for (int q = 0; q < 2; ++q) { const bool w = c >= p.Ci; c -= w ? p.Ci : 0; tap += w ? 1 : 0; }
+        }
     };
-    // v = POST((z - mean) * rstd * W + B); padding / out-of-range lanes must stay exactly 0
-    auto store_tile = [&](float *Ad, float *Bd) {
+    // v = POST((z - mean) * rstd * W + B), two elements per packed-fp32 instruction.  Rows outside the
+    // input (conv padding, m >= M, k >= k_end) need no select: their offsets were out of range, so
+    // W = B = 0 arrive from the buffer unit and (z - mean) * rstd * 0 + 0 = +-0, which every
+    // activation maps to 0.
+    auto store_tile = [&](const Stage &S, float *Ad, float *Bd) {
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            const bool ok = (okmask >> i) & 1u;
+            const f32x2 mu2 = {amu[i], amu[i]}, rs2 = {ars[i], ars[i]};
             f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float z = ra[i][e];
+            for (int h = 0; h < 2; ++h) {
+                f32x2 z = {S.ra[i][2 * h], S.ra[i][2 * h + 1]};
                 if (FIRST) {   // same FMA order as conv_first_stats_kernel: bias, then taps 0, 1, 2
-                    z = b1v[e];
+                    z = f32x2{S.b1v[2 * h], S.b1v[2 * h + 1]};
 #pragma unroll
-                    for (int t1 = 0; t1 < 3; ++t1) z += ra[i][t1] * w1v[t1][e];
+                    for (int t1 = 0; t1 < 3; ++t1)
+                        z = __builtin_elementwise_fma(f32x2{S.ra[i][t1], S.ra[i][t1]},
+                                                      f32x2{S.w1v[t1][2 * h], S.w1v[t1][2 * h + 1]}, z);
+                    if (!RELU_BN && !p.after_bn) { z[0] = act_fn(z[0], p.act); z[1] = act_fn(z[1], p.act); }   // PRE of sub-layer 0
                 }
-                if (FIRST && !RELU_BN && !p.after_bn) z = act_fn(z, p.act);   // PRE of sub-layer 0
-                float t = (z - amu[i]) * ars[i] * rw[i][e] + rbb[i][e];
-                if (RELU_BN) t = fmaxf(t, 0.f);
-                else t = p.after_bn ? act_fn(t, p.act) : t;
-                v[e] = ok ? t : 0.f;
+                const f32x2 w2 = {S.rw[i][2 * h], S.rw[i][2 * h + 1]}, b2 = {S.rbb[i][2 * h], S.rbb[i][2 * h + 1]};
+                f32x2 t = __builtin_elementwise_fma((z - mu2) * rs2, w2, b2);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    if (RELU_BN) t[e] = fmaxf(t[e], 0.f);
+                    else t[e] = p.after_bn ? act_fn(t[e], p.act) : t[e];
+                    v[2 * h + e] = t[e];
+                }
             }
             *reinterpret_cast<f32x4 *>(&Ad[(rowq + RPT * i) * LDK + col4 * 4]) = v;
         }
 #pragma unroll
         for (int j = 0; j < BR; ++j)
-            *reinterpret_cast<f32x4 *>(&Bd[(rowq + RPT * j) * LDK + col4 * 4]) = rb[j];
+            *reinterpret_cast<f32x4 *>(&Bd[(rowq + RPT * j) * LDK + col4 * 4]) = S.rb[j];
     };
 
     f32x16 acc[TM][TN];
@@ -246,14 +301,21 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_ln_kerne
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // LDS double buffer, one barrier per K-tile (see csrc/encoder.hip for the schedule)
+#ifdef PF_EXP_KREP
+    const int nk = PF_EXP_KREP * ((p.k_end - p.k_begin + BK - 1) / BK);
+#else
     const int nk = (p.k_end - p.k_begin + BK - 1) / BK;
-    load_tile();
-    store_tile(As, Bs);
-    __syncthreads();
+#endif
     const int l31 = lane & 31, lhalf = lane >> 5;
+    Stage S;
+    load_tile(S);
+    store_tile(S, As, Bs);
+    __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
+        // MFMAs on LDS buffer kt&1 while tile kt+1 goes global -> registers -> buffer (kt+1)&1
         const float *Ac = As + (kt & 1) * (BM * LDK), *Bc = Bs + (kt & 1) * (BN * LDK);
         float *An = As + ((kt + 1) & 1) * (BM * LDK), *Bn = Bs + ((kt + 1) & 1) * (BN * LDK);
+        const bool more = kt + 1 < nk;   // UNI offsets are not range-checked against k_end: no loads past it
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
             f32x4 a4[TM], b4[TN];
@@ -264,12 +326,12 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_ln_kerne
             for (int j = 0; j < TN; ++j)
                 b4[j] = *reinterpret_cast<const f32x4 *>(&Bc[(wn * WN + j * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
             if (kk == 0) {
-                load_tile();
+                if (more) load_tile(S);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (kk == BK / 8 - 1) {
-                __builtin_amdgcn_sched_barrier(0);   // ...and never hoist the dependent store phase
-                store_tile(An, Bn);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) store_tile(S, An, Bn);
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s)
@@ -376,7 +438,7 @@ static void live_taps(const SubLayer &L, int in_len, int &k_begin, int &k_end) {
 static int gemm_tile(const SubLayer &L, int64_t B) {
     const int64_t M = B * L.Fo * L.To;
     const int64_t blocks128 = (int64_t)cdiv(M, 128) * cdiv(L.co, 128);
-    return (L.co >= 128 && blocks128 >= 512) ? 128 : 64;
+    return (L.co >= 128 && blocks128 >= 512 && L.ci % 32 == 0) ? 128 : 64;
 }
 
 int fused_out_slots(const SubLayer &L, int64_t B) {
@@ -425,34 +487,36 @@ int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, 
         p.T0 = Lfirst->T; p.s1 = Lfirst->stride; p.pad1 = Lfirst->pad_lo;
     }
     const double flops = 2.0 * (double)p.M * p.N * (p.k_end - p.k_begin);
+    const bool first = Lfirst != nullptr, relu_bn = act == 0 && after_bn, uni = L.ci % 32 == 0;
+#define PF_GEMM_LN(BM, BN, WM, WN, NTHR)                                                                  \
+    do {                                                                                                  \
+        const dim3 g((unsigned)blocks), t(NTHR);                                                          \
+        if (first && relu_bn) PF_LAUNCH((conv_gemm_ln_kernel<BM, BN, WM, WN, true, true, UNI_>), g, t, 0, s, p);   \
+        else if (first) PF_LAUNCH((conv_gemm_ln_kernel<BM, BN, WM, WN, false, true, UNI_>), g, t, 0, s, p);        \
+        else if (relu_bn) PF_LAUNCH((conv_gemm_ln_kernel<BM, BN, WM, WN, true, false, UNI_>), g, t, 0, s, p);      \
+        else PF_LAUNCH((conv_gemm_ln_kernel<BM, BN, WM, WN, false, false, UNI_>), g, t, 0, s, p);                  \
+    } while (0)
     if (gemm_tile(L, B) == 128) {
         p.n_tiles_n = cdiv(p.N, 128);
         const int64_t blocks = (int64_t)cdiv(p.M, 128) * p.n_tiles_n;
         ProfScope ps("conv_gemm_ln_128", s, flops);
         // 8 waves (512 threads), each a 64x32 tile: half the prefetch registers per thread and four
         // waves per SIMD with two resident blocks
-        if (Lfirst != nullptr && act == 0 && after_bn)
-            PF_LAUNCH((conv_gemm_ln_kernel<128, 128, 64, 32, true, true>), dim3((unsigned)blocks), dim3(512), 0, s, p);
-        else if (Lfirst != nullptr)
-            PF_LAUNCH((conv_gemm_ln_kernel<128, 128, 64, 32, false, true>), dim3((unsigned)blocks), dim3(512), 0, s, p);
-        else if (act == 0 && after_bn)
-            PF_LAUNCH((conv_gemm_ln_kernel<128, 128, 64, 32, true>), dim3((unsigned)blocks), dim3(512), 0, s, p);
-        else
-            PF_LAUNCH((conv_gemm_ln_kernel<128, 128, 64, 32, false>), dim3((unsigned)blocks), dim3(512), 0, s, p);
+        constexpr bool UNI_ = true;
+        PF_GEMM_LN(128, 128, 64, 32, 512);
     } else {
         p.n_tiles_n = cdiv(p.N, 64);
         const int64_t blocks = (int64_t)cdiv(p.M, 64) * p.n_tiles_n;
         ProfScope ps("conv_gemm_ln_64", s, flops);
-        if (Lfirst != nullptr && act == 0 && after_bn)
-            PF_LAUNCH((conv_gemm_ln_kernel<64, 64, 32, 32, true, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
-        else if (Lfirst != nullptr)
-            PF_LAUNCH((conv_gemm_ln_kernel<64, 64, 32, 32, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
-        else if (act == 0 && after_bn)
-            PF_LAUNCH((conv_gemm_ln_kernel<64, 64, 32, 32, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
-        else
-            PF_LAUNCH((conv_gemm_ln_kernel<64, 64, 32, 32, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        if (uni) {
+            constexpr bool UNI_ = true;
+            PF_GEMM_LN(64, 64, 32, 32, 256);
+        } else {
+            constexpr bool UNI_ = false;
+            PF_GEMM_LN(64, 64, 32, 32, 256);
+        }
     }
-    PF_HIP(hipGetLastError());
+#undef PF_GEMM_LN
     return 0;
 }
 
