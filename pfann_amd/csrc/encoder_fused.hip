@@ -19,6 +19,8 @@
 #include <stdlib.h>
 
 #include "kernels.h"
+#include <set>
+#include <string>
 
 namespace pfann {
 
@@ -29,22 +31,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct FusedGemmParams {
     const float *x, *w, *bias;
     float *y;
-    int64_t M;
+    int M;                       // B * rows_per_sample (< 2^31, checked by the launcher)
     int N, K, Ci;
     int rows_per_sample, To, F, T;
+    int rps_shift, To_shift;     // rows_per_sample and To are powers of two (fused_supported)
     int axis, stride, pad_lo, in_len;
     int64_t tap_stride;
     int n_tiles_n;
     int k_begin, k_end;
     // input normalisation
-    const float *in_part; int in_P;
+    const float *in_stats;       // [n_samples][2] = (mean, rstd) of the input, from ln_finalize_kernel
     const float *ln_w, *ln_b;
-    double inv_n_in;
     int64_t in_elems;            // F*T*Ci
     // output statistics
     float *out_part; int out_P;
     int act, after_bn;
-    int64_t n_samples;
+    int n_samples;
     // FIRST variant: the input is the C_in = 1 first conv computed on the fly from the log-mel
     const float *w1, *b1;        // first conv weights [3][Ci] and bias [Ci]
     int T0, s1, pad1;            // mel frames, first conv stride and left pad along T
@@ -58,7 +60,8 @@ struct FusedGemmParams {
 // tensor through HBM; p.x is then the log-mel batch [B][F][T0].
 // UNI = true: Ci % 32 == 0, see "Operand addressing" below.
 template <int BM, int BN, int WM, int WN, bool RELU_BN, bool FIRST, bool UNI>
-__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_ln_kernel(FusedGemmParams p) {
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM / WM) * (BN / WN) == 8 ? 4 : 1)
+void conv_gemm_ln_kernel(FusedGemmParams p) {
     constexpr int BK = 32, LDK = BK + 4;
     constexpr int WAVES_N = BN / WN;
     constexpr int NWAVES = (BM / WM) * WAVES_N, NT = 64 * NWAVES;
@@ -68,25 +71,23 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_ln_kerne
     constexpr int AR = BM / RPT, BR = BN / RPT;
     __shared__ __attribute__((aligned(16))) float As[2 * BM * LDK];
     __shared__ __attribute__((aligned(16))) float Bs[2 * BN * LDK];
-    __shared__ float s_mu[BM], s_rs[BM];
-    __shared__ double s_red[2 * NWAVES];
+    __shared__ __attribute__((aligned(16))) float s_w1[FIRST ? 4 * 256 : 4];   // FIRST: w1[3][Ci], b1[Ci]; Ci <= 256
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int L = xcd_remap(blockIdx.x, gridDim.x);
     const int rps = p.rows_per_sample;
-    int64_t mt;
-    int nt;
+    int mt, nt;
     if (rps >= 2 * BM) {
         // several tiles per sample: run tile `ti` of GS neighbouring samples back to back, so the
         // LayerNorm affine slice they all stream (identical for every sample) stays in this XCD's L2
         constexpr int GS = 64;
         const int tps = rps / BM;
-        const int64_t per_group = (int64_t)GS * tps * p.n_tiles_n;
-        const int64_t g = L / per_group;
-        const int64_t left = p.n_samples - g * GS;
-        const int gs = left < GS ? (int)left : GS;
-        const int r = (int)(L - g * per_group);
+        const int per_group = GS * tps * p.n_tiles_n;
+        const int g = L / per_group;
+        const int left = p.n_samples - g * GS;
+        const int gs = left < GS ? left : GS;
+        const int r = L - g * per_group;
         const int ti = r / (gs * p.n_tiles_n);
         const int r2 = r - ti * (gs * p.n_tiles_n);
         const int bi = r2 / p.n_tiles_n;
@@ -94,50 +95,22 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_ln_kerne
         mt = (g * GS + bi) * tps + ti;
     } else {
         mt = L / p.n_tiles_n;
-        nt = L - (int)mt * p.n_tiles_n;
+        nt = L - mt * p.n_tiles_n;
     }
-    const int64_t m0 = mt * BM;
+    const int m0 = mt * BM;
     const int n0 = nt * BN;
-
-    // ---- (mean, rstd) of every input sample this tile touches -----------------------------
-    const int64_t b_first = m0 / rps;
-    const int ns = rps >= BM ? 1 : BM / rps;
-    if (ns == 1) {
-        double s1 = 0, s2 = 0;
-        const float *pp = p.in_part + b_first * p.in_P * 2;
-        for (int i = tid; i < p.in_P; i += NT) { s1 += (double)pp[2 * i]; s2 += (double)pp[2 * i + 1]; }
-        s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
-        if (lane == 0) { s_red[wave] = s1; s_red[NWAVES + wave] = s2; }
+    const int b_first = m0 >> p.rps_shift;
+    if (FIRST) {     // first-conv weights and bias -> LDS (visible after the barrier that publishes tile 0)
+        for (int i = tid; i < 4 * p.Ci; i += NT) s_w1[i] = i < 3 * p.Ci ? p.w1[i] : p.b1[i - 3 * p.Ci];
         __syncthreads();
-        if (tid == 0) {
-            double t1 = 0, t2 = 0;
-            for (int w = 0; w < NWAVES; ++w) { t1 += s_red[w]; t2 += s_red[NWAVES + w]; }
-            const double mean = t1 * p.inv_n_in;
-            double var = t2 * p.inv_n_in - mean * mean;
-            if (var < 0) var = 0;
-            s_mu[0] = (float)mean;
-            s_rs[0] = (float)(1.0 / sqrt(var + 1e-5));
-        }
-    } else if (tid < ns && b_first + tid < p.n_samples) {
-        const float *pp = p.in_part + (b_first + tid) * p.in_P * 2;
-        double s1 = 0, s2 = 0;
-        for (int i = 0; i < p.in_P; ++i) { s1 += (double)pp[2 * i]; s2 += (double)pp[2 * i + 1]; }
-        const double mean = s1 * p.inv_n_in;
-        double var = s2 * p.inv_n_in - mean * mean;
-        if (var < 0) var = 0;
-        s_mu[tid] = (float)mean;
-        s_rs[tid] = (float)(1.0 / sqrt(var + 1e-5));
     }
-    __syncthreads();
 
     const int col4 = tid & 7, rowq = tid >> 3;
     // bounds-checked buffer loads (OOB lanes read 0): activation window from the first sample of
     // the tile, LayerNorm affine tensors addressed sample-relative, weights by output channel
     const int64_t x_elems = FIRST ? (int64_t)p.F * p.T0 : p.in_elems;       // per-sample size of p.x
     const __amdgpu_buffer_rsrc_t srd_a =
-        make_srd(p.x + b_first * x_elems, (unsigned long long)(p.n_samples - b_first) * x_elems * 4ull);
-    const __amdgpu_buffer_rsrc_t srd_w1 = make_srd(p.w1, FIRST ? (unsigned long long)3 * p.Ci * 4ull : 0ull);
-    const __amdgpu_buffer_rsrc_t srd_b1 = make_srd(p.b1, FIRST ? (unsigned long long)p.Ci * 4ull : 0ull);
+        make_srd(p.x + (int64_t)b_first * x_elems, (unsigned long long)(p.n_samples - b_first) * x_elems * 4ull);
     const __amdgpu_buffer_rsrc_t srd_w = make_srd(p.ln_w, (unsigned long long)p.in_elems * 4ull);
     const __amdgpu_buffer_rsrc_t srd_lb = make_srd(p.ln_b, (unsigned long long)p.in_elems * 4ull);
     const __amdgpu_buffer_rsrc_t srd_b = make_srd(p.w, (unsigned long long)p.N * p.K * 4ull);
@@ -145,23 +118,23 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_ln_kerne
     float amu[AR], ars[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-        const int64_t m = m0 + rowq + RPT * i;
+        const int m = m0 + rowq + RPT * i;
         if (m < p.M) {
-            const int64_t b = m / rps;
-            const int r = (int)(m - b * rps);
-            const int fo = r / p.To, to = r - fo * p.To;
+            const int b = m >> p.rps_shift;
+            const int r = m & (rps - 1);
+            const int fo = r >> p.To_shift, to = r & (p.To - 1);
             int rel;
             if (p.axis == 0) { ap0[i] = to * p.stride - p.pad_lo; rel = (fo * p.T + ap0[i]) * p.Ci; }
             else { ap0[i] = fo * p.stride - p.pad_lo; rel = (ap0[i] * p.T + to) * p.Ci; }
-            const int sl = (int)(b - b_first);
+            const int sl = b - b_first;
             arel[i] = rel;
             aoff[i] = sl * (int)p.in_elems + rel;
             if (FIRST) {   // mel element of tap2 = 0, tap1 = 0:  ((b*F + f_in) * T0 + to*s1 - pad1)
                 atq[i] = to * p.s1 - p.pad1;
                 aoff[i] = (sl * p.F + ap0[i]) * p.T0 + atq[i];
             }
-            amu[i] = s_mu[sl];
-            ars[i] = s_rs[sl];
+            amu[i] = p.in_stats[2 * b];
+            ars[i] = p.in_stats[2 * b + 1];
         } else {
             ap0[i] = -(1 << 20);
             aoff[i] = 0; arel[i] = 0; amu[i] = 0.f; ars[i] = 0.f; atq[i] = 0;
@@ -175,14 +148,12 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_ln_kerne
     // (measured: the loop without staging runs at 97 % of the fp32 MFMA peak).
     // !UNI: generic per-thread (tap, channel) cursor, offsets recomputed for every tile.
     constexpr int NA = FIRST ? 3 : 1;
-    unsigned va[AR][NA], vr[AR], vb[BR], vw1[3];
+    unsigned va[AR][NA], vr[AR], vb[BR];
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
         const int n = n0 + rowq + RPT * j;
         vb[j] = n < p.N ? (unsigned)n * (unsigned)p.K * 4u + (UNI ? (unsigned)col4 * 16u : 0u) : BUF_OOB;
     }
-#pragma unroll
-    for (int t1 = 0; t1 < 3; ++t1) vw1[t1] = (unsigned)(t1 * p.Ci + (UNI ? col4 * 4 : 0)) * 4u;
     const int tap_stride = (int)p.tap_stride;
     int kap = p.k_begin + (UNI ? 0 : col4 * 4);          // UNI: uniform (scalar) cursor
     int tap = kap / p.Ci, c = kap - tap * p.Ci;
@@ -207,8 +178,8 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_ln_kerne
     if (UNI) set_offsets(tap, col4 * 4, true);
 
     struct Stage {                       // one K-tile of prefetched operands, in registers
-        f32x4 ra[AR], rw[AR], rbb[AR], rb[BR];
-        f32x4 w1v[3], b1v;
+        f32x4 ra[AR], rw[AR], rbb[AR], rb[BR];   // FIRST: ra[i][0..2] = the three log-mel taps
+        int cc;                                   // channel of element 0 (first-conv weights come from LDS)
     };
     auto load_tile = [&](Stage &S) {
         int so_c = 0, so_k = 0;          // scalar byte offsets (UNI)
@@ -231,12 +202,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_ln_kerne
             S.rw[i] = buf_load4(srd_w, vr[i], so_c);
             S.rbb[i] = buf_load4(srd_lb, vr[i], so_c);
         }
-        if (FIRST) {
-#pragma unroll
-            for (int t1 = 0; t1 < 3; ++t1)
-                S.w1v[t1] = buf_load4(srd_w1, kok ? vw1[t1] + (UNI ? 0u : (unsigned)c * 4u) : BUF_OOB, so_c);
-            S.b1v = buf_load4(srd_b1, kok ? (unsigned)(UNI ? col4 * 4 : c) * 4u : BUF_OOB, so_c);
-        }
+        S.cc = kok ? c + (UNI ? col4 * 4 : 0) : 0;
 #pragma unroll
         for (int j = 0; j < BR; ++j)
             S.rb[j] = buf_load4(srd_b, (UNI || vb[j] == BUF_OOB) ? vb[j] : (kok ? vb[j] + (unsigned)kap * 4u : BUF_OOB), so_k);
@@ -264,16 +230,21 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_ln_kerne
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             const f32x2 mu2 = {amu[i], amu[i]}, rs2 = {ars[i], ars[i]};
-            f32x4 v;
+            f32x4 v, w1v[3], b1v;
+            if (FIRST) {
+#pragma unroll
+                for (int t1 = 0; t1 < 3; ++t1) w1v[t1] = *reinterpret_cast<const f32x4 *>(&s_w1[t1 * p.Ci + S.cc]);
+                b1v = *reinterpret_cast<const f32x4 *>(&s_w1[3 * p.Ci + S.cc]);
+            }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 f32x2 z = {S.ra[i][2 * h], S.ra[i][2 * h + 1]};
                 if (FIRST) {   // same FMA order as conv_first_stats_kernel: bias, then taps 0, 1, 2
-                    z = f32x2{S.b1v[2 * h], S.b1v[2 * h + 1]};
+                    z = f32x2{b1v[2 * h], b1v[2 * h + 1]};
 #pragma unroll
                     for (int t1 = 0; t1 < 3; ++t1)
                         z = __builtin_elementwise_fma(f32x2{S.ra[i][t1], S.ra[i][t1]},
-                                                      f32x2{S.w1v[t1][2 * h], S.w1v[t1][2 * h + 1]}, z);
+                                                      f32x2{w1v[t1][2 * h], w1v[t1][2 * h + 1]}, z);
                     if (!RELU_BN && !p.after_bn) { z[0] = act_fn(z[0], p.act); z[1] = act_fn(z[1], p.act); }   // PRE of sub-layer 0
                 }
                 const f32x2 w2 = {S.rw[i][2 * h], S.rw[i][2 * h + 1]}, b2 = {S.rbb[i][2 * h], S.rbb[i][2 * h + 1]};
@@ -346,7 +317,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_ln_kerne
 
     // ---- epilogue: z = PRE(acc + bias) -> HBM; per-sample partial statistics -------------
     // C layout of a 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    const __amdgpu_buffer_rsrc_t srd_y = make_srd(p.y + m0 * p.N, (unsigned long long)(p.M - m0) * p.N * 4ull);
+    const __amdgpu_buffer_rsrc_t srd_y = make_srd(p.y + (int64_t)m0 * p.N, (unsigned long long)(p.M - m0) * p.N * 4ull);
     float *red1 = As;                 // [BM][WAVES_N] row (or sub-tile) sums; As/Bs are free now
     float *red2 = As + BM * WAVES_N;
     const int G = rps >= BM ? BM : rps;          // rows per statistics group inside the tile
@@ -363,7 +334,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_ln_kerne
         float rs1[16], rs2[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int64_t m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+            const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
             float a1 = 0.f, a2 = 0.f;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -373,7 +344,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_ln_kerne
                     a1 += z;
                     a2 = fmaf(z, z, a2);
                 }
-                buf_store1(srd_y, nok[j] ? (unsigned)((int)(m - m0) * p.N + n0 + wn * WN + j * 32 + l31) * 4u : BUF_OOB, z);
+                buf_store1(srd_y, nok[j] ? (unsigned)((m - m0) * p.N + n0 + wn * WN + j * 32 + l31) * 4u : BUF_OOB, z);
             }
             rs1[r] = a1; rs2[r] = a2;
         }
@@ -406,19 +377,38 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void conv_gemm_ln_kerne
     {
         const int ngroups = BM / G;
         if (tid < ngroups) {
-            const int64_t mg = m0 + (int64_t)tid * G;
+            const int mg = m0 + tid * G;
             if (mg < p.M) {
                 float t1 = 0.f, t2 = 0.f;
                 const int step = G >= 32 ? 32 : 1;
                 for (int row = tid * G; row < (tid + 1) * G; row += step)
                     for (int w = 0; w < WAVES_N; ++w) { t1 += red1[row * WAVES_N + w]; t2 += red2[row * WAVES_N + w]; }
-                const int64_t b = mg / rps;
-                const int slot = (int)((mg - b * rps) / G) * p.n_tiles_n + nt;
-                float *o = p.out_part + (b * p.out_P + slot) * 2;
+                const int b = mg >> p.rps_shift;
+                const int slot = ((mg & (rps - 1)) / G) * p.n_tiles_n + nt;
+                float *o = p.out_part + ((int64_t)b * p.out_P + slot) * 2;
                 o[0] = t1;
                 o[1] = t2;
             }
         }
+    }
+}
+
+// (mean, rstd) of every sample from its P partial (sum, sum of squares) pairs: one wave per sample,
+// fp64, fixed order.  Done once here rather than by every GEMM block that touches the sample.
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float *__restrict__ part, int P, double inv_n,
+                                                          float *__restrict__ stats, int B) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const float *pp = part + (int64_t)b * P * 2;
+    double s1 = 0, s2 = 0;
+    for (int i = lane; i < P; i += 64) { s1 += (double)pp[2 * i]; s2 += (double)pp[2 * i + 1]; }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+    if (lane == 0) {
+        const double mean = s1 * inv_n;
+        double var = s2 * inv_n - mean * mean;
+        if (var < 0) var = 0;
+        stats[2 * b] = (float)mean;
+        stats[2 * b + 1] = (float)(1.0 / sqrt(var + 1e-5));
     }
 }
 
@@ -461,33 +451,50 @@ bool fused_supported(const SubLayer *sub, int n) {
 }
 
 // Lfirst != nullptr: x is the log-mel batch and Lfirst (= Lin, the C_in = 1 conv) is folded into the A-loader
+static int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
+
 int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, const float *in_part, int in_P,
-                        float *y, float *out_part, int64_t B, int act, int after_bn, const SubLayer *Lfirst,
-                        hipStream_t s) {
+                        float *in_stats, float *y, float *out_part, int64_t B, int act, int after_bn,
+                        const SubLayer *Lfirst, hipStream_t s) {
     FusedGemmParams p;
+    if (B * L.Fo * L.To >= (int64_t)0x7FFF0000) { set_error("conv_gemm_ln: batch too large"); return -1; }
     p.x = x; p.w = L.w; p.bias = L.bias; p.y = y;
     p.rows_per_sample = L.Fo * L.To;
-    p.M = B * p.rows_per_sample;
+    p.M = (int)(B * p.rows_per_sample);
+    p.rps_shift = ilog2(p.rows_per_sample); p.To_shift = ilog2(L.To);
     p.N = L.co; p.Ci = L.ci; p.K = 3 * L.ci;
     p.To = L.To; p.F = L.F; p.T = L.T;
     p.axis = L.axis; p.stride = L.stride; p.pad_lo = L.pad_lo;
     p.in_len = L.axis == 0 ? L.T : L.F;
     p.tap_stride = L.axis == 0 ? (int64_t)L.ci : (int64_t)L.T * L.ci;
     live_taps(L, p.in_len, p.k_begin, p.k_end);
-    p.in_part = in_part; p.in_P = in_P;
+    p.in_stats = in_stats;
     p.ln_w = Lin.ln_w; p.ln_b = Lin.ln_b;
     p.in_elems = (int64_t)L.F * L.T * L.ci;
-    p.inv_n_in = 1.0 / (double)p.in_elems;
     p.out_part = out_part; p.out_P = fused_out_slots(L, B);
     p.act = act; p.after_bn = after_bn;
-    p.n_samples = B;
+    p.n_samples = (int)B;
     p.w1 = nullptr; p.b1 = nullptr; p.T0 = 0; p.s1 = 1; p.pad1 = 0;
     if (Lfirst != nullptr) {
         p.w1 = Lfirst->w; p.b1 = Lfirst->bias;
         p.T0 = Lfirst->T; p.s1 = Lfirst->stride; p.pad1 = Lfirst->pad_lo;
     }
+    {
+        ProfScope ps("ln_finalize", s);
+        PF_LAUNCH(ln_finalize_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, s, in_part, in_P, 1.0 / (double)p.in_elems,
+                  in_stats, (int)B);
+    }
     const double flops = 2.0 * (double)p.M * p.N * (p.k_end - p.k_begin);
     const bool first = Lfirst != nullptr, relu_bn = act == 0 && after_bn, uni = L.ci % 32 == 0;
+    // PFANN_PROF_LAYERS=1: one profiling tag per layer shape (tuning aid; bench.py's roofline wants the plain tags)
+    static const bool per_layer = getenv("PFANN_PROF_LAYERS") != nullptr;
+    auto layer_tag = [&](const char *base) -> const char * {
+        if (!per_layer) return base;
+        static std::set<std::string> names;
+        char buf[128];
+        snprintf(buf, sizeof buf, "%s rows=%d K=%d N=%d%s", base, p.rows_per_sample, p.k_end - p.k_begin, p.N, first ? " first" : "");
+        return names.insert(buf).first->c_str();
+    };
 #define PF_GEMM_LN(BM, BN, WM, WN, NTHR)                                                                  \
     do {                                                                                                  \
         const dim3 g((unsigned)blocks), t(NTHR);                                                          \
@@ -499,7 +506,7 @@ int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, 
     if (gemm_tile(L, B) == 128) {
         p.n_tiles_n = cdiv(p.N, 128);
         const int64_t blocks = (int64_t)cdiv(p.M, 128) * p.n_tiles_n;
-        ProfScope ps("conv_gemm_ln_128", s, flops);
+        ProfScope ps(layer_tag("conv_gemm_ln_128"), s, flops);
         // 8 waves (512 threads), each a 64x32 tile: half the prefetch registers per thread and four
         // waves per SIMD with two resident blocks
         constexpr bool UNI_ = true;
@@ -507,7 +514,7 @@ int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, 
     } else {
         p.n_tiles_n = cdiv(p.N, 64);
         const int64_t blocks = (int64_t)cdiv(p.M, 64) * p.n_tiles_n;
-        ProfScope ps("conv_gemm_ln_64", s, flops);
+        ProfScope ps(layer_tag("conv_gemm_ln_64"), s, flops);
         if (uni) {
             constexpr bool UNI_ = true;
             PF_GEMM_LN(64, 64, 32, 32, 256);
