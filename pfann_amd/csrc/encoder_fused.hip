@@ -321,30 +321,35 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
     float *red1 = As;                 // [BM][WAVES_N] row (or sub-tile) sums; As/Bs are free now
     float *red2 = As + BM * WAVES_N;
     const int G = rps >= BM ? BM : rps;          // rows per statistics group inside the tile
+    // No validity selects: columns n >= N have zero weights and bias (z = 0 adds nothing to the sums) and
+    // an out-of-range store offset; rows m >= M lie beyond srd_y and form whole statistics groups
+    // (M is a multiple of G) that are never written out.
     float bv[TN];
-    bool nok[TN];
+    unsigned cb[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * WN + j * 32 + l31;
-        nok[j] = n < p.N;
-        bv[j] = nok[j] ? p.bias[n] : 0.f;
+        bv[j] = n < p.N ? p.bias[n] : 0.f;
+        cb[j] = n < p.N ? (unsigned)n * 4u : BUF_OOB;
     }
+    const unsigned rowbytes = (unsigned)p.N * 4u, rowbytes5 = 5u * rowbytes;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         float rs1[16], rs2[16];
+        unsigned vo[TN];                 // running store offset: C rows of a lane go 0,1,2,3, 8,9,10,11, ...
+#pragma unroll
+        for (int j = 0; j < TN; ++j) vo[j] = cb[j] + (unsigned)(wm * WM + i * 32 + 4 * lhalf) * rowbytes;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-            float a1 = 0.f, a2 = 0.f;
+            float a1, a2;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 float z = acc[i][j][r] + bv[j];
                 if (!RELU_BN && !p.after_bn) z = act_fn(z, p.act);
-                if (m < p.M && nok[j]) {
-                    a1 += z;
-                    a2 = fmaf(z, z, a2);
-                }
-                buf_store1(srd_y, nok[j] ? (unsigned)((m - m0) * p.N + n0 + wn * WN + j * 32 + l31) * 4u : BUF_OOB, z);
+                if (j == 0) { a1 = z; a2 = z * z; }
+                else { a1 += z; a2 = fmaf(z, z, a2); }
+                buf_store1(srd_y, vo[j], z);
+                vo[j] += (r & 3) == 3 ? rowbytes5 : rowbytes;
             }
             rs1[r] = a1; rs2[r] = a2;
         }
