@@ -212,9 +212,6 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
             if (c >= p.Ci) {             // uniform branch: next filter tap
                 c = 0;
                 ++tap;
-#ifdef PF_EXP_KREP
-                if (kap >= p.k_end) { kap = p.k_begin; tap = kap / p.Ci; }
-#endif
                 set_offsets(tap, col4 * 4, true);
             }
         } else {
@@ -272,11 +269,7 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // LDS double buffer, one barrier per K-tile (see csrc/encoder.hip for the schedule)
-#ifdef PF_EXP_KREP
-    const int nk = PF_EXP_KREP * ((p.k_end - p.k_begin + BK - 1) / BK);
-#else
     const int nk = (p.k_end - p.k_begin + BK - 1) / BK;
-#endif
     const int l31 = lane & 31, lhalf = lane >> 5;
     Stage S;
     load_tile(S);
