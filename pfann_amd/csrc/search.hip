@@ -425,7 +425,7 @@ static int ensure_ws(SearchWorkspace &ws, int64_t nq) {
     PF_HIP(hipMalloc(&ws.thr_adj, sizeof(float) * cap));
     PF_HIP(hipMalloc(&ws.eps, sizeof(float) * cap));
     PF_HIP(hipMalloc(&ws.thr, sizeof(float) * cap));
-    PF_HIP(hipMalloc(&ws.cnt, sizeof(int) * (cap < 2048 ? 2048 : cap)));
+    PF_HIP(hipMalloc(&ws.cnt, sizeof(int) * (cap < 32 ? 32 : cap) * 64));      // up to 64 sub-lists per row
     PF_HIP(hipMalloc(&ws.cl, sizeof(unsigned long long) * cap * CAP));
     ws.cap_q = cap;
     ws.cap_c = CAP;
@@ -469,14 +469,18 @@ int search_topk(const float *db, const void *dbh, float xnorm_max, int64_t n, in
         if (launch_q_prep(q, nq, d, xnorm_max, ws.qh, ws.eps, s)) return -1;
         const float *ta = nullptr;
         for (int lev = levels; lev >= 1; --lev) {
-            if (launch_scan_f16(dbh, n, d, stride, ws.qh, nq, ta, ws, s)) return -1;
-            if (launch_select_rescore(ws, nq, k, 0, nullptr, nullptr, 0, q, db, d, s)) return -1;
+            int nsub = 1;
+            if (launch_scan_f16(dbh, n, d, stride, ws.qh, nq, ta, ws, true, &nsub, s)) return -1;
+            if (launch_select_rescore(ws, nq, k, 0, nullptr, nullptr, 0, q, db, d, nsub, s)) return -1;
             ta = ws.thr_adj;
             stride /= R;
         }
         for (int attempt = 0; attempt < 4; ++attempt) {
-            if (launch_scan_f16(dbh, n, d, 1, ws.qh, nq, ta, ws, s)) return -1;
-            if (launch_select_rescore(ws, nq, k, 1, D, I, label_base, q, db, d, s)) return -1;
+            int nsub = 1;
+            // a retry means some sub-list overflowed (e.g. hundreds of near-duplicate rows in one place):
+            // fall back to one list of CAP entries per row
+            if (launch_scan_f16(dbh, n, d, 1, ws.qh, nq, ta, ws, attempt == 0, &nsub, s)) return -1;
+            if (launch_select_rescore(ws, nq, k, 1, D, I, label_base, q, db, d, nsub, s)) return -1;
             int ovf = 0;
             PF_HIP(hipMemcpyAsync(&ovf, ws.overflow, sizeof(int), hipMemcpyDeviceToHost, s));
             PF_HIP(hipStreamSynchronize(s));

@@ -56,8 +56,8 @@ __device__ inline void bitonic_sort_u64(unsigned long long *s, int P, int tid, i
 int launch_rows_to_half(const float *x, int64_t n, int d, void *xh, float *norm_max_dev, hipStream_t s);
 int launch_q_prep(const float *q, int64_t nq, int d, float xnorm_max, void *qh, float *eps, hipStream_t s);
 int launch_scan_f16(const void *dbh, int64_t n, int d, int64_t stride, const void *qh, int64_t nq,
-                    const float *thr_adj, SearchWorkspace &ws, hipStream_t s);
+                    const float *thr_adj, SearchWorkspace &ws, bool allow_sublists, int *nsub_out, hipStream_t s);
 int launch_select_rescore(SearchWorkspace &ws, int64_t nq, int k, int mode, float *D, int64_t *I, int64_t label_base,
-                          const float *q32, const float *db32, int d, hipStream_t s);
+                          const float *q32, const float *db32, int d, int nsub, hipStream_t s);
 
 }  // namespace pfann

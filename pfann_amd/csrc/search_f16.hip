@@ -20,6 +20,7 @@
 // Reference precedent for fp16 search: faiss GpuMultipleClonerOptions.useFloat16
 // (database.py:102-104), there without re-scoring, i.e. approximate.
 #include "search_common.h"
+#include <stdlib.h>
 
 namespace pfann {
 
@@ -99,9 +100,12 @@ __global__ __launch_bounds__(256, 2) void scan_f16_kernel(ScanParams p) {
     const int col4 = tid & 7, rowq = tid >> 3;
     const unsigned row_bytes = (unsigned)p.d * 2u;             // one fp16 row
 
+    // thr_s = -(tau - eps): the accumulators START there, so the MFMA chain yields s16 - (tau - eps) and
+    // "survivor" is a sign test; query rows past nq start at -inf and never qualify
+    const bool dense = p.thr == nullptr;
     for (int i = tid; i < QT * BM; i += 256) {
         const int64_t m = (int64_t)mt0 * BM + i;
-        thr_s[i] = (p.thr != nullptr && m < p.nq) ? p.thr[m] : -INFINITY;
+        thr_s[i] = dense ? 0.f : (m < p.nq ? -p.thr[m] : -INFINITY);
     }
     const char *qb = reinterpret_cast<const char *>(p.q), *dbb = reinterpret_cast<const char *>(p.db);
     const int64_t mq0 = (int64_t)mt0 * BM;
@@ -156,13 +160,19 @@ __global__ __launch_bounds__(256, 2) void scan_f16_kernel(ScanParams p) {
 #pragma unroll 1
     for (int q = 0; q < n_q; ++q) {
         const int64_t m0 = mq0 + (int64_t)q * BM;
+        const float *thr_c = thr_s + q * BM;
         f32x16 acc[TM][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int g = 0; g < 4; ++g) {
+                // C rows of register 4g+e: wm*WM + i*32 + 8g + 4*lhalf + e
+                const f32x4 t4 = *reinterpret_cast<const f32x4 *>(thr_c + wm * WM + i * 32 + 8 * g + 4 * lhalf);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = t4[e];
+            }
 #pragma unroll 1
         for (int kt = 0; kt < nk; ++kt, ++it) {
             const float *Ac = As + (it & 1) * (BM * LDK), *Bc = Bs + (it & 1) * (BN * LDK);
@@ -191,7 +201,6 @@ __global__ __launch_bounds__(256, 2) void scan_f16_kernel(ScanParams p) {
             }
             __syncthreads();
         }
-        const float *thr_c = thr_s + q * BM;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int64_t n = n0 + wn * WN + j * 32 + l31;
@@ -199,32 +208,26 @@ __global__ __launch_bounds__(256, 2) void scan_f16_kernel(ScanParams p) {
             const unsigned row = (unsigned)(n * p.row_stride);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                if (p.thr == nullptr) {
+                if (dense) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int64_t m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
                         if (nok && m < p.nq) p.keys[m * CAP + n] = pack_key(acc[i][j][r], row);
                     }
                 } else {
+                    // fast reject: the largest of this lane's 16 values is negative (a handful of
+                    // v_max3 instead of 16 compares; about one survivor per 3000 values gets through)
+                    float mx = fmaxf(acc[i][j][0], acc[i][j][1]);
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int mlg = wm * WM + i * 32 + 8 * g + 4 * lhalf;
-                        const f32x4 th = *reinterpret_cast<const f32x4 *>(thr_c + mlg);
-                        bool sv[4];
-                        bool any = false;
+                    for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(mx, acc[i][j][r]), acc[i][j][r + 1]);
+                    if (__any(nok && mx >= 0.f)) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            sv[e] = nok && (m0 + mlg + e) < p.nq && acc[i][j][4 * g + e] >= th[e];
-                            any |= sv[e];
-                        }
-                        if (__any(any)) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                if (sv[e]) {
-                                    const int64_t m = m0 + mlg + e;
-                                    const int pos = atomicAdd(&p.cnt[m], 1);
-                                    if (pos < CAP) p.keys[m * CAP + pos] = pack_key(acc[i][j][4 * g + e], row);
-                                }
+                        for (int r = 0; r < 16; ++r) {
+                            if (nok && acc[i][j][r] >= 0.f) {
+                                const int ml = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                                const int64_t m = m0 + ml;
+                                const int pos = atomicAdd(&p.cnt[m], 1);
+                                if (pos < CAP) p.keys[m * CAP + pos] = pack_key(acc[i][j][r] - thr_c[ml], row);
                             }
                         }
                     }
@@ -235,13 +238,155 @@ __global__ __launch_bounds__(256, 2) void scan_f16_kernel(ScanParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Query-stationary fp16 scan (d = 16*KS <= 128, thresholds present).  A workgroup owns ONE 128-row
+// query tile and one of S interleaved slices of the db tiles:
+//   * the query tile lives in REGISTERS as MFMA A-fragments for the whole launch (64 VGPRs at
+//     d = 128), and so does -(tau - eps) of its rows, which is the C operand of every first MFMA:
+//     the chain yields s16 - (tau - eps) and "survivor" is a sign test on the max of a lane's 16
+//     results (a handful of v_max instead of 16 compares);
+//   * only the 32 KB db tile goes through LDS per step (double buffered, one barrier): half the
+//     LDS traffic and staging instructions per MFMA of the generic kernel above, which matters
+//     because with d this small the loop is bound by LDS and issue slots, not by the fp16 MFMA rate;
+//   * survivors go to the workgroup's OWN sub-list (query row, segment) with LDS counters; the
+//     15 million device-scope atomics of a db-stationary split cost 5 ms per pass on MI355X
+//     (measured) and are gone.  The select kernels gather the S sub-lists of a row.
+// ------------------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(256, 2) void scan_f16_qres_kernel(ScanParams p) {
+    constexpr int BM = 128, WM = 64, WN = 64, TM = 2, TN = 2;
+    constexpr int ROWB = KS * 32;                 // bytes of one fp16 row
+    constexpr int CPR = ROWB / 16;                // 16-byte chunks per row
+    constexpr int NLD = 128 * CPR / 256;          // direct-to-LDS loads per thread per db tile
+    __shared__ __attribute__((aligned(1024))) float Bs[2][128 * ROWB / 4];
+    __shared__ int s_cnt[BM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lhalf = lane >> 5;
+    const int S = p.nsub, subcap = CAP / S;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int seg = L / p.n_tiles_m, mt = L - seg * p.n_tiles_m;     // neighbours share the db segment (L2)
+    const int64_t m0 = (int64_t)mt * BM;
+    // db tiles seg, seg + S, seg + 2S, ...: interleaved, so a run of similar rows (one song) is spread
+    // over the sub-lists instead of overflowing one
+    const int64_t t_lo = seg, t_hi = (p.nrows + 127) / 128;
+    if (tid < BM) s_cnt[tid] = 0;
+    // this workgroup's sub-lists: row ml, slot pos -> keys[(m0 + ml) * CAP + seg * subcap + pos]
+    const __amdgpu_buffer_rsrc_t srd_k = make_srd(p.keys + m0 * CAP + (int64_t)seg * subcap, (unsigned long long)BM * CAP * 8ull);
+    const char *qb = reinterpret_cast<const char *>(p.q), *dbb = reinterpret_cast<const char *>(p.db);
+
+    // ---- A fragments: lane (l31, lhalf) holds k = 16*kk + 8*lhalf .. +7 of query row m0 + wm*64 + i*32 + l31
+    const __amdgpu_buffer_rsrc_t srd_q = make_srd(qb + m0 * ROWB, (unsigned long long)(p.nq - m0) * ROWB);
+    f16x8 afr[TM][KS];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+            afr[i][kk] = __builtin_bit_cast(f16x8, buf_load4(srd_q, (unsigned)(wm * WM + i * 32 + l31) * ROWB + kk * 32 + lhalf * 16));
+    // C operand: -(tau - eps) of C rows wm*64 + i*32 + 8g + 4*lhalf + e (register 4g + e); rows past nq: -inf
+    f32x16 cinit[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+            cinit[i][r] = m < p.nq ? -p.thr[m] : -INFINITY;
+        }
+
+    // ---- db-tile staging straight into LDS (global_load_lds_dwordx4: no staging registers, no
+    // ds_write pass).  The LDS image is lane-linear (wave-uniform base + lane*16), so rows cannot be
+    // padded; instead 16-byte chunk c of row r is FETCHED by the lane whose slot is c ^ key(r) and
+    // the fragment reads apply the same XOR: 16 consecutive rows hit 16 different bank groups.
+    //   instruction (wave, u) covers LDS chunks [(wave*NLD + u)*64, +64)
+    constexpr int RP = 256 / ROWB;                 // rows per 256 bytes of LDS (1 at d = 128, 2 at d = 64)
+    auto key = [](int r) { return (r / RP) & (CPR - 1); };
+    const int64_t last_row = (p.nrows - 1) * p.row_stride;
+    unsigned long long goff[NLD];                  // byte offset of this lane's chunk inside a tile (stride folded in)
+    int lrow[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+        const int ci = (wave * NLD + u) * 64 + lane;
+        const int r = ci / CPR, cs = ci % CPR;
+        lrow[u] = r;
+        goff[u] = (unsigned long long)r * p.row_stride * ROWB + (unsigned)((cs ^ key(r)) * 16);
+    }
+    auto load_tile = [&](int64_t t, int bb) {
+        const int64_t r0 = t * 128 * p.row_stride;
+        const char *base = dbb + r0 * ROWB;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            // rows past the end: fetch the last row instead (their columns are masked by `nok`)
+            const bool ok = t * 128 + lrow[u] < p.nrows;
+            const char *src = ok ? base + goff[u] : dbb + last_row * ROWB + (goff[u] & (ROWB - 1));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)&Bs[bb][(wave * NLD + u) * 256],
+                                             16, 0, 0);
+        }
+    };
+    if (t_lo < t_hi) load_tile(t_lo, 0);
+    __syncthreads();
+
+    int b = 0;
+#pragma unroll 1
+    for (int64_t t = t_lo; t < t_hi; t += S, b ^= 1) {
+        if (t + S < t_hi) load_tile(t + S, b ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            f16x8 b8[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = wn * WN + j * 32 + l31;
+                b8[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(
+                                                      &Bs[b][r * (ROWB / 4) + (((kk * 2 + lhalf) ^ key(r)) * 4)]));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[i][kk], b8[j], kk == 0 ? cinit[i] : acc[i][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int64_t n = t * 128 + wn * WN + j * 32 + l31;
+            const bool nok = n < p.nrows;
+            const unsigned rowid = (unsigned)(n * p.row_stride);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float mx = fmaxf(acc[i][j][0], acc[i][j][1]);
+#pragma unroll
+                for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(mx, acc[i][j][r]), acc[i][j][r + 1]);
+                if (__any(nok && mx >= 0.f)) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (nok && acc[i][j][r] >= 0.f) {
+                            const int ml = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                            const int pos = atomicAdd(&s_cnt[ml], 1);
+                            if (pos < subcap) {
+                                const unsigned long long key = pack_key(acc[i][j][r] - cinit[i][r], rowid);
+                                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, key), srd_k,
+                                                                      (ml * CAP + pos) * 8, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();                 // (waits for the tile in flight: vmcnt(0) precedes the barrier)
+    }
+    if (tid < BM && m0 + tid < p.nq) p.cnt[(m0 + tid) * S + seg] = s_cnt[tid];
+}
+
 __global__ void fill_int2_kernel(int *p, int v, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
 
 int launch_scan_f16(const void *dbh, int64_t n, int d, int64_t stride, const void *qh, int64_t nq,
-                    const float *thr_adj, SearchWorkspace &ws, hipStream_t s) {
+                    const float *thr_adj, SearchWorkspace &ws, bool allow_sublists, int *nsub_out, hipStream_t s) {
     ScanParams p;
     p.q = reinterpret_cast<const float *>(qh);
     p.db = reinterpret_cast<const float *>(dbh);
@@ -259,11 +404,23 @@ int launch_scan_f16(const void *dbh, int64_t n, int d, int64_t stride, const voi
     ProfScope ps(stride == 1 ? "scan_topk_f16" : "scan_topk_f16_sample", s, 2.0 * (double)nq * p.nrows * d);
     p.n_tiles_m = cdiv(nq, 128);
     const int64_t db_tiles = cdiv(p.nrows, 128);
-    if (db_tiles * cdiv(p.n_tiles_m, 4) >= 4096)
+    static const bool no_qres = getenv("PFANN_NO_QRES") != nullptr;
+    if (thr_adj != nullptr && allow_sublists && !no_qres && (d == 128 || d == 64) && nq >= 1024 && db_tiles >= 64) {
+        // S interleaved db slices: about four rounds of the 512 resident workgroups, sub-lists of >= 256
+        int S = (int)(2048 / p.n_tiles_m);
+        S = S < 1 ? 1 : (S > 32 ? 32 : S);
+        if (S > db_tiles) S = (int)db_tiles;
+        p.nsub = S;
+        PF_HIP(hipMemsetAsync(ws.cnt, 0, sizeof(int) * nq * S, s));
+        const dim3 grid((unsigned)(p.n_tiles_m * S));
+        if (d == 128) PF_LAUNCH((scan_f16_qres_kernel<8>), grid, dim3(256), 0, s, p);
+        else PF_LAUNCH((scan_f16_qres_kernel<4>), grid, dim3(256), 0, s, p);
+    } else if (db_tiles * cdiv(p.n_tiles_m, 4) >= 4096)
         PF_LAUNCH((scan_f16_kernel<4>), dim3((unsigned)(db_tiles * cdiv(p.n_tiles_m, 4))), dim3(256), 0, s, p);
     else
         PF_LAUNCH((scan_f16_kernel<1>), dim3((unsigned)(db_tiles * p.n_tiles_m)), dim3(256), 0, s, p);
     PF_HIP(hipGetLastError());
+    *nsub_out = p.nsub;
     return 0;
 }
 
@@ -278,20 +435,45 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(const unsigned lon
                                                               const float *__restrict__ eps, float *__restrict__ D,
                                                               int64_t *__restrict__ I, int64_t label_base,
                                                               int *overflow, const float *__restrict__ q32,
-                                                              const float *__restrict__ db32, int d) {
+                                                              const float *__restrict__ db32, int d, int nsub) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
     __shared__ int s_n2;
+    __shared__ int s_off[66];
     const int64_t m = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int n = cnt[m];
-    const bool over = n > CAP;
-    if (over) {
-        if (mode == 1 && tid == 0) atomicExch(overflow, 1);
-        n = CAP;
+    // gather the row's nsub sub-lists (sub-list g holds cnt[m*nsub+g] keys at keys[m*CAP + g*subcap])
+    const int subcap = CAP / nsub;
+    if (tid < 64) {
+        int c = tid < nsub ? cnt[m * nsub + tid] : 0;
+        const bool ov = c > subcap;
+        c = ov ? subcap : c;
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (tid >= o) incl += v;
+        }
+        s_off[tid + 1] = incl;
+        if (tid == 0) s_off[0] = 0;
+        const bool any_ov = __any(ov);
+        if (tid == 0) s_off[65] = any_ov ? 1 : 0;
     }
+    __syncthreads();
+    const int n = s_off[nsub];
+    const bool over = s_off[65] != 0;
+    if (over && mode == 1 && tid == 0) atomicExch(overflow, 1);
     int P = 1;
     while (P < n) P <<= 1;
-    for (int i = tid; i < P; i += 1024) skeys[i] = i < n ? keys[m * CAP + i] : ~0ull;
+    if (nsub == 1) {
+        for (int i = tid; i < n; i += 1024) skeys[i] = keys[m * CAP + i];
+    } else {
+        const int g = tid >> 4, l = tid & 15;      // 16 threads per sub-list
+        if (g < nsub) {
+            const int o = s_off[g], c = s_off[g + 1] - o;
+            for (int i = l; i < c; i += 16) skeys[o + i] = keys[m * CAP + g * subcap + i];
+        }
+    }
+    for (int i = n + tid; i < P; i += 1024) skeys[i] = ~0ull;
     __syncthreads();
     bitonic_sort_u64(skeys, P, tid, 1024);          // by approximate score, descending
     // candidates that can still belong to the exact top-k
@@ -331,7 +513,7 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(const unsigned lon
         if (tid == 0) {
             const float t = n2 >= k ? ord2f(~(unsigned)(skeys[k - 1] >> 32)) : -INFINITY;
             thr[m] = t;
-            thr_adj[m] = t - eps[m];
+            thr_adj[m] = fmaxf(t - eps[m], -1000.f * eps[m]);   // finite: below every possible score
         }
     } else {
         for (int i = tid; i < k; i += 1024) {
@@ -347,13 +529,13 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(const unsigned lon
         if (over && tid == 0 && n2 >= k) {          // raised threshold for the rescan
             const float t = ord2f(~(unsigned)(skeys[k - 1] >> 32));
             thr[m] = t;
-            thr_adj[m] = t - eps[m];
+            thr_adj[m] = fmaxf(t - eps[m], -1000.f * eps[m]);
         }
     }
 }
 
 int launch_select_rescore(SearchWorkspace &ws, int64_t nq, int k, int mode, float *D, int64_t *I, int64_t label_base,
-                          const float *q32, const float *db32, int d, hipStream_t s) {
+                          const float *q32, const float *db32, int d, int nsub, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         PF_HIP(hipFuncSetAttribute((const void *)select_rescore_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -363,7 +545,7 @@ int launch_select_rescore(SearchWorkspace &ws, int64_t nq, int k, int mode, floa
     ProfScope ps("topk_select_rescore", s);
     PF_LAUNCH(select_rescore_kernel, dim3((unsigned)nq), dim3(1024), CAP * 8, s,
                        reinterpret_cast<const unsigned long long *>(ws.cl), ws.cnt, k, mode, ws.thr, ws.thr_adj, ws.eps, D,
-                       I, label_base, ws.overflow, q32, db32, d);
+                       I, label_base, ws.overflow, q32, db32, d, nsub);
     PF_HIP(hipGetLastError());
     return 0;
 }

@@ -262,6 +262,33 @@ def test_search_topk_clustered_and_duplicate_rows(torch_cuda):
     _check_topk(torch_cuda, base.astype(np.float32), qb, 100, False)
 
 
+@pytest.mark.parametrize("n,d,nq,k", [(40000, 128, 1100, 100), (70001, 64, 1030, 20), (150000, 128, 2100, 300)])
+def test_search_topk_large_batch_sublists(torch_cuda, n, d, nq, k):
+    """nq >= 1024 takes the query-stationary fp16 scan (survivors in per-slice sub-lists, gathered
+    by the select kernel); same exact answer, including a ragged last query tile and db tile."""
+    db = synth.unit_rows(41, "t/lb%d" % n, n, d)
+    q = synth.unit_rows(42, "t/lbq%d" % n, nq, d)
+    q[::7] = db[(np.arange(len(q[::7])) * 911) % n] + 0.2 * q[::7]
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    _check_topk(torch_cuda, db.astype(np.float32), q.astype(np.float32), k, True)
+
+
+def test_search_topk_sublist_overflow_falls_back(torch_cuda):
+    """More near-identical rows inside ONE interleaved db slice than a sub-list holds (256 at 32
+    slices): the final pass must notice the overflow and redo the scan with one list per row."""
+    d, n, nq = 128, 60000, 1100
+    db = synth.unit_rows(43, "t/of", n, d)
+    c = synth.unit_rows(44, "t/ofc", 1, d)
+    for u in range(3):                                   # db tiles 5, 37, 69 all belong to slice 5 of 32
+        lo = (5 + 32 * u) * 128
+        db[lo:lo + 128] = c + 0.01 * db[lo:lo + 128]
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    q = synth.unit_rows(45, "t/ofq", nq, d)
+    q[:3] = c + 0.05 * q[:3]
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    _check_topk(torch_cuda, db.astype(np.float32), q.astype(np.float32), 300, True)
+
+
 def test_search_prefilter_near_ties_stay_exact(torch_cuda):
     """Adversarial for the fp16 pre-filter: thousands of rows whose exact scores differ by ~1e-6
     (far below fp16 resolution, 1e-3) around the k-th best.  The re-scoring window (2 eps below
