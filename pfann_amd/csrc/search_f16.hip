@@ -473,52 +473,100 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(const unsigned lon
             for (int i = l; i < c; i += 16) skeys[o + i] = keys[m * CAP + g * subcap + i];
         }
     }
-    for (int i = n + tid; i < P; i += 1024) skeys[i] = ~0ull;
     __syncthreads();
-    bitonic_sort_u64(skeys, P, tid, 1024);          // by approximate score, descending
-    // candidates that can still belong to the exact top-k
+    // candidates that can still belong to the exact top-k: s16 >= (k-th best s16) - 2 eps
     const float e2 = 2.0f * eps[m];
-    if (tid == 0) {
-        int n2 = n;
-        if (n > k) {
+    unsigned long long *ck = skeys;               // the candidates end up in ck[0 .. n2)
+    if (n <= k) {
+        if (tid == 0) s_n2 = n;
+    } else if (n <= CAP / 2) {
+        // k-th smallest key by MSB radix select on the 32 score bits (4 passes of 8 bits, LDS
+        // histogram), then compaction of everything above the cut: no sort of the ~16k survivors
+        __shared__ int hist[256];
+        __shared__ int s_bin, s_kk;
+        unsigned prefix = 0;
+        int kk = k;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            for (int i = tid; i < n; i += 1024) {
+                const unsigned hi = (unsigned)(skeys[i] >> 32);
+                if (pass == 0 || (hi >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(hi >> shift) & 255], 1);
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const int c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+                const int sum4 = c0 + c1 + c2 + c3;
+                int incl = sum4;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += v;
+                }
+                const int excl = incl - sum4;
+                if (excl < kk && kk <= incl) {          // exactly one lane
+                    int rem = kk - excl, bin = 4 * lane;
+                    if (rem > c0) { rem -= c0; ++bin; if (rem > c1) { rem -= c1; ++bin; if (rem > c2) { rem -= c2; ++bin; } } }
+                    s_bin = bin;
+                    s_kk = rem;
+                }
+            }
+            __syncthreads();
+            prefix |= (unsigned)s_bin << shift;
+            kk = s_kk;
+        }
+        const float cut = ord2f(~prefix) - e2;
+        const unsigned cut_hi = ~f2ord(cut);         // score >= cut  <=>  key's high word <= cut_hi
+        ck = skeys + CAP / 2;
+        if (tid == 0) s_n2 = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += 1024) {
+            const unsigned long long key = skeys[i];
+            if ((unsigned)(key >> 32) <= cut_hi) ck[atomicAdd(&s_n2, 1)] = key;
+        }
+    } else {
+        for (int i = n + tid; i < P; i += 1024) skeys[i] = ~0ull;
+        __syncthreads();
+        bitonic_sort_u64(skeys, P, tid, 1024);      // by approximate score, descending
+        if (tid == 0) {
             const float cut = ord2f(~(unsigned)(skeys[k - 1] >> 32)) - e2;
             int lo = k, hi = n;                   // first index whose score < cut
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
                 if (ord2f(~(unsigned)(skeys[mid] >> 32)) >= cut) lo = mid + 1; else hi = mid;
             }
-            n2 = lo;
+            s_n2 = lo;
         }
-        s_n2 = n2;
     }
     __syncthreads();
     const int n2 = s_n2;
     // exact fp32 scores: one wave per candidate, coalesced row reads, fixed reduction order
     const float *qv = q32 + m * d;
     for (int c = wave; c < n2; c += 16) {
-        const unsigned row = (unsigned)(skeys[c] & 0xFFFFFFFFull);
+        const unsigned row = (unsigned)(ck[c] & 0xFFFFFFFFull);
         const float *xv = db32 + (int64_t)row * d;
         float part = 0.f;
         for (int e = lane; e < d; e += 64) part = fmaf(xv[e], qv[e], part);
         part = wave_sum(part);
-        if (lane == 0) skeys[c] = pack_key(part, row);
+        if (lane == 0) ck[c] = pack_key(part, row);
     }
     __syncthreads();
     int P2 = 1;
     while (P2 < n2) P2 <<= 1;
-    for (int i = n2 + tid; i < P2; i += 1024) skeys[i] = ~0ull;     // entries beyond n2 can no longer matter
+    for (int i = n2 + tid; i < P2; i += 1024) ck[i] = ~0ull;     // entries beyond n2 can no longer matter
     __syncthreads();
-    bitonic_sort_u64(skeys, P2, tid, 1024);         // by exact score, descending
+    bitonic_sort_u64(ck, P2, tid, 1024);         // by exact score, descending
     if (mode == 0) {
         if (tid == 0) {
-            const float t = n2 >= k ? ord2f(~(unsigned)(skeys[k - 1] >> 32)) : -INFINITY;
+            const float t = n2 >= k ? ord2f(~(unsigned)(ck[k - 1] >> 32)) : -INFINITY;
             thr[m] = t;
             thr_adj[m] = fmaxf(t - eps[m], -1000.f * eps[m]);   // finite: below every possible score
         }
     } else {
         for (int i = tid; i < k; i += 1024) {
             if (i < n2) {
-                const unsigned long long key = skeys[i];
+                const unsigned long long key = ck[i];
                 D[m * k + i] = ord2f(~(unsigned)(key >> 32));
                 I[m * k + i] = (int64_t)(unsigned)(key & 0xFFFFFFFFu) + label_base;
             } else {
@@ -527,7 +575,7 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(const unsigned lon
             }
         }
         if (over && tid == 0 && n2 >= k) {          // raised threshold for the rescan
-            const float t = ord2f(~(unsigned)(skeys[k - 1] >> 32));
+            const float t = ord2f(~(unsigned)(ck[k - 1] >> 32));
             thr[m] = t;
             thr_adj[m] = fmaxf(t - eps[m], -1000.f * eps[m]);
         }
