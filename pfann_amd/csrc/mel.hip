@@ -72,6 +72,13 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs a) {
         denom = fmaxf(t, 1e-12f);
     }
 
+    // each wave owns its FFT buffers: LDS operations of one wave execute in order, so a wave-level
+    // fence (no s_barrier) is all the stages need
+    auto wave_sync = []() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
     float *zre = fre + wave * M, *zim = fim + wave * M, *pwr = pw + wave * (M + 4);
     const int n_groups = (a.n_frames + 3) >> 2;
     for (int g = 0; g < n_groups; ++g) {
@@ -100,7 +107,7 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs a) {
             zre[r] = v[0];
             zim[r] = v[1];
         }
-        __syncthreads();
+        wave_sync();
         // ---- radix-2 DIT stages
         for (int s = 1; s <= log2m; ++s) {
             const int half = 1 << (s - 1);
@@ -115,7 +122,7 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs a) {
                 zre[i0] = ur + tr; zim[i0] = ui + ti;
                 zre[i1] = ur - tr; zim[i1] = ui - ti;
             }
-            __syncthreads();
+            wave_sync();
         }
         // ---- real-FFT split + power:  X[k] = E[k] + W_N^k O[k],  k = 0..M
         for (int k = lane; k <= M; k += 64) {
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs a) {
             const float p2 = xr * xr + xi * xi;
             pwr[k] = a.power == 2 ? p2 : sqrtf(p2);
         }
-        __syncthreads();
+        wave_sync();
         // ---- sparse mel + log into the LDS tile
         if (live) {
             for (int m = lane; m < a.n_mels; m += 64) {
@@ -143,8 +150,9 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs a) {
                 tile[m * (a.n_frames + 1) + t] = acc;
             }
         }
-        __syncthreads();
+        wave_sync();
     }
+    __syncthreads();                      // the [n_mels][n_frames] tile is complete
     // ---- spec_norm == 'max': subtract the tile maximum (melspec.py:48-49)
     float sub = 0.f;
     if (a.spec_norm_max) {
