@@ -303,72 +303,60 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][s], b4[j][s], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[j][s], a4[i][s], acc[i][j], 0, 0, 0);   // C^T: rows = n
         }
         __syncthreads();
     }
 
     // ---- epilogue: z = PRE(acc + bias) -> HBM; per-sample partial statistics -------------
-    // C layout of a 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // The MFMAs computed C^T (weights as the A operand), so in a 32x32 tile a lane holds ONE output row
+    // m = lane&31 and the columns n = 8g + 4*(lane>>5) + e for register 4g + e: four consecutive channels
+    // per register quad, stored with one dwordx4 (the texture addresser takes as long for a 64-lane dword
+    // store as for a dwordx4 one; scalar stores made the epilogue 6 % of the kernel).
     const __amdgpu_buffer_rsrc_t srd_y = make_srd(p.y + (int64_t)m0 * p.N, (unsigned long long)(p.M - m0) * p.N * 4ull);
+    const __amdgpu_buffer_rsrc_t srd_bias = make_srd(p.bias, (unsigned long long)p.N * 4ull);
     float *red1 = As;                 // [BM][WAVES_N] row (or sub-tile) sums; As/Bs are free now
     float *red2 = As + BM * WAVES_N;
     const int G = rps >= BM ? BM : rps;          // rows per statistics group inside the tile
-    // No validity selects: columns n >= N have zero weights and bias (z = 0 adds nothing to the sums) and
-    // an out-of-range store offset; rows m >= M lie beyond srd_y and form whole statistics groups
-    // (M is a multiple of G) that are never written out.
-    float bv[TN];
-    unsigned cb[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WN + j * 32 + l31;
-        bv[j] = n < p.N ? p.bias[n] : 0.f;
-        cb[j] = n < p.N ? (unsigned)n * 4u : BUF_OOB;
-    }
-    const unsigned rowbytes = (unsigned)p.N * 4u, rowbytes5 = 5u * rowbytes;
+    // No validity selects: columns n >= N (N % 4 == 0) have zero weights and bias (z = 0 adds nothing to
+    // the sums) and an out-of-range store offset; rows m >= M lie beyond srd_y and form whole statistics
+    // groups (M is a multiple of G) that are never written out.
+    const unsigned rowbytes = (unsigned)p.N * 4u;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        float rs1[16], rs2[16];
-        unsigned vo[TN];                 // running store offset: C rows of a lane go 0,1,2,3, 8,9,10,11, ...
+        float a1 = 0.f, a2 = 0.f;        // this lane's row m = wm*WM + i*32 + l31
+        const unsigned ro = (unsigned)(wm * WM + i * 32 + l31) * rowbytes;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) vo[j] = cb[j] + (unsigned)(wm * WM + i * 32 + 4 * lhalf) * rowbytes;
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float a1, a2;
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * WN + j * 32 + 8 * g + 4 * lhalf;
+                const unsigned nb = n < p.N ? (unsigned)n * 4u : BUF_OOB;
+                const f32x4 b4v = buf_load4(srd_bias, nb);
+                f32x4 z4;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                float z = acc[i][j][r] + bv[j];
-                if (!RELU_BN && !p.after_bn) z = act_fn(z, p.act);
-                if (j == 0) { a1 = z; a2 = z * z; }
-                else { a1 += z; a2 = fmaf(z, z, a2); }
-                buf_store1(srd_y, vo[j], z);
-                vo[j] += (r & 3) == 3 ? rowbytes5 : rowbytes;
-            }
-            rs1[r] = a1; rs2[r] = a2;
-        }
-        if (G >= 32) {
-            // the whole 32-row sub-tile belongs to one sample: registers first, then the wave
-            float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { t1 += rs1[r]; t2 += rs2[r]; }
-            t1 = wave_sum(t1); t2 = wave_sum(t2);
-            if (lane == 0) {
-                red1[(wm * WM + i * 32) * WAVES_N + wn] = t1;
-                red2[(wm * WM + i * 32) * WAVES_N + wn] = t2;
-            }
-        } else {
-            // several samples inside the sub-tile: per-row sums across the 32 lanes of a half
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float t1 = rs1[r], t2 = rs2[r];
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o, 64); t2 += __shfl_xor(t2, o, 64); }
-                if (l31 == 0) {
-                    const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-                    red1[row * WAVES_N + wn] = t1;
-                    red2[row * WAVES_N + wn] = t2;
+                for (int e = 0; e < 4; ++e) {
+                    float z = acc[i][j][4 * g + e] + b4v[e];
+                    if (!RELU_BN && !p.after_bn) z = act_fn(z, p.act);
+                    a1 += z;
+                    a2 = fmaf(z, z, a2);
+                    z4[e] = z;
                 }
+                buf_store4(srd_y, nb + ro, z4);
             }
+        a1 += __shfl_xor(a1, 32, 64);    // the other half of the row's columns
+        a2 += __shfl_xor(a2, 32, 64);
+        if (G >= 32) {
+            // the whole 32-row sub-tile belongs to one sample
+            a1 = wave_sum_half(a1); a2 = wave_sum_half(a2);
+            if (lane == 0) {
+                red1[(wm * WM + i * 32) * WAVES_N + wn] = a1;
+                red2[(wm * WM + i * 32) * WAVES_N + wn] = a2;
+            }
+        } else if (lhalf == 0) {
+            // several samples inside the sub-tile: per-row sums
+            red1[(wm * WM + i * 32 + l31) * WAVES_N + wn] = a1;
+            red2[(wm * WM + i * 32 + l31) * WAVES_N + wn] = a2;
         }
     }
     __syncthreads();
@@ -443,7 +431,7 @@ bool fused_supported(const SubLayer *sub, int n) {
         if (L.depthwise) return false;
         if (rps & (rps - 1)) return false;                  // power of two: tiles never straddle samples unevenly
         if (L.ci == 1) { if (i != 0 || rps % 64 || L.co % 4) return false; }
-        else if (L.ci % 4) return false;
+        else if (L.ci % 4 || L.co % 4) return false;
     }
     return true;
 }
