@@ -192,14 +192,15 @@ def main():
             kernels[tag] = {"ms_per_step": ms / args.steps, "launches_per_step": cnt.value / args.steps,
                             "avg_us": 1e3 * ms / max(cnt.value, 1), "work_per_launch": work / max(cnt.value, 1)}
     # roofline of the dominant kernel (most time in the timed region)
-    ROOF = {"conv_gemm_ln_128": ("pfann::conv_gemm_ln_kernel<128,128,64,64> (implicit-GEMM conv with LayerNorm+ReLU "
-                                 "of its input fused into the A-loader and LN statistics of its output in the epilogue)", "mfma"),
+    ROOF = {"conv_gemm_ln_128": ("pfann::conv_gemm_ln_kernel<128,128,64,32,...> (implicit-GEMM conv with LayerNorm+ReLU "
+                                 "of its input fused into the A-loader and LN statistics of its output in the epilogue; "
+                                 "all instantiations, incl. the one with the first conv folded in)", "mfma"),
             "conv_gemm_ln_64": ("pfann::conv_gemm_ln_kernel<64,64,32,32>", "mfma"),
             "conv_first_stats": ("pfann::conv_first_stats_kernel", "hbm"),
             "conv_gemm_128": ("pfann::conv_gemm_kernel<128,128,64,64>", "mfma"),
             "conv_gemm_64": ("pfann::conv_gemm_kernel<64,64,32,32>", "mfma"),
             "scan_topk": ("pfann::scan_emit_kernel (full-db pass)", "mfma"),
-            "scan_topk_f16": ("pfann::scan_f16_kernel (fp16 pre-filter pass; exact fp32 re-scoring follows)", "mfma16"),
+            "scan_topk_f16": ("pfann::scan_f16_qres_kernel (fp16 pre-filter pass; exact fp32 re-scoring follows)", "mfma16"),
             "ln_act": ("pfann::ln_act_kernel", "hbm"), "conv_first": ("pfann::conv_first_kernel", "hbm")}
     for tag, kv in kernels.items():
         if tag in ROOF and kv["work_per_launch"] > 0:
@@ -232,8 +233,10 @@ def main():
         try:
             tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
             key = ROOF[dom][0].split("<")[0].split(" ")[0]
-            tmpl = ROOF[dom][0].split(" ")[0].replace(",", ", ")
-            for name, rec in tj.items():
+            tmpl = ROOF[dom][0].split(" ")[0].replace(",...>", "").replace(",", ", ")
+            names = sorted(tj, key=lambda nm: "all instantiations" not in nm)     # prefer the combined record
+            for name in names:
+                rec = tj[name]
                 if name.replace("void ", "").startswith(tmpl.split(">")[0]) or (key in name and "<" not in tmpl):
                     roofline["traffic"] = rec["hbm_bytes_per_launch"]
                     roofline["traffic_source"] = "%s PMC FETCH_SIZE x2 + WRITE_SIZE (%s)" % (rec["source"], name[:60])

@@ -14,7 +14,7 @@ def parse(path, counter):
     for ln in open(path):
         m = re.match(r"(.*?)\s+%s\s+dispatches=(\d+)\s+sum=(\S+)\s+per_dispatch=(\S+)" % counter, ln)
         if m:
-            out[m.group(1).strip()] = float(m.group(4))
+            out[m.group(1).strip()] = (float(m.group(4)), int(m.group(2)))
     return out
 
 
@@ -22,9 +22,27 @@ def main(d):
     fe, wr = parse(d + "/pmc_fetch.txt", "FETCH_SIZE"), parse(d + "/pmc_write.txt", "WRITE_SIZE")
     res = {}
     for k in fe:
-        res[k] = {"fetch_size_kb_per_launch": fe[k], "write_size_kb_per_launch": wr.get(k, 0.0),
-                  "hbm_bytes_per_launch": (2.0 * fe[k] + wr.get(k, 0.0)) * 1024.0,
+        f, nd = fe[k]
+        w = wr.get(k, (0.0, 0))[0]
+        res[k] = {"fetch_size_kb_per_launch": f, "write_size_kb_per_launch": w, "dispatches": nd,
+                  "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0,
                   "correction": "FETCH_SIZE x2 (gfx950, 16 B/lane loads), WRITE_SIZE x1", "source": d}
+    # template instantiations of one kernel that bench.py times under one tag (e.g. the fused GEMM with
+    # and without the folded first conv): launch-weighted average
+    groups = {}
+    for k, r in res.items():
+        m = re.match(r"(?:void )?(pfann::\w+<\d+, \d+)", k)
+        if m:
+            groups.setdefault(m.group(1), []).append(r)
+    for g, rs in groups.items():
+        if len(rs) > 1:
+            nd = sum(r["dispatches"] for r in rs)
+            res[g + ", ...> (all instantiations)"] = {
+                "dispatches": nd, "source": d,
+                "fetch_size_kb_per_launch": sum(r["fetch_size_kb_per_launch"] * r["dispatches"] for r in rs) / nd,
+                "write_size_kb_per_launch": sum(r["write_size_kb_per_launch"] * r["dispatches"] for r in rs) / nd,
+                "hbm_bytes_per_launch": sum(r["hbm_bytes_per_launch"] * r["dispatches"] for r in rs) / nd,
+                "correction": "FETCH_SIZE x2 (gfx950, 16 B/lane loads), WRITE_SIZE x1; launch-weighted over instantiations"}
     json.dump(res, open("profiles/traffic.json", "w"), indent=1, sort_keys=True)
     print(json.dumps(res, indent=1)[:1500])
 
