@@ -48,7 +48,9 @@ def main():
     ap.add_argument("--db-songs", type=int, default=16950, help="16950 x 59 = 1,000,050 segments")
     ap.add_argument("--real-songs", type=int, default=48)
     ap.add_argument("--snr", type=float, default=0.0)
-    ap.add_argument("--max-batch", type=int, default=4864)
+    ap.add_argument("--max-batch", type=int, default=9728,
+                    help="encoder chunk (segments); 9728 = the whole step in one chunk: 29 GB of activations, and the\n"
+                         "small late layers get enough 128x128 tiles to fill the 512 resident workgroups")
     ap.add_argument("--cpu-queries", type=int, default=12, help="bounded sample for the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
