@@ -346,35 +346,34 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
             }
         a1 += __shfl_xor(a1, 32, 64);    // the other half of the row's columns
         a2 += __shfl_xor(a2, 32, 64);
-        if (G >= 32) {
-            // the whole 32-row sub-tile belongs to one sample
-            a1 = wave_sum_half(a1); a2 = wave_sum_half(a2);
-            if (lane == 0) {
-                red1[(wm * WM + i * 32) * WAVES_N + wn] = a1;
-                red2[(wm * WM + i * 32) * WAVES_N + wn] = a2;
-            }
-        } else if (lhalf == 0) {
-            // several samples inside the sub-tile: per-row sums
+        if (lhalf == 0) {                // per-row sums of this wave's column range
             red1[(wm * WM + i * 32 + l31) * WAVES_N + wn] = a1;
             red2[(wm * WM + i * 32 + l31) * WAVES_N + wn] = a2;
         }
     }
     __syncthreads();
-    {
-        const int ngroups = BM / G;
-        if (tid < ngroups) {
-            const int mg = m0 + tid * G;
-            if (mg < p.M) {
-                float t1 = 0.f, t2 = 0.f;
-                const int step = G >= 32 ? 32 : 1;
-                for (int row = tid * G; row < (tid + 1) * G; row += step)
-                    for (int w = 0; w < WAVES_N; ++w) { t1 += red1[row * WAVES_N + w]; t2 += red2[row * WAVES_N + w]; }
-                const int b = mg >> p.rps_shift;
-                const int slot = ((mg & (rps - 1)) / G) * p.n_tiles_n + nt;
-                float *o = p.out_part + ((int64_t)b * p.out_P + slot) * 2;
-                o[0] = t1;
-                o[1] = t2;
-            }
+    // rows -> statistics groups of G rows (one per sample touched), in a fixed order: thread r owns row r
+    float t1 = 0.f, t2 = 0.f;
+    if (tid < BM) {
+#pragma unroll
+        for (int w = 0; w < WAVES_N; ++w) { t1 += red1[tid * WAVES_N + w]; t2 += red2[tid * WAVES_N + w]; }
+        for (int o = (G < 64 ? G : 64) >> 1; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o, 64); t2 += __shfl_xor(t2, o, 64); }
+    }
+    if (G > 64) {                        // BM = G = 128: one group spanning two waves
+        float *x2 = As + 2 * BM * WAVES_N;
+        if (tid < BM && lane == 0) { x2[2 * wave] = t1; x2[2 * wave + 1] = t2; }
+        __syncthreads();
+        t1 = x2[0] + x2[2];
+        t2 = x2[1] + x2[3];
+    }
+    if (tid < BM && (tid & (G - 1)) == 0) {
+        const int mg = m0 + tid;
+        if (mg < p.M) {
+            const int b = mg >> p.rps_shift;
+            const int slot = ((mg & (rps - 1)) / G) * p.n_tiles_n + nt;
+            float *o = p.out_part + ((int64_t)b * p.out_P + slot) * 2;
+            o[0] = t1;
+            o[1] = t2;
         }
     }
 }
