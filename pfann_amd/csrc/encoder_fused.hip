@@ -687,54 +687,97 @@ int launch_ln_apply(const SubLayer &L, const float *z, const float *part, int P,
 // ------------------------------------------------------------------------------------
 // Projection head with the last LayerNorm(+act) applied on load.
 // ------------------------------------------------------------------------------------
+// SEG segments per workgroup: thread g (one output dimension) keeps its v inputs of each segment in
+// registers and walks its u hidden units once, so every weight row is loaded once per SEG segments
+// (float4 loads when v % 4 == 0) instead of once per segment.
+template <int SEG, int VMAX>
 __global__ void myg_ln_kernel(const float *__restrict__ z, const float *__restrict__ part, int P,
                               const float *__restrict__ lw, const float *__restrict__ lb, int act, int after_bn,
                               const float *__restrict__ w1, const float *__restrict__ b1,
                               const float *__restrict__ w2, const float *__restrict__ b2, int d, int u, int v,
-                              float *__restrict__ emb, int normalize) {
-    __shared__ float red[16];
-    __shared__ float stat[2];
+                              float *__restrict__ emb, int normalize, int64_t B) {
+    __shared__ float red[SEG][16];
+    __shared__ float stat[SEG][2];
     const int g = threadIdx.x;
     const int h = d * v;
-    if (g == 0) {
-        const float *pp = part + (int64_t)blockIdx.x * P * 2;
+    const int64_t seg0 = (int64_t)blockIdx.x * SEG;
+    if (g < SEG && seg0 + g < B) {
+        const float *pp = part + (seg0 + g) * P * 2;
         double s1 = 0, s2 = 0;
         for (int i = 0; i < P; ++i) { s1 += (double)pp[2 * i]; s2 += (double)pp[2 * i + 1]; }
         const double mean = s1 / h;
         double var = s2 / h - mean * mean;
         if (var < 0) var = 0;
-        stat[0] = (float)mean;
-        stat[1] = (float)(1.0 / sqrt(var + 1e-5));
+        stat[g][0] = (float)mean;
+        stat[g][1] = (float)(1.0 / sqrt(var + 1e-5));
     }
     __syncthreads();
-    const float mean = stat[0], rstd = stat[1];
-    const float *xs = z + (int64_t)blockIdx.x * h;
-    float y = 0.f;
+    float y[SEG];
+#pragma unroll
+    for (int sg = 0; sg < SEG; ++sg) y[sg] = 0.f;
     if (g < d) {
-        float xin[32];
-        for (int j = 0; j < v; ++j) {
-            const float t = (xs[g * v + j] - mean) * rstd * lw[g * v + j] + lb[g * v + j];
-            xin[j] = after_bn ? act_fn(t, act) : t;
+        float xin[SEG][VMAX];
+#pragma unroll
+        for (int sg = 0; sg < SEG; ++sg) {
+            const bool ok = seg0 + sg < B;
+            const float mean = ok ? stat[sg][0] : 0.f, rstd = ok ? stat[sg][1] : 0.f;
+            const float *xs = z + (seg0 + sg) * h;
+#pragma unroll
+            for (int j = 0; j < VMAX; ++j) {
+                float t = 0.f;
+                if (ok && j < v) {
+                    t = (xs[g * v + j] - mean) * rstd * lw[g * v + j] + lb[g * v + j];
+                    t = after_bn ? act_fn(t, act) : t;
+                }
+                xin[sg][j] = t;
+            }
         }
         for (int k = 0; k < u; ++k) {
             const float *wr = w1 + ((int64_t)g * u + k) * v;
-            float hsum = 0.f;
-            for (int j = 0; j < v; ++j) hsum = fmaf(wr[j], xin[j], hsum);
-            hsum += b1[g * u + k];
-            hsum = hsum > 0.f ? hsum : expm1f(hsum);
-            y = fmaf(w2[g * u + k], hsum, y);
+            float wv[VMAX];
+            if ((v & 3) == 0) {
+#pragma unroll
+                for (int j = 0; j < VMAX; j += 4)
+                    if (j < v) {
+                        const float4 t = *reinterpret_cast<const float4 *>(wr + j);
+                        wv[j] = t.x; wv[j + 1] = t.y; wv[j + 2] = t.z; wv[j + 3] = t.w;
+                    }
+            } else {
+#pragma unroll
+                for (int j = 0; j < VMAX; ++j) wv[j] = j < v ? wr[j] : 0.f;
+            }
+            const float bb = b1[g * u + k], ww = w2[g * u + k];
+#pragma unroll
+            for (int sg = 0; sg < SEG; ++sg) {
+                float hsum = 0.f;
+#pragma unroll
+                for (int j = 0; j < VMAX; ++j)
+                    if (j < v) hsum = fmaf(wv[j], xin[sg][j], hsum);
+                hsum += bb;
+                hsum = hsum > 0.f ? hsum : expm1f(hsum);
+                y[sg] = fmaf(ww, hsum, y[sg]);
+            }
         }
-        y += b2[g];
+#pragma unroll
+        for (int sg = 0; sg < SEG; ++sg) y[sg] += b2[g];
     }
     if (normalize) {
-        float ss = wave_sum(g < d ? y * y : 0.f);
-        if ((g & 63) == 0) red[g >> 6] = ss;
+#pragma unroll
+        for (int sg = 0; sg < SEG; ++sg) {
+            const float ss = wave_sum(g < d ? y[sg] * y[sg] : 0.f);
+            if ((g & 63) == 0) red[sg][g >> 6] = ss;
+        }
         __syncthreads();
-        float tot = 0.f;
-        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) tot += red[i];
-        y = y / fmaxf(sqrtf(tot), 1e-12f);
+#pragma unroll
+        for (int sg = 0; sg < SEG; ++sg) {
+            float tot = 0.f;
+            for (int i = 0; i < (int)(blockDim.x >> 6); ++i) tot += red[sg][i];
+            y[sg] = y[sg] / fmaxf(sqrtf(tot), 1e-12f);
+        }
     }
-    if (g < d) emb[(int64_t)blockIdx.x * d + g] = y;
+#pragma unroll
+    for (int sg = 0; sg < SEG; ++sg)
+        if (g < d && seg0 + sg < B) emb[(seg0 + sg) * d + g] = y[sg];
 }
 
 int launch_myg_ln(const SubLayer &Llast, const float *z, const float *part, int P, int act, int after_bn,
@@ -744,8 +787,12 @@ int launch_myg_ln(const SubLayer &Llast, const float *z, const float *part, int 
     const int nt = ((d + 63) / 64) * 64;
     if (nt > 1024) { set_error("MyG: d = %d > 1024 unsupported", d); return -1; }
     ProfScope ps("myg_ln", s);
-    PF_LAUNCH(myg_ln_kernel, dim3((unsigned)B), dim3(nt), 0, s, z, part, P, Llast.ln_w, Llast.ln_b, act,
-                       after_bn, w1, b1, w2, b2, d, u, v, emb, normalize);
+    if (v <= 8)
+        PF_LAUNCH((myg_ln_kernel<4, 8>), dim3((unsigned)cdiv(B, 4)), dim3(nt), 0, s, z, part, P, Llast.ln_w, Llast.ln_b, act,
+                  after_bn, w1, b1, w2, b2, d, u, v, emb, normalize, B);
+    else
+        PF_LAUNCH((myg_ln_kernel<1, 32>), dim3((unsigned)B), dim3(nt), 0, s, z, part, P, Llast.ln_w, Llast.ln_b, act,
+                  after_bn, w1, b1, w2, b2, d, u, v, emb, normalize, B);
     PF_HIP(hipGetLastError());
     return 0;
 }
