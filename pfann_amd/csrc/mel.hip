@@ -25,6 +25,31 @@ struct MelArgs {
 
 __device__ __forceinline__ unsigned bitrev(unsigned x, int bits) { return __brev(x) >> (32 - bits); }
 
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }          // a * (-i)
+
+// forward 8-point DFT in registers (radix-2 DIF), natural order in and out
+__device__ __forceinline__ void dft8(float2 (&a)[8]) {
+    const float c = 0.70710678118654752440f;
+    float2 u[8], v[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { u[j] = cadd(a[j], a[j + 4]); u[j + 4] = csub(a[j], a[j + 4]); }
+    u[5] = make_float2(c * (u[5].x + u[5].y), c * (u[5].y - u[5].x));       // * W8^1 = c(1 - i)
+    u[6] = mul_mi(u[6]);                                                    // * W8^2 = -i
+    u[7] = make_float2(c * (u[7].y - u[7].x), -c * (u[7].x + u[7].y));      // * W8^3 = -c(1 + i)
+#pragma unroll
+    for (int h = 0; h < 8; h += 4) {
+        v[h] = cadd(u[h], u[h + 2]); v[h + 2] = csub(u[h], u[h + 2]);
+        v[h + 1] = cadd(u[h + 1], u[h + 3]); v[h + 3] = mul_mi(csub(u[h + 1], u[h + 3]));
+    }
+    a[0] = cadd(v[0], v[1]); a[4] = csub(v[0], v[1]);
+    a[2] = cadd(v[2], v[3]); a[6] = csub(v[2], v[3]);
+    a[1] = cadd(v[4], v[5]); a[5] = csub(v[4], v[5]);
+    a[3] = cadd(v[6], v[7]); a[7] = csub(v[6], v[7]);
+}
+
 __global__ __launch_bounds__(256) void melspec_kernel(MelArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int M = a.n_fft >> 1;           // complex FFT length
@@ -33,9 +58,9 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs a) {
     // LDS carve-up
     float *tw_re = smem;                  // [M]   exp(-2*pi*i*j/n_fft), j < M
     float *tw_im = tw_re + M;             // [M]
-    float *fre = tw_im + M;               // [4][M]
-    float *fim = fre + 4 * M;             // [4][M]
-    float *pw = fim + 4 * M;              // [4][M+4]  power spectrum per wave
+    const int WSZ = 2 * M > 1152 ? 2 * M : 1152;
+    float *work = tw_im + M;              // [4][WSZ]  per-wave FFT buffer (re[M], im[M]; radix-8 path: 576 float2)
+    float *pw = work + 4 * WSZ;           // [4][M+4]  power spectrum per wave
     float *tile = pw + 4 * (M + 4);       // [n_mels][n_frames+1]
     float *red = tile + a.n_mels * (a.n_frames + 1);  // [8]
 
@@ -79,50 +104,112 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs a) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    float *zre = fre + wave * M, *zim = fim + wave * M, *pwr = pw + wave * (M + 4);
+    float *zre = work + wave * WSZ, *zim = zre + M, *pwr = pw + wave * (M + 4);
+    const bool radix8 = a.n_fft == 1024;
     const int n_groups = (a.n_frames + 3) >> 2;
     for (int g = 0; g < n_groups; ++g) {
         const int t = g * 4 + wave;
         const bool live = t < a.n_frames;
-        // ---- gather frame (reflect / zero padding), normalise, window; write bit-reversed
-        for (int m = lane; m < M; m += 64) {
-            float v[2];
+        if (radix8) {
+            // ---- 512-point complex FFT as 8 x 8 x 8, eight points per lane in registers, two LDS
+            // transposes (Cooley-Tukey n = 64 n1 + n2, then n2 = 8 a + b); the frame is gathered straight
+            // into registers (lane = n2), no bit-reversal pass
+            float2 *tb = reinterpret_cast<float2 *>(zre);            // [8][72] float2 (pitch 72: conflict-free reads)
+            auto twid = [&](int e2) {                                 // W_1024^e2, 0 <= e2 < 1024
+                const int j = e2 & 511;
+                const float sg = e2 >= 512 ? -1.f : 1.f;
+                return make_float2(sg * tw_re[j], sg * tw_im[j]);
+            };
+            float2 v[8];
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int n = 2 * m + e;
-                int idx = t * a.hop - M + n;
-                float s = 0.f;
-                if (live) {
-                    if (a.pad_reflect) {
-                        if (idx < 0) idx = -idx;
-                        if (idx > a.seg_len - 1) idx = 2 * (a.seg_len - 1) - idx;
-                        s = (x[idx] - mean) / denom;
-                    } else if (idx >= 0 && idx < a.seg_len) {
-                        s = (x[idx] - mean) / denom;
+            for (int n1 = 0; n1 < 8; ++n1) {
+                const int m = 64 * n1 + lane;
+                float w[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int n = 2 * m + e;
+                    int idx = t * a.hop - M + n;
+                    float s = 0.f;
+                    if (live) {
+                        if (a.pad_reflect) {
+                            if (idx < 0) idx = -idx;
+                            if (idx > a.seg_len - 1) idx = 2 * (a.seg_len - 1) - idx;
+                            s = (x[idx] - mean) / denom;
+                        } else if (idx >= 0 && idx < a.seg_len) {
+                            s = (x[idx] - mean) / denom;
+                        }
                     }
+                    w[e] = s * a.window[n];
                 }
-                v[e] = s * a.window[n];
+                v[n1] = make_float2(w[0], w[1]);
             }
-            const unsigned r = bitrev((unsigned)m, log2m);
-            zre[r] = v[0];
-            zim[r] = v[1];
-        }
-        wave_sync();
-        // ---- radix-2 DIT stages
-        for (int s = 1; s <= log2m; ++s) {
-            const int half = 1 << (s - 1);
-            for (int bf = lane; bf < (M >> 1); bf += 64) {
-                const int grp = bf >> (s - 1), j = bf & (half - 1);
-                const int i0 = (grp << s) + j, i1 = i0 + half;
-                const int k = (j << (log2m - s)) << 1;   // W_M^(j*M/2^s) = tw[2*...]
-                const float wr = tw_re[k], wi = tw_im[k];
-                const float xr = zre[i1], xi = zim[i1];
-                const float tr = wr * xr - wi * xi, ti = wr * xi + wi * xr;
-                const float ur = zre[i0], ui = zim[i0];
-                zre[i0] = ur + tr; zim[i0] = ui + ti;
-                zre[i1] = ur - tr; zim[i1] = ui - ti;
+            dft8(v);                                                   // over n1 -> k1
+#pragma unroll
+            for (int k1 = 1; k1 < 8; ++k1) v[k1] = cmul(v[k1], twid(2 * lane * k1));     // W_512^(n2 k1)
+#pragma unroll
+            for (int k1 = 0; k1 < 8; ++k1) tb[k1 * 72 + lane] = v[k1];
+            wave_sync();
+            const int hi = lane >> 3, lo = lane & 7;                  // (k1, b) then (k1, c)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = tb[hi * 72 + 8 * q + lo];               // n2 = 8a + b
+            dft8(v);                                                   // over a -> c
+#pragma unroll
+            for (int c = 1; c < 8; ++c) v[c] = cmul(v[c], twid(16 * lo * c));            // W_64^(b c)
+            wave_sync();
+#pragma unroll
+            for (int c = 0; c < 8; ++c) tb[hi * 72 + c * 8 + lo] = v[c];                 // [k1][c][b]
+            wave_sync();
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = tb[hi * 72 + lo * 8 + q];               // lane (k1, c): b = 0..7
+            dft8(v);                                                   // over b -> e;  X[k1 + 8c + 64e]
+            wave_sync();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                zre[hi + 8 * lo + 64 * e] = v[e].x;
+                zim[hi + 8 * lo + 64 * e] = v[e].y;
             }
             wave_sync();
+        } else {
+            // ---- gather frame (reflect / zero padding), normalise, window; write bit-reversed
+            for (int m = lane; m < M; m += 64) {
+                float v[2];
+    #pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int n = 2 * m + e;
+                    int idx = t * a.hop - M + n;
+                    float s = 0.f;
+                    if (live) {
+                        if (a.pad_reflect) {
+                            if (idx < 0) idx = -idx;
+                            if (idx > a.seg_len - 1) idx = 2 * (a.seg_len - 1) - idx;
+                            s = (x[idx] - mean) / denom;
+                        } else if (idx >= 0 && idx < a.seg_len) {
+                            s = (x[idx] - mean) / denom;
+                        }
+                    }
+                    v[e] = s * a.window[n];
+                }
+                const unsigned r = bitrev((unsigned)m, log2m);
+                zre[r] = v[0];
+                zim[r] = v[1];
+            }
+            wave_sync();
+            // ---- radix-2 DIT stages
+            for (int s = 1; s <= log2m; ++s) {
+                const int half = 1 << (s - 1);
+                for (int bf = lane; bf < (M >> 1); bf += 64) {
+                    const int grp = bf >> (s - 1), j = bf & (half - 1);
+                    const int i0 = (grp << s) + j, i1 = i0 + half;
+                    const int k = (j << (log2m - s)) << 1;   // W_M^(j*M/2^s) = tw[2*...]
+                    const float wr = tw_re[k], wi = tw_im[k];
+                    const float xr = zre[i1], xi = zim[i1];
+                    const float tr = wr * xr - wi * xi, ti = wr * xi + wi * xr;
+                    const float ur = zre[i0], ui = zim[i0];
+                    zre[i0] = ur + tr; zim[i0] = ui + ti;
+                    zre[i1] = ur - tr; zim[i1] = ui - ti;
+                }
+                wave_sync();
+            }
         }
         // ---- real-FFT split + power:  X[k] = E[k] + W_N^k O[k],  k = 0..M
         for (int k = lane; k <= M; k += 64) {
@@ -181,7 +268,8 @@ int launch_melspec(const MelPlan &mp, const float *segs, int64_t B, int64_t seg_
     a.window = mp.window; a.twiddle = mp.twiddle;
     a.fb_ptr = mp.fb_ptr; a.fb_idx = mp.fb_idx; a.fb_val = mp.fb_val;
     const int M = mp.n_fft / 2;
-    const size_t lds = sizeof(float) * (size_t)(2 * M + 8 * M + 4 * (M + 4) + mp.n_mels * (mp.n_frames + 1) + 8);
+    const int WSZ = 2 * M > 1152 ? 2 * M : 1152;
+    const size_t lds = sizeof(float) * (size_t)(2 * M + 4 * WSZ + 4 * (M + 4) + mp.n_mels * (mp.n_frames + 1) + 8);
     if (lds > 160 * 1024) { set_error("melspec: LDS need %zu B > 160 KiB", lds); return -1; }
     static bool attr_set = false;
     if (!attr_set) {
