@@ -229,6 +229,7 @@ int pfann_set_melbank(pfann_ctx *c, const float *fb, int n_freqs, int n_mels) {
     PF_HIP(hipMemcpy(mp.fb_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
     PF_HIP(hipMemcpy(mp.fb_val, val.data(), val.size() * sizeof(float), hipMemcpyHostToDevice));
     mp.max_nnz_row = mx;
+    mp.fb_nnz = (int)idx.size();
     c->mel_ready = true;
     return 0;
 }

@@ -14,7 +14,7 @@ struct MelPlan {
     int *fb_ptr;          // [n_mels+1] CSR over mel bins
     int *fb_idx;          // [nnz] frequency bin
     float *fb_val;        // [nnz]
-    int max_nnz_row;
+    int max_nnz_row, fb_nnz;
 };
 int launch_melspec(const MelPlan &mp, const float *segs, int64_t B, int64_t seg_stride,
                    const int64_t *starts, int remove_mean, float *out, hipStream_t s);

@@ -21,6 +21,7 @@ struct MelArgs {
     float log_eps;
     const float *window; const float2 *twiddle;
     const int *fb_ptr, *fb_idx; const float *fb_val;
+    int fb_nnz;
 };
 
 __device__ __forceinline__ unsigned bitrev(unsigned x, int bits) { return __brev(x) >> (32 - bits); }
@@ -63,17 +64,37 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs a) {
     float *pw = work + 4 * WSZ;           // [4][M+4]  power spectrum per wave
     float *tile = pw + 4 * (M + 4);       // [n_mels][n_frames+1]
     float *red = tile + a.n_mels * (a.n_frames + 1);  // [8]
+    int *s_ptr = reinterpret_cast<int *>(red + 8);    // mel bank CSR, resident in LDS: [n_mels+1], [nnz], [nnz]
+    int *s_idx = s_ptr + a.n_mels + 1;
+    float *s_val = reinterpret_cast<float *>(s_idx + a.fb_nnz);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *x = a.segs + (a.starts ? a.starts[blockIdx.x] : (int64_t)blockIdx.x * a.seg_stride);
 
     for (int j = tid; j < M; j += 256) { const float2 t = a.twiddle[j]; tw_re[j] = t.x; tw_im[j] = t.y; }
+    for (int j = tid; j <= a.n_mels; j += 256) s_ptr[j] = a.fb_ptr[j];
+    for (int j = tid; j < a.fb_nnz; j += 256) { s_idx[j] = a.fb_idx[j]; s_val[j] = a.fb_val[j]; }
 
-    // ---- segment statistics: mean (optional), then L2 norm or max-abs of (x - mean)
+    // ---- segment statistics: mean (optional), then L2 norm or max-abs of (x - mean).  The segment is
+    // read once, all loads in flight together (32 registers per thread), instead of two latency-bound
+    // passes over global memory; summation order is the same as a strided loop's.
+    constexpr int SMAX = 32;
+    const bool inreg = a.seg_len <= SMAX * 256;
+    float xr[SMAX];
+#pragma unroll
+    for (int j = 0; j < SMAX; ++j) {
+        const int i = tid + 256 * j;
+        xr[j] = (inreg && i < a.seg_len) ? x[i] : 0.f;
+    }
     float mean = 0.f;
     if (a.remove_mean) {
         float s = 0.f;
-        for (int i = tid; i < a.seg_len; i += 256) s += x[i];
+        if (inreg) {
+#pragma unroll
+            for (int j = 0; j < SMAX; ++j) if (tid + 256 * j < a.seg_len) s += xr[j];
+        } else {
+            for (int i = tid; i < a.seg_len; i += 256) s += x[i];
+        }
         s = wave_sum(s);
         if (lane == 0) red[wave] = s;
         __syncthreads();
@@ -84,10 +105,21 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs a) {
     {
         float s = 0.f;
         if (a.spec_norm_max) {
-            for (int i = tid; i < a.seg_len; i += 256) s = fmaxf(s, fabsf(x[i] - mean));
+            if (inreg) {
+#pragma unroll
+                for (int j = 0; j < SMAX; ++j) if (tid + 256 * j < a.seg_len) s = fmaxf(s, fabsf(xr[j] - mean));
+            } else {
+                for (int i = tid; i < a.seg_len; i += 256) s = fmaxf(s, fabsf(x[i] - mean));
+            }
             s = wave_max(s);
         } else {
-            for (int i = tid; i < a.seg_len; i += 256) { const float v = x[i] - mean; s = fmaf(v, v, s); }
+            if (inreg) {
+#pragma unroll
+                for (int j = 0; j < SMAX; ++j)
+                    if (tid + 256 * j < a.seg_len) { const float v = xr[j] - mean; s = fmaf(v, v, s); }
+            } else {
+                for (int i = tid; i < a.seg_len; i += 256) { const float v = x[i] - mean; s = fmaf(v, v, s); }
+            }
             s = wave_sum(s);
         }
         if (lane == 0) red[4 + wave] = s;
@@ -106,6 +138,11 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs a) {
     };
     float *zre = work + wave * WSZ, *zim = zre + M, *pwr = pw + wave * (M + 4);
     const bool radix8 = a.n_fft == 1024;
+    float win[8][2];                      // radix-8 path: this lane's 16 window taps, the same for every frame
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) win[n1][e] = radix8 ? a.window[2 * (64 * n1 + lane) + e] : 0.f;
     const int n_groups = (a.n_frames + 3) >> 2;
     for (int g = 0; g < n_groups; ++g) {
         const int t = g * 4 + wave;
@@ -139,17 +176,17 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs a) {
                             s = (x[idx] - mean) / denom;
                         }
                     }
-                    w[e] = s * a.window[n];
+                    w[e] = s * win[n1][e];
                 }
                 v[n1] = make_float2(w[0], w[1]);
             }
+            const int hi = lane >> 3, lo = lane & 7;                  // (k1, b) then (k1, c)
             dft8(v);                                                   // over n1 -> k1
 #pragma unroll
             for (int k1 = 1; k1 < 8; ++k1) v[k1] = cmul(v[k1], twid(2 * lane * k1));     // W_512^(n2 k1)
 #pragma unroll
             for (int k1 = 0; k1 < 8; ++k1) tb[k1 * 72 + lane] = v[k1];
             wave_sync();
-            const int hi = lane >> 3, lo = lane & 7;                  // (k1, b) then (k1, c)
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = tb[hi * 72 + 8 * q + lo];               // n2 = 8a + b
             dft8(v);                                                   // over a -> c
@@ -229,8 +266,14 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs a) {
         if (live) {
             for (int m = lane; m < a.n_mels; m += 64) {
                 float acc = 0.f;
-                const int e1 = a.fb_ptr[m + 1];
-                for (int e = a.fb_ptr[m]; e < e1; ++e) acc = fmaf(a.fb_val[e], pwr[a.fb_idx[e]], acc);
+                const int e1 = s_ptr[m + 1];
+                int e = s_ptr[m];
+                for (; e + 3 < e1; e += 4) {      // four independent gathers in flight; same summation order
+                    const float v0 = s_val[e], v1 = s_val[e + 1], v2 = s_val[e + 2], v3 = s_val[e + 3];
+                    const float p0 = pwr[s_idx[e]], p1 = pwr[s_idx[e + 1]], p2 = pwr[s_idx[e + 2]], p3 = pwr[s_idx[e + 3]];
+                    acc = fmaf(v0, p0, acc); acc = fmaf(v1, p1, acc); acc = fmaf(v2, p2, acc); acc = fmaf(v3, p3, acc);
+                }
+                for (; e < e1; ++e) acc = fmaf(s_val[e], pwr[s_idx[e]], acc);
                 acc += a.log_eps;
                 if (a.log_mode == 1) acc = logf(acc);
                 else if (a.log_mode == 2) acc = log10f(acc);
@@ -252,8 +295,14 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs a) {
         sub = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     }
     float *o = a.out + (int64_t)blockIdx.x * a.n_mels * a.n_frames;
-    for (int i = tid; i < a.n_mels * a.n_frames; i += 256)
-        o[i] = tile[(i / a.n_frames) * (a.n_frames + 1) + (i % a.n_frames)] - sub;
+    if (256 % a.n_frames == 0) {          // thread -> fixed frame, mel rows advance by 256 / n_frames: no divisions
+        const int tf = tid % a.n_frames, mstep = 256 / a.n_frames;
+        int m = tid / a.n_frames;
+        for (int i = tid; i < a.n_mels * a.n_frames; i += 256, m += mstep) o[i] = tile[m * (a.n_frames + 1) + tf] - sub;
+    } else {
+        for (int i = tid; i < a.n_mels * a.n_frames; i += 256)
+            o[i] = tile[(i / a.n_frames) * (a.n_frames + 1) + (i % a.n_frames)] - sub;
+    }
 }
 
 int launch_melspec(const MelPlan &mp, const float *segs, int64_t B, int64_t seg_stride, const int64_t *starts,
@@ -266,10 +315,11 @@ int launch_melspec(const MelPlan &mp, const float *segs, int64_t B, int64_t seg_
     a.power = mp.power; a.pad_reflect = mp.pad_reflect; a.log_mode = mp.log_mode;
     a.spec_norm_max = mp.spec_norm_max; a.remove_mean = remove_mean; a.log_eps = mp.log_eps;
     a.window = mp.window; a.twiddle = mp.twiddle;
-    a.fb_ptr = mp.fb_ptr; a.fb_idx = mp.fb_idx; a.fb_val = mp.fb_val;
+    a.fb_ptr = mp.fb_ptr; a.fb_idx = mp.fb_idx; a.fb_val = mp.fb_val; a.fb_nnz = mp.fb_nnz;
     const int M = mp.n_fft / 2;
     const int WSZ = 2 * M > 1152 ? 2 * M : 1152;
-    const size_t lds = sizeof(float) * (size_t)(2 * M + 4 * WSZ + 4 * (M + 4) + mp.n_mels * (mp.n_frames + 1) + 8);
+    const size_t lds = sizeof(float) * (size_t)(2 * M + 4 * WSZ + 4 * (M + 4) + mp.n_mels * (mp.n_frames + 1) + 8 +
+                                               mp.n_mels + 1 + 2 * (size_t)mp.fb_nnz);
     if (lds > 160 * 1024) { set_error("melspec: LDS need %zu B > 160 KiB", lds); return -1; }
     static bool attr_set = false;
     if (!attr_set) {
