@@ -22,6 +22,7 @@ struct MelArgs {
     const float *window; const float2 *twiddle;
     const int *fb_ptr, *fb_idx; const float *fb_val;
     int fb_nnz;
+    int group_out;           // 1: stream each group of 4 frames out through a small LDS tile (3 workgroups / CU)
 };
 
 __device__ __forceinline__ unsigned bitrev(unsigned x, int bits) { return __brev(x) >> (32 - bits); }
@@ -62,8 +63,8 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs a) {
     const int WSZ = 2 * M > 1152 ? 2 * M : 1152;
     float *work = tw_im + M;              // [4][WSZ]  per-wave FFT buffer (re[M], im[M]; radix-8 path: 576 float2)
     float *pw = work + 4 * WSZ;           // [4][M+4]  power spectrum per wave
-    float *tile = pw + 4 * (M + 4);       // [n_mels][n_frames+1]
-    float *red = tile + a.n_mels * (a.n_frames + 1);  // [8]
+    float *tile = pw + 4 * (M + 4);       // [n_mels][n_frames+1], or [n_mels][5] when group_out
+    float *red = tile + a.n_mels * (a.group_out ? 5 : a.n_frames + 1);  // [8]
     int *s_ptr = reinterpret_cast<int *>(red + 8);    // mel bank CSR, resident in LDS: [n_mels+1], [nnz], [nnz]
     int *s_idx = s_ptr + a.n_mels + 1;
     float *s_val = reinterpret_cast<float *>(s_idx + a.fb_nnz);
@@ -277,11 +278,22 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs a) {
                 acc += a.log_eps;
                 if (a.log_mode == 1) acc = logf(acc);
                 else if (a.log_mode == 2) acc = log10f(acc);
-                tile[m * (a.n_frames + 1) + t] = acc;
+                if (a.group_out) tile[m * 5 + wave] = acc;
+                else tile[m * (a.n_frames + 1) + t] = acc;
             }
         }
         wave_sync();
+        if (a.group_out) {
+            // frames 4g .. 4g+3 of every mel row: 16 contiguous bytes of the [n_mels][n_frames] output
+            __syncthreads();
+            float *o4 = a.out + (int64_t)blockIdx.x * a.n_mels * a.n_frames + 4 * g;
+            for (int m = tid; m < a.n_mels; m += 256)
+                *reinterpret_cast<float4 *>(o4 + (int64_t)m * a.n_frames) =
+                    make_float4(tile[m * 5], tile[m * 5 + 1], tile[m * 5 + 2], tile[m * 5 + 3]);
+            __syncthreads();
+        }
     }
+    if (a.group_out) return;
     __syncthreads();                      // the [n_mels][n_frames] tile is complete
     // ---- spec_norm == 'max': subtract the tile maximum (melspec.py:48-49)
     float sub = 0.f;
@@ -316,9 +328,10 @@ int launch_melspec(const MelPlan &mp, const float *segs, int64_t B, int64_t seg_
     a.spec_norm_max = mp.spec_norm_max; a.remove_mean = remove_mean; a.log_eps = mp.log_eps;
     a.window = mp.window; a.twiddle = mp.twiddle;
     a.fb_ptr = mp.fb_ptr; a.fb_idx = mp.fb_idx; a.fb_val = mp.fb_val; a.fb_nnz = mp.fb_nnz;
+    a.group_out = (!mp.spec_norm_max && mp.n_frames % 4 == 0) ? 1 : 0;
     const int M = mp.n_fft / 2;
     const int WSZ = 2 * M > 1152 ? 2 * M : 1152;
-    const size_t lds = sizeof(float) * (size_t)(2 * M + 4 * WSZ + 4 * (M + 4) + mp.n_mels * (mp.n_frames + 1) + 8 +
+    const size_t lds = sizeof(float) * (size_t)(2 * M + 4 * WSZ + 4 * (M + 4) + mp.n_mels * (a.group_out ? 5 : mp.n_frames + 1) + 8 +
                                                mp.n_mels + 1 + 2 * (size_t)mp.fb_nnz);
     if (lds > 160 * 1024) { set_error("melspec: LDS need %zu B > 160 KiB", lds); return -1; }
     static bool attr_set = false;
