@@ -450,6 +450,9 @@ int search_topk(const float *db, const void *dbh, float xnorm_max, int64_t n, in
     }
     if (ensure_ws(ws, nq)) return -1;
     // sampling ratio per level: expected survivors ~ R*k per query, kept <= CAP/4
+    // (R = 8 and 4 were measured for the batched path too: more passes and selects cost more than the
+    // shorter survivor lists save)
+    const bool batched = dbh != nullptr && nq > 64;
     const int R = k <= 128 ? 16 : (k <= 512 ? 4 : 2);
     int levels = 0;
     int64_t stride = 1;
@@ -458,7 +461,7 @@ int search_topk(const float *db, const void *dbh, float xnorm_max, int64_t n, in
     const int64_t DENSE_CAP = 4096;
     while ((n + stride - 1) / stride > DENSE_CAP) { stride *= R; ++levels; }
     PF_HIP(hipMemsetAsync(ws.overflow, 0, sizeof(int), s));
-    if (dbh != nullptr && nq > 64) {
+    if (batched) {
         // ---- fp16 pre-filter + exact fp32 re-scoring (search_f16.hip): same levels, same exact result
         if (ws.qh_elems < nq * d) {
             if (ws.qh) (void)hipFree(ws.qh);
