@@ -59,15 +59,16 @@ struct FusedGemmParams {
 // order as conv_first_stats_kernel, so bit-identical) instead of streaming the 2 MiB/segment
 // tensor through HBM; p.x is then the log-mel batch [B][F][T0].
 // UNI = true: Ci % 32 == 0, see "Operand addressing" below.
-template <int BM, int BN, int WM, int WN, bool RELU_BN, bool FIRST, bool UNI>
-__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM / WM) * (BN / WN) == 8 ? 4 : 1)
+// BK = K-tile depth: 32, or 16 for the 4-wave 128x128 variant that fits three workgroups per CU.
+template <int BM, int BN, int WM, int WN, bool RELU_BN, bool FIRST, bool UNI, int BK = 32>
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM / WM) * (BN / WN) == 8 ? 4 : (BK == 16 ? 3 : 1))
 void conv_gemm_ln_kernel(FusedGemmParams p) {
-    constexpr int BK = 32, LDK = BK + 4;
+    constexpr int LDK = BK + 4, TPR = BK / 4;         // TPR loader threads per tile row (4 floats each)
     constexpr int WAVES_N = BN / WN;
     constexpr int NWAVES = (BM / WM) * WAVES_N, NT = 64 * NWAVES;
     static_assert(NWAVES == 4 || NWAVES == 8, "4 or 8 waves per block");
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int RPT = NT / 8;                        // tile rows covered per loader pass
+    constexpr int RPT = NT / TPR;                      // tile rows covered per loader pass
     constexpr int AR = BM / RPT, BR = BN / RPT;
     __shared__ __attribute__((aligned(16))) float As[2 * BM * LDK];
     __shared__ __attribute__((aligned(16))) float Bs[2 * BN * LDK];
@@ -105,7 +106,7 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
         __syncthreads();
     }
 
-    const int col4 = tid & 7, rowq = tid >> 3;
+    const int col4 = tid & (TPR - 1), rowq = tid / TPR;
     // bounds-checked buffer loads (OOB lanes read 0): activation window from the first sample of
     // the tile, LayerNorm affine tensors addressed sample-relative, weights by output channel
     const int64_t x_elems = FIRST ? (int64_t)p.F * p.T0 : p.in_elems;       // per-sample size of p.x
