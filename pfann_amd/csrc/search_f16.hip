@@ -541,22 +541,48 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(const unsigned lon
     }
     __syncthreads();
     const int n2 = s_n2;
-    // exact fp32 scores: one wave per candidate, coalesced row reads, fixed reduction order
+    // exact fp32 scores, all candidates of a pass in flight together: 8 threads per candidate, each a
+    // strided set of float4 chunks (a row is read as whole 128-byte lines), fixed reduction order
     const float *qv = q32 + m * d;
-    for (int c = wave; c < n2; c += 16) {
-        const unsigned row = (unsigned)(ck[c] & 0xFFFFFFFFull);
-        const float *xv = db32 + (int64_t)row * d;
+    for (int c0 = 0; c0 < n2; c0 += 128) {
+        const int c = c0 + (tid >> 3), sub = tid & 7;
         float part = 0.f;
-        for (int e = lane; e < d; e += 64) part = fmaf(xv[e], qv[e], part);
-        part = wave_sum(part);
-        if (lane == 0) ck[c] = pack_key(part, row);
+        unsigned row = 0;
+        if (c < n2) {
+            row = (unsigned)(ck[c] & 0xFFFFFFFFull);
+            const float *xv = db32 + (int64_t)row * d;
+            for (int e = sub * 4; e < d; e += 32) {
+                const float4 x4 = *reinterpret_cast<const float4 *>(xv + e);
+                const float4 q4 = *reinterpret_cast<const float4 *>(qv + e);
+                part = fmaf(x4.x, q4.x, part); part = fmaf(x4.y, q4.y, part);
+                part = fmaf(x4.z, q4.z, part); part = fmaf(x4.w, q4.w, part);
+            }
+        }
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        part += __shfl_xor(part, 4, 64);
+        if (c < n2 && sub == 0) ck[c] = pack_key(part, row);
     }
     __syncthreads();
-    int P2 = 1;
-    while (P2 < n2) P2 <<= 1;
-    for (int i = n2 + tid; i < P2; i += 1024) ck[i] = ~0ull;     // entries beyond n2 can no longer matter
-    __syncthreads();
-    bitonic_sort_u64(ck, P2, tid, 1024);         // by exact score, descending
+    if (n2 <= 1024) {
+        // rank sort (keys are unique: they contain the row): one pass of broadcast LDS reads, no
+        // log^2 barrier ladder for ~100-150 candidates
+        unsigned long long mine = ~0ull;
+        int rank = 0;
+        if (tid < n2) {
+            mine = ck[tid];
+            for (int j = 0; j < n2; ++j) rank += ck[j] < mine ? 1 : 0;
+        }
+        __syncthreads();
+        if (tid < n2) ck[rank] = mine;
+        __syncthreads();
+    } else {
+        int P2 = 1;
+        while (P2 < n2) P2 <<= 1;
+        for (int i = n2 + tid; i < P2; i += 1024) ck[i] = ~0ull;     // entries beyond n2 can no longer matter
+        __syncthreads();
+        bitonic_sort_u64(ck, P2, tid, 1024);         // by exact score, descending
+    }
     if (mode == 0) {
         if (tid == 0) {
             const float t = n2 >= k ? ord2f(~(unsigned)(ck[k - 1] >> 32)) : -INFINITY;
