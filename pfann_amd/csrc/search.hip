@@ -419,7 +419,7 @@ static int launch_select(SearchWorkspace &ws, int64_t nq, int k, int mode, float
 static int ensure_ws(SearchWorkspace &ws, int64_t nq) {
     if (ws.cap_q >= nq) return 0;
     if (ws.thr) { (void)hipFree(ws.thr); (void)hipFree(ws.cnt); (void)hipFree(ws.cl); }
-    if (!ws.overflow) PF_HIP(hipMalloc(&ws.overflow, sizeof(int)));
+    if (!ws.overflow) PF_HIP(hipMalloc(&ws.overflow, 4 * sizeof(int)));    // [0] overflow flag, [1] rows left to the big select kernel
     const int64_t cap = nq < 64 ? 64 : nq;
     if (ws.thr_adj) { (void)hipFree(ws.thr_adj); (void)hipFree(ws.eps); }
     PF_HIP(hipMalloc(&ws.thr_adj, sizeof(float) * cap));

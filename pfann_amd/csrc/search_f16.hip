@@ -425,6 +425,178 @@ int launch_scan_f16(const void *dbh, int64_t n, int d, int64_t stride, const voi
 }
 
 // ------------------------------------------------------------------------------------
+// Select with exact re-scoring for rows with at most SMALL_N survivors (the normal case: ~1600):
+// 256 threads and 32 KB of LDS per query row, so four rows are resident per CU and their global
+// round trips (count / key gather / candidate rows) overlap.  Same steps and results as
+// select_rescore_kernel below, which keeps the rows with more survivors.
+// ------------------------------------------------------------------------------------
+constexpr int SMALL_N = 4096;
+__global__ __launch_bounds__(256) void select_rescore_small_kernel(const unsigned long long *__restrict__ keys,
+                                                                   const int *__restrict__ cnt, int k, int mode,
+                                                                   float *__restrict__ thr, float *__restrict__ thr_adj,
+                                                                   const float *__restrict__ eps, float *__restrict__ D,
+                                                                   int64_t *__restrict__ I, int64_t label_base,
+                                                                   int *overflow, const float *__restrict__ q32,
+                                                                   const float *__restrict__ db32, int d, int nsub) {
+    constexpr int NT = 256, KPT = SMALL_N / NT;
+    __shared__ __attribute__((aligned(16))) unsigned long long skeys[SMALL_N];
+    __shared__ int s_n2, s_bin, s_kk;
+    __shared__ int s_off[66];
+    __shared__ int hist[256];
+    const int64_t m = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int subcap = CAP / nsub;
+    if (tid < 64) {
+        int c = tid < nsub ? cnt[m * nsub + tid] : 0;
+        const bool ov = c > subcap;
+        c = ov ? subcap : c;
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (tid >= o) incl += v;
+        }
+        s_off[tid + 1] = incl;
+        if (tid == 0) s_off[0] = 0;
+        const bool any_ov = __any(ov);
+        if (tid == 0) s_off[65] = any_ov ? 1 : 0;
+    }
+    __syncthreads();
+    const int n = s_off[nsub];
+    if (n > SMALL_N) {                                // select_rescore_kernel's job
+        if (tid == 0) atomicAdd(overflow + 1, 1);
+        return;
+    }
+    const bool over = s_off[65] != 0;
+    if (over && mode == 1 && tid == 0) atomicExch(overflow, 1);
+    if (nsub == 1) {
+        for (int i = tid; i < n; i += NT) skeys[i] = keys[m * CAP + i];
+    } else {
+        const int l = tid & 7;                        // 8 threads per sub-list, 32 sub-lists per pass
+        for (int g = tid >> 3; g < nsub; g += NT / 8) {
+            const int o = s_off[g], c = s_off[g + 1] - o;
+            for (int i = l; i < c; i += 8) skeys[o + i] = keys[m * CAP + g * subcap + i];
+        }
+    }
+    __syncthreads();
+    const float e2 = 2.0f * eps[m];
+    if (n <= k) {
+        if (tid == 0) s_n2 = n;
+        __syncthreads();
+    } else {
+        unsigned prefix = 0;
+        int kk = k;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            hist[tid] = 0;
+            __syncthreads();
+            for (int i = tid; i < n; i += NT) {
+                const unsigned hi = (unsigned)(skeys[i] >> 32);
+                if (pass == 0 || (hi >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(hi >> shift) & 255], 1);
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const int c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+                const int sum4 = c0 + c1 + c2 + c3;
+                int incl = sum4;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += v;
+                }
+                const int excl = incl - sum4;
+                if (excl < kk && kk <= incl) {
+                    int rem = kk - excl, bin = 4 * lane;
+                    if (rem > c0) { rem -= c0; ++bin; if (rem > c1) { rem -= c1; ++bin; if (rem > c2) { rem -= c2; ++bin; } } }
+                    s_bin = bin;
+                    s_kk = rem;
+                }
+            }
+            __syncthreads();
+            prefix |= (unsigned)s_bin << shift;
+            kk = s_kk;
+        }
+        const float cut = ord2f(~prefix) - e2;
+        const unsigned cut_hi = ~f2ord(cut);
+        // in-place compaction: every thread takes its keys into registers first
+        unsigned long long mine[KPT];
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) mine[j] = tid + NT * j < n ? skeys[tid + NT * j] : ~0ull;
+        if (tid == 0) s_n2 = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KPT; ++j)
+            if (tid + NT * j < n && (unsigned)(mine[j] >> 32) <= cut_hi) skeys[atomicAdd(&s_n2, 1)] = mine[j];
+        __syncthreads();
+    }
+    const int n2 = s_n2;
+    // exact fp32 scores: 4 threads per candidate, 64 candidates in flight per pass
+    const float *qv = q32 + m * d;
+    for (int c0 = 0; c0 < n2; c0 += NT / 4) {
+        const int c = c0 + (tid >> 2), sub = tid & 3;
+        float part = 0.f;
+        unsigned row = 0;
+        if (c < n2) {
+            row = (unsigned)(skeys[c] & 0xFFFFFFFFull);
+            const float *xv = db32 + (int64_t)row * d;
+            for (int e = sub * 4; e < d; e += 16) {
+                const float4 x4 = *reinterpret_cast<const float4 *>(xv + e);
+                const float4 q4 = *reinterpret_cast<const float4 *>(qv + e);
+                part = fmaf(x4.x, q4.x, part); part = fmaf(x4.y, q4.y, part);
+                part = fmaf(x4.z, q4.z, part); part = fmaf(x4.w, q4.w, part);
+            }
+        }
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        __syncthreads();                              // every lane has read its key before it is replaced
+        if (c < n2 && sub == 0) skeys[c] = pack_key(part, row);
+    }
+    __syncthreads();
+    // rank sort (keys are unique: they contain the row)
+    {
+        unsigned long long mine[KPT];
+        int rank[KPT];
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const int i = tid + NT * j;
+            mine[j] = ~0ull; rank[j] = 0;
+            if (i < n2) {
+                mine[j] = skeys[i];
+                for (int t = 0; t < n2; ++t) rank[j] += skeys[t] < mine[j] ? 1 : 0;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KPT; ++j)
+            if (tid + NT * j < n2) skeys[rank[j]] = mine[j];
+        __syncthreads();
+    }
+    if (mode == 0) {
+        if (tid == 0) {
+            const float t = n2 >= k ? ord2f(~(unsigned)(skeys[k - 1] >> 32)) : -INFINITY;
+            thr[m] = t;
+            thr_adj[m] = fmaxf(t - eps[m], -1000.f * eps[m]);   // finite: below every possible score
+        }
+    } else {
+        for (int i = tid; i < k; i += NT) {
+            if (i < n2) {
+                const unsigned long long key = skeys[i];
+                D[m * k + i] = ord2f(~(unsigned)(key >> 32));
+                I[m * k + i] = (int64_t)(unsigned)(key & 0xFFFFFFFFu) + label_base;
+            } else {
+                D[m * k + i] = -3.4028234663852886e38f;
+                I[m * k + i] = -1;
+            }
+        }
+        if (over && tid == 0 && n2 >= k) {          // raised threshold for the rescan
+            const float t = ord2f(~(unsigned)(skeys[k - 1] >> 32));
+            thr[m] = t;
+            thr_adj[m] = fmaxf(t - eps[m], -1000.f * eps[m]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // Select with exact re-scoring (step 4 above).  One 1024-thread workgroup per query row.
 //   mode 0: thr[m] = exact k-th best (or -inf), thr_adj[m] = thr[m] - eps[m]
 //   mode 1: D, I = exact top-k;  list overflow -> overflow flag (+ raised thresholds)
@@ -435,12 +607,14 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(const unsigned lon
                                                               const float *__restrict__ eps, float *__restrict__ D,
                                                               int64_t *__restrict__ I, int64_t label_base,
                                                               int *overflow, const float *__restrict__ q32,
-                                                              const float *__restrict__ db32, int d, int nsub) {
+                                                              const float *__restrict__ db32, int d, int nsub,
+                                                              int skip_small) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
     __shared__ int s_n2;
     __shared__ int s_off[66];
     const int64_t m = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (skip_small && overflow[1] == 0) return;       // every row was handled by select_rescore_small_kernel
     // gather the row's nsub sub-lists (sub-list g holds cnt[m*nsub+g] keys at keys[m*CAP + g*subcap])
     const int subcap = CAP / nsub;
     if (tid < 64) {
@@ -460,6 +634,7 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(const unsigned lon
     }
     __syncthreads();
     const int n = s_off[nsub];
+    if (skip_small && n <= SMALL_N) return;          // done by select_rescore_small_kernel
     const bool over = s_off[65] != 0;
     if (over && mode == 1 && tid == 0) atomicExch(overflow, 1);
     int P = 1;
@@ -617,9 +792,13 @@ int launch_select_rescore(SearchWorkspace &ws, int64_t nq, int k, int mode, floa
         attr_set = true;
     }
     ProfScope ps("topk_select_rescore", s);
+    PF_HIP(hipMemsetAsync(ws.overflow + 1, 0, sizeof(int), s));
+    PF_LAUNCH(select_rescore_small_kernel, dim3((unsigned)nq), dim3(256), 0, s,
+              reinterpret_cast<const unsigned long long *>(ws.cl), ws.cnt, k, mode, ws.thr, ws.thr_adj, ws.eps, D,
+              I, label_base, ws.overflow, q32, db32, d, nsub);
     PF_LAUNCH(select_rescore_kernel, dim3((unsigned)nq), dim3(1024), CAP * 8, s,
                        reinterpret_cast<const unsigned long long *>(ws.cl), ws.cnt, k, mode, ws.thr, ws.thr_adj, ws.eps, D,
-                       I, label_base, ws.overflow, q32, db32, d, nsub);
+                       I, label_base, ws.overflow, q32, db32, d, nsub, 1);
     PF_HIP(hipGetLastError());
     return 0;
 }

@@ -289,6 +289,23 @@ def test_search_topk_sublist_overflow_falls_back(torch_cuda):
     _check_topk(torch_cuda, db.astype(np.float32), q.astype(np.float32), 300, True)
 
 
+@pytest.mark.parametrize("nq", [80, 1100])
+def test_search_topk_more_than_4096_survivors(torch_cuda, nq):
+    """5000 near-identical rows all clear the sampled threshold of the queries that match them: those
+    rows' survivor lists (> 4096, < 8192 entries) are left to the large select kernel, the others go
+    through the 256-thread one; both in the same call (nq = 1100 additionally overflows the per-slice
+    sub-lists and takes the one-list-per-row rescan)."""
+    d, n = 128, 100000
+    db = synth.unit_rows(51, "t/big", n, d)
+    c = synth.unit_rows(52, "t/bigc", 1, d)
+    db[20000:25000] = c + 0.003 * db[20000:25000]
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    q = synth.unit_rows(53, "t/bigq", nq, d)
+    q[:5] = c + 0.05 * q[:5]
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    _check_topk(torch_cuda, db.astype(np.float32), q.astype(np.float32), 100, True)
+
+
 def test_search_prefilter_near_ties_stay_exact(torch_cuda):
     """Adversarial for the fp16 pre-filter: thousands of rows whose exact scores differ by ~1e-6
     (far below fp16 resolution, 1e-3) around the k-th best.  The re-scoring window (2 eps below
