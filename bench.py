@@ -84,6 +84,14 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    # PFANN_EMULATE_WORLD=N (tuning aid, single process): do rank 0's share of an N-rank job -- 1/N of the db,
+    # 1/N of the queries embedded (then tiled to the full batch), the sharded query path with its merge and
+    # owned-only rerank -- without the collectives.  Shows how the per-rank work shrinks with N; never a result.
+    emu = int(os.environ.get("PFANN_EMULATE_WORLD", "0"))
+    if emu > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29611")
+        dist.init_process_group("gloo", rank=0, world_size=1)
     params = read_config(os.path.join(REPO, "configs", "default.json"))
     d, k = params["model"]["d"], params["indexer"]["top_k"]
     t_setup = time.time()
@@ -96,7 +104,7 @@ def main():
     n_rows = int(song_pos[-1])
     real_ids = np.unique(np.linspace(0, n_songs - 1, args.real_songs).astype(np.int64))
     songs = {int(s): synth.make_song(int(s)) for s in real_ids}
-    s_lo, s_hi = shard_songs(song_pos, world)[rank]
+    s_lo, s_hi = shard_songs(song_pos, emu if emu > 1 else world)[rank]
     r_lo, r_hi = int(song_pos[s_lo]), int(song_pos[s_hi])
     gen = torch.Generator(device=dev)
     shard = torch.empty((r_hi - r_lo, d), device=dev, dtype=torch.float32)
@@ -115,7 +123,7 @@ def main():
             shard[int(song_pos[s]) - r_lo: int(song_pos[s + 1]) - r_lo] = e
     index = DeviceIndex(d, local_rank)
     index.load(shard, song_pos, r_lo)
-    if world > 1:
+    if world > 1 or emu > 1:
         sharded = ShardedIndex(index, song_pos, k, 1, 0.0)
 
     # ----------------------------------------------------------------- queries (untimed)
@@ -127,7 +135,7 @@ def main():
         q_pcm.append(pcm)
         q_off.append(off)
     q_len = q_pcm[0].shape[0]
-    my_q = split_even(Q, world)[rank]
+    my_q = split_even(Q, emu if emu > 1 else world)[rank]
     q_counts = [(hi - lo) * QUERY_SEGS for lo, hi in split_even(Q, world)]
     pcm_dev = torch.as_tensor(np.concatenate(q_pcm[my_q[0]:my_q[1]]) if my_q[1] > my_q[0]
                               else np.zeros(0, np.int16)).to(dev)          # resident in HBM
@@ -143,6 +151,9 @@ def main():
     def step():
         wav = eng.pcm16_to_mono(pcm_dev)
         emb = eng.embed_windows(wav, starts_dev)
+        if emu > 1:
+            emb = emb.repeat(emu, 1)[: Q * QUERY_SEGS].contiguous()
+            return sharded.query_batch(emb, qstart, qlen), emb
         if world > 1:
             emb = all_gather_ragged(emb, q_counts)
             return sharded.query_batch(emb, qstart, qlen), emb

@@ -359,17 +359,22 @@ __global__ __launch_bounds__(256, 2) void scan_f16_qres_kernel(ScanParams p) {
 #pragma unroll
                 for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(mx, acc[i][j][r]), acc[i][j][r + 1]);
                 if (__any(nok && mx >= 0.f)) {
+                    // all LDS counter updates first (one latency), then the stores
+                    int pos[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        if (nok && acc[i][j][r] >= 0.f) {
+                        pos[r] = 0x7FFFFFFF;
+                        if (nok && acc[i][j][r] >= 0.f)
+                            pos[r] = atomicAdd(&s_cnt[wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf], 1);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (pos[r] < subcap) {
                             const int ml = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-                            const int pos = atomicAdd(&s_cnt[ml], 1);
-                            if (pos < subcap) {
-                                const unsigned long long key = pack_key(acc[i][j][r] - cinit[i][r], rowid);
-                                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, key), srd_k,
-                                                                      (ml * CAP + pos) * 8, 0, 0);
-                            }
+                            const unsigned long long key = pack_key(acc[i][j][r] - cinit[i][r], rowid);
+                            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, key), srd_k,
+                                                                  (ml * CAP + pos[r]) * 8, 0, 0);
                         }
                     }
                 }
@@ -405,7 +410,7 @@ int launch_scan_f16(const void *dbh, int64_t n, int d, int64_t stride, const voi
     p.n_tiles_m = cdiv(nq, 128);
     const int64_t db_tiles = cdiv(p.nrows, 128);
     static const bool no_qres = getenv("PFANN_NO_QRES") != nullptr;
-    if (thr_adj != nullptr && allow_sublists && !no_qres && (d == 128 || d == 64) && nq >= 1024 && db_tiles >= 64) {
+    if (thr_adj != nullptr && allow_sublists && !no_qres && (d == 128 || d == 64) && nq >= 1024 && db_tiles >= 16) {
         // S interleaved db slices: about four rounds of the 512 resident workgroups, sub-lists of >= 256
         int S = (int)(2048 / p.n_tiles_m);
         S = S < 1 ? 1 : (S > 32 ? 32 : S);
