@@ -31,7 +31,7 @@ def main(d):
     # and without the folded first conv): launch-weighted average
     groups = {}
     for k, r in res.items():
-        m = re.match(r"(?:void )?(pfann::\w+<\d+, \d+)", k)
+        m = re.match(r"(?:void )?(pfann::\w+<\d+(?:, \d+)*)", k)
         if m:
             groups.setdefault(m.group(1), []).append(r)
     for g, rs in groups.items():
