@@ -52,7 +52,10 @@ def main():
                     help="encoder chunk (segments); 9728 = the whole step in one chunk: 29 GB of activations, and the\n"
                          "small late layers get enough 128x128 tiles to fill the 512 resident workgroups")
     ap.add_argument("--cpu-queries", type=int, default=12, help="bounded sample for the CPU baseline")
+    ap.add_argument("--encoder-precision", type=int, default=0, choices=[0, 1],
+                    help="0: exact fp32 MFMA (default, the headline); 1: opt-in 3-term fp16 split (pfann_set_encoder_precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the informational split-precision run")
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--dump-decisions", default=None, help="write (song, offset, score) per query as .npy (rank 0)")
     args = ap.parse_args()
@@ -97,6 +100,8 @@ def main():
     t_setup = time.time()
     eng = Engine(params, local_rank, max_batch=args.max_batch)
     eng.load_state_dict(synth.make_state_dict(params, seed=123))
+    if args.encoder_precision:
+        assert eng.set_encoder_precision(args.encoder_precision) == args.encoder_precision
 
     # ---------------------------------------------------------------- database (untimed)
     n_songs = args.db_songs
@@ -189,6 +194,26 @@ def main():
         elapsed = float(t.item())
     n_seg = Q * QUERY_SEGS
     value = n_seg * args.steps / elapsed
+
+    # ---- informational: the opt-in split-precision encoder (never `value`): same step, 2 timed runs
+    alt = None
+    if world == 1 and emu <= 1 and not args.encoder_precision and not args.no_alt:
+        if eng.set_encoder_precision(1) == 1:
+            step()
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            for _ in range(2):
+                res_alt, emb_alt = step()
+            torch.cuda.synchronize()
+            el = (time.perf_counter() - ta) / 2
+            same = int(np.sum((res_alt["song"] == res["song"]) & (res_alt["offset"] == res["offset"])))
+            alt = {"encoder_precision_1": {
+                "what": "conv products as 3 fp16-MFMA terms of 2-term operand splits (2^-22 relative), fp32 accumulate; "
+                        "pfann_set_encoder_precision(ctx, 1); NOT the headline value",
+                "value": round(n_seg / el, 1), "unit": "segments/s", "ms_per_step": round(1e3 * el, 3),
+                "max_abs_embedding_diff_vs_fp32_path": float((emb_alt - emb).abs().max().item()),
+                "decisions_identical_to_fp32_path": "%d/%d" % (same, Q)}}
+        eng.set_encoder_precision(0)
 
     # ------------------------------------------------------------ per-kernel event times
     kernels = {}
@@ -344,6 +369,7 @@ def main():
             "top1_hit_rate": round(hits / Q, 4), "top1_near_0.5s": round(near / Q, 4),
             "top1_exact_0.25s": round(exact / Q, 4),
             "roofline": roofline, "single_query_scan_roofline": single, "cpu_baseline": cpu, "oracle_decision_parity": parity,
+            "alt_modes": alt,
             "kernels": {t: {kk: (float("%.4g" % vv) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                         for t, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
         }

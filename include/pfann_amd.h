@@ -120,6 +120,13 @@ void pfann_debug_keep(pfann_ctx *ctx, int on);
  * effect (1 fused / 0 unfused).  Both paths are parity-tested. */
 int pfann_set_fused_layernorm(pfann_ctx *ctx, int on);
 
+/* Arithmetic of the fused conv GEMMs.  0 (default): fp32 MFMA, bitwise an fmaf chain.  1: every operand as two
+ * fp16 terms (x = hi + lo to 2^-22 relative; weights pre-scaled by a power of two), three fp16 MFMAs per product
+ * (hi*hi + lo*hi + hi*lo) with fp32 accumulation -- fp32-grade results (embeddings within ~1e-6 of mode 0,
+ * far inside the 1e-4 parity bar) at 3/16 of the MFMA cycles.  Needs the fused path.  Returns the mode now in
+ * effect.  New capability: the reference computes these convolutions in fp32 (model.py:54-73). */
+int pfann_set_encoder_precision(pfann_ctx *ctx, int mode);
+
 /* Number of internal HIP streams (1..8) a batch is split over inside pfann_encode /
  * pfann_segment_embed*: the MFMA-bound GEMMs of one sub-batch overlap the HBM-bound passes
  * of another.  Work is forked from and joined back into the caller's stream.  Returns n. */

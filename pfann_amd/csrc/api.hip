@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 #include <map>
 
 #include "kernels.h"
@@ -71,6 +72,7 @@ struct pfann_ctx {
     float gram[14] = {};
     bool gram_ready = false;
     bool fused = false;             // LayerNorm fused into the GEMMs (encoder_fused.hip)
+    int precision = 0;              // 0: fp32 MFMA (exact); 1: 3-term fp16 split on the fp16 MFMA (opt-in)
     int n_streams = 1;              // sub-batches run on this many internal streams (MFMA-bound GEMMs of one
                                     // sub-batch overlap the HBM-bound LayerNorm passes of another)
     hipStream_t side[8] = {};
@@ -187,6 +189,7 @@ void pfann_destroy(pfann_ctx *c) {
     (void)hipDeviceSynchronize();
     for (int i = 0; i < 16; ++i) {
         if (c->sub[i].w) (void)hipFree(c->sub[i].w);
+        if (c->sub[i].w_hi) { (void)hipFree(c->sub[i].w_hi); (void)hipFree(c->sub[i].w_lo); }
         if (c->sub[i].bias) (void)hipFree(c->sub[i].bias);
         if (c->sub[i].ln_w) (void)hipFree(c->sub[i].ln_w);
         if (c->sub[i].ln_b) (void)hipFree(c->sub[i].ln_b);
@@ -264,6 +267,25 @@ int pfann_load_weight(pfann_ctx *c, const char *name, const float *host, int64_t
                 }
                 if (upload(&L.w, w.data(), numel)) return -1;
                 if (blk == 0 && !second) { c->w1_host = w; c->gram_ready = false; }
+                if (ci > 1) {
+                    // 2-term fp16 split of w * 2^e (largest magnitude in [2^14, 2^15)): hi = fl16(ws),
+                    // lo = fl16(ws - hi) exactly representable residual -> 2^-22 relative, both in the normal range
+                    float mx = 0.f;
+                    for (float v : w) mx = std::max(mx, std::fabs(v));
+                    int e = 0;
+                    if (mx > 0.f) { (void)std::frexp(mx, &e); e = 15 - e; }      // mx * 2^e in [2^14, 2^15)
+                    const float sc = std::ldexp(1.0f, e);
+                    std::vector<_Float16> hi((size_t)numel), lo((size_t)numel);
+                    for (size_t i = 0; i < (size_t)numel; ++i) {
+                        const float ws = w[i] * sc;
+                        hi[i] = (_Float16)ws;
+                        lo[i] = (_Float16)(ws - (float)hi[i]);
+                    }
+                    if (!L.w_hi) { PF_HIP(hipMalloc(&L.w_hi, numel * 2)); PF_HIP(hipMalloc(&L.w_lo, numel * 2)); }
+                    PF_HIP(hipMemcpy(L.w_hi, hi.data(), numel * 2, hipMemcpyHostToDevice));
+                    PF_HIP(hipMemcpy(L.w_lo, lo.data(), numel * 2, hipMemcpyHostToDevice));
+                    L.w_inv_scale = std::ldexp(1.0f, -e);
+                }
             }
         } else if (strncmp(mod, "ln", 2) == 0) {
             const int64_t hw = (int64_t)L.Fo * L.To;
@@ -377,7 +399,7 @@ static int encode_chunk_fused(pfann_ctx *c, const float *mel, int64_t B, float *
     for (int i = 1; i < 16; ++i) {
         const bool first = fold_first && i == 1;
         if (launch_conv_gemm_ln(c->sub[i], c->sub[i - 1], first ? mel : buf[(i - 1) & 1], part[(i - 1) & 1], P, c->stats + slot0 * 2, buf[i & 1],
-                                part[i & 1], B, g.activation, g.relu_after_bn, first ? &c->sub[0] : nullptr, s)) return -1;
+                                part[i & 1], B, g.activation, g.relu_after_bn, first ? &c->sub[0] : nullptr, c->precision, s)) return -1;
         P = fused_out_slots(c->sub[i], B);
         if (c->keep && keep_tap_fused(c, i, buf[i & 1], part[i & 1], P, B, s)) return -1;
     }
@@ -480,6 +502,11 @@ void pfann_debug_keep(pfann_ctx *c, int on) { c->keep = on != 0; }
 int pfann_set_streams(pfann_ctx *c, int n) {
     c->n_streams = n < 1 ? 1 : (n > 8 ? 8 : n);
     return c->n_streams;
+}
+
+int pfann_set_encoder_precision(pfann_ctx *c, int mode) {
+    c->precision = (mode == 1 && c->fused) ? 1 : 0;
+    return c->precision;
 }
 
 int pfann_set_fused_layernorm(pfann_ctx *c, int on) {

@@ -86,6 +86,10 @@ __device__ __forceinline__ f32x4_t buf_load4(__amdgpu_buffer_rsrc_t r, unsigned 
     return __builtin_bit_cast(f32x4_t, v);
 }
 
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2_t buf_load2u(__amdgpu_buffer_rsrc_t r, unsigned byte_off, int soff = 0) {
+    return __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, soff, 0);
+}
 __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
 }
@@ -120,6 +124,10 @@ struct SubLayer {          // one conv (+LN+act) sub-layer, channels-last activa
     float *w;              // [co][3][ci] (full) or [co][3] (depthwise / ci==1)
     float *bias;           // [co]
     float *ln_w, *ln_b;    // [Fo][To][co]  (channels-last re-layout of [co][Fo][To])
+    // optional 2-term fp16 split of w * w_scale (w_scale a power of two), same [co][3][ci] layout:
+    // w * w_scale = hi + lo to 2^-22 relative (encoder_fused.hip, SPLIT kernels)
+    void *w_hi, *w_lo;
+    float w_inv_scale;
 };
 
 }  // namespace pfann

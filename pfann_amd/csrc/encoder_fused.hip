@@ -30,6 +30,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct FusedGemmParams {
     const float *x, *w, *bias;
+    const void *w_hi, *w_lo;     // SPLIT kernels: fp16 halves of w * 2^e, [N][K]
+    float w_inv_scale;           // 2^-e
     float *y;
     int M;                       // B * rows_per_sample (< 2^31, checked by the launcher)
     int N, K, Ci;
@@ -60,7 +62,10 @@ struct FusedGemmParams {
 // tensor through HBM; p.x is then the log-mel batch [B][F][T0].
 // UNI = true: Ci % 32 == 0, see "Operand addressing" below.
 // BK = K-tile depth: 32, or 16 for the 4-wave 128x128 variant that fits three workgroups per CU.
-template <int BM, int BN, int WM, int WN, bool RELU_BN, bool FIRST, bool UNI, int BK = 32>
+// SPLIT: operands as two fp16 terms each (x = hi + lo to 2^-22 relative), three fp16 MFMAs per product
+// term (hi*hi + lo*hi + hi*lo, fp32 accumulate) instead of one fp32 MFMA: ~fp32 accuracy at 3/16 of the
+// MFMA cycles.  Opt-in (pfann_set_encoder_precision); the default path is the exact fp32 one.
+template <int BM, int BN, int WM, int WN, bool RELU_BN, bool FIRST, bool UNI, int BK = 32, bool SPLIT = false>
 __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM / WM) * (BN / WN) == 8 ? 4 : (BK == 16 ? 3 : 1))
 void conv_gemm_ln_kernel(FusedGemmParams p) {
     constexpr int LDK = BK + 4, TPR = BK / 4;         // TPR loader threads per tile row (4 floats each)
@@ -115,6 +120,8 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
     const __amdgpu_buffer_rsrc_t srd_w = make_srd(p.ln_w, (unsigned long long)p.in_elems * 4ull);
     const __amdgpu_buffer_rsrc_t srd_lb = make_srd(p.ln_b, (unsigned long long)p.in_elems * 4ull);
     const __amdgpu_buffer_rsrc_t srd_b = make_srd(p.w, (unsigned long long)p.N * p.K * 4ull);
+    const __amdgpu_buffer_rsrc_t srd_bh = make_srd(p.w_hi, SPLIT ? (unsigned long long)p.N * p.K * 2ull : 0ull);
+    const __amdgpu_buffer_rsrc_t srd_bl = make_srd(p.w_lo, SPLIT ? (unsigned long long)p.N * p.K * 2ull : 0ull);
     int aoff[AR], arel[AR], ap0[AR], atq[AR];
     float amu[AR], ars[AR];
 #pragma unroll
@@ -180,6 +187,7 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
 
     struct Stage {                       // one K-tile of prefetched operands, in registers
         f32x4 ra[AR], rw[AR], rbb[AR], rb[BR];   // FIRST: ra[i][0..2] = the three log-mel taps
+                                                  // SPLIT: rb[j] = (hi k0..3 as 2 dwords, lo k0..3 as 2 dwords)
         int cc;                                   // channel of element 0 (first-conv weights come from LDS)
     };
     auto load_tile = [&](Stage &S) {
@@ -205,8 +213,15 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
         }
         S.cc = kok ? c + (UNI ? col4 * 4 : 0) : 0;
 #pragma unroll
-        for (int j = 0; j < BR; ++j)
-            S.rb[j] = buf_load4(srd_b, (UNI || vb[j] == BUF_OOB) ? vb[j] : (kok ? vb[j] + (unsigned)kap * 4u : BUF_OOB), so_k);
+        for (int j = 0; j < BR; ++j) {
+            if (SPLIT) {     // UNI only: 4 k as halves = 8 bytes from each of the hi / lo arrays
+                const unsigned o2 = vb[j] == BUF_OOB ? BUF_OOB : vb[j] >> 1;
+                const u32x2_t hh = buf_load2u(srd_bh, o2, so_k >> 1), ll = buf_load2u(srd_bl, o2, so_k >> 1);
+                S.rb[j] = __builtin_bit_cast(f32x4, u32x4_t{hh[0], hh[1], ll[0], ll[1]});
+            } else {
+                S.rb[j] = buf_load4(srd_b, (UNI || vb[j] == BUF_OOB) ? vb[j] : (kok ? vb[j] + (unsigned)kap * 4u : BUF_OOB), so_k);
+            }
+        }
         kap += BK;
         c += BK;
         if (UNI) {
@@ -254,11 +269,34 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
                     v[2 * h + e] = t[e];
                 }
             }
-            *reinterpret_cast<f32x4 *>(&Ad[(rowq + RPT * i) * LDK + col4 * 4]) = v;
+            if (SPLIT) {
+                // row = [hi: BK halves][lo: BK halves][pad]; this thread's 4 k go to byte 8*col4 of each half-row
+                typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                f16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float c = RELU_BN ? fminf(v[e], 65000.f) : fminf(fmaxf(v[e], -65000.f), 65000.f);
+                    hi[e] = (_Float16)c;
+                    lo[e] = (_Float16)(c - (float)hi[e]);
+                }
+                char *row = reinterpret_cast<char *>(&Ad[(rowq + RPT * i) * LDK]);
+                *reinterpret_cast<f16x4 *>(row + col4 * 8) = hi;
+                *reinterpret_cast<f16x4 *>(row + BK * 2 + col4 * 8) = lo;
+            } else {
+                *reinterpret_cast<f32x4 *>(&Ad[(rowq + RPT * i) * LDK + col4 * 4]) = v;
+            }
         }
 #pragma unroll
-        for (int j = 0; j < BR; ++j)
-            *reinterpret_cast<f32x4 *>(&Bd[(rowq + RPT * j) * LDK + col4 * 4]) = S.rb[j];
+        for (int j = 0; j < BR; ++j) {
+            if (SPLIT) {
+                const u32x4_t r = __builtin_bit_cast(u32x4_t, S.rb[j]);
+                char *row = reinterpret_cast<char *>(&Bd[(rowq + RPT * j) * LDK]);
+                *reinterpret_cast<u32x2_t *>(row + col4 * 8) = u32x2_t{r[0], r[1]};
+                *reinterpret_cast<u32x2_t *>(row + BK * 2 + col4 * 8) = u32x2_t{r[2], r[3]};
+            } else {
+                *reinterpret_cast<f32x4 *>(&Bd[(rowq + RPT * j) * LDK + col4 * 4]) = S.rb[j];
+            }
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -281,30 +319,73 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
         const float *Ac = As + (kt & 1) * (BM * LDK), *Bc = Bs + (kt & 1) * (BN * LDK);
         float *An = As + ((kt + 1) & 1) * (BM * LDK), *Bn = Bs + ((kt + 1) & 1) * (BN * LDK);
         const bool more = kt + 1 < nk;   // UNI offsets are not range-checked against k_end: no loads past it
+        if constexpr (SPLIT) {
+            typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            f32x4 a4[TM], b4[TN];
+            for (int ks = 0; ks < BK / 16; ++ks) {           // 16 k per fp16 MFMA; lane half h holds k = 8h .. 8h+7
+                const char *arow[TM], *brow[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                a4[i] = *reinterpret_cast<const f32x4 *>(&Ac[(wm * WM + i * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
+                for (int i = 0; i < TM; ++i)
+                    arow[i] = reinterpret_cast<const char *>(&Ac[(wm * WM + i * 32 + l31) * LDK]) + ks * 32 + lhalf * 16;
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                b4[j] = *reinterpret_cast<const f32x4 *>(&Bc[(wn * WN + j * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
-            if (kk == 0) {
-                if (more) load_tile(S);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (kk == BK / 8 - 1) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) store_tile(S, An, Bn);
-            }
+                for (int j = 0; j < TN; ++j)
+                    brow[j] = reinterpret_cast<const char *>(&Bc[(wn * WN + j * 32 + l31) * LDK]) + ks * 32 + lhalf * 16;
+                f16x8 ah[TM], bh[TN], bl[TN];
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+                for (int j = 0; j < TN; ++j) bh[j] = *reinterpret_cast<const f16x8 *>(brow[j]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) ah[i] = *reinterpret_cast<const f16x8 *>(arow[i]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bl[j] = *reinterpret_cast<const f16x8 *>(brow[j] + BK * 2);
+                if (ks == 0) {
+                    if (more) load_tile(S);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (ks == BK / 16 - 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) store_tile(S, An, Bn);
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const f16x8 al = *reinterpret_cast<const f16x8 *>(arow[i] + BK * 2);
+#pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[j][s], a4[i][s], acc[i][j], 0, 0, 0);   // C^T: rows = n
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al, acc[i][j], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BK / 8; ++kk) {
+                f32x4 a4[TM], b4[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    a4[i] = *reinterpret_cast<const f32x4 *>(&Ac[(wm * WM + i * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    b4[j] = *reinterpret_cast<const f32x4 *>(&Bc[(wn * WN + j * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
+                if (kk == 0) {
+                    if (more) load_tile(S);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (kk == BK / 8 - 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) store_tile(S, An, Bn);
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[j][s], a4[i][s], acc[i][j], 0, 0, 0);   // C^T: rows = n
+            }
         }
         __syncthreads();
     }
@@ -337,7 +418,7 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
                 f32x4 z4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float z = acc[i][j][4 * g + e] + b4v[e];
+                    float z = SPLIT ? fmaf(acc[i][j][4 * g + e], p.w_inv_scale, b4v[e]) : acc[i][j][4 * g + e] + b4v[e];
                     if (!RELU_BN && !p.after_bn) z = act_fn(z, p.act);
                     a1 += z;
                     a2 = fmaf(z, z, a2);
@@ -441,10 +522,11 @@ static int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
 
 int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, const float *in_part, int in_P,
                         float *in_stats, float *y, float *out_part, int64_t B, int act, int after_bn,
-                        const SubLayer *Lfirst, hipStream_t s) {
+                        const SubLayer *Lfirst, int precision, hipStream_t s) {
     FusedGemmParams p;
     if (B * L.Fo * L.To >= (int64_t)0x7FFF0000) { set_error("conv_gemm_ln: batch too large"); return -1; }
     p.x = x; p.w = L.w; p.bias = L.bias; p.y = y;
+    p.w_hi = L.w_hi; p.w_lo = L.w_lo; p.w_inv_scale = L.w_inv_scale;
     p.rows_per_sample = L.Fo * L.To;
     p.M = (int)(B * p.rows_per_sample);
     p.rps_shift = ilog2(p.rows_per_sample); p.To_shift = ilog2(L.To);
@@ -496,6 +578,11 @@ int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, 
         // 8 waves (512 threads), each a 64x32 tile: half the prefetch registers per thread and four
         // waves per SIMD with two resident blocks
         constexpr bool UNI_ = true;
+        if (precision == 1 && relu_bn && L.w_hi != nullptr) {
+            const dim3 g((unsigned)blocks), t(512);
+            if (first) PF_LAUNCH((conv_gemm_ln_kernel<128, 128, 64, 32, true, true, true, 32, true>), g, t, 0, s, p);
+            else PF_LAUNCH((conv_gemm_ln_kernel<128, 128, 64, 32, true, false, true, 32, true>), g, t, 0, s, p);
+        } else
         PF_GEMM_LN(128, 128, 64, 32, 512);
     } else {
         p.n_tiles_n = cdiv(p.N, 64);

@@ -185,6 +185,10 @@ class Engine:
         """-> True if the LayerNorm-fused GEMM path is now active."""
         return bool(self.lib.pfann_set_fused_layernorm(self.handle, 1 if on else 0))
 
+    def set_encoder_precision(self, mode=0):
+        """0 = fp32 MFMA (default, exact); 1 = 3-term fp16 split on the fp16 MFMA.  -> mode in effect."""
+        return int(self.lib.pfann_set_encoder_precision(self.handle, int(mode)))
+
     # ---- verification taps -----------------------------------------------------------
     def debug_keep(self, on=True):
         self.lib.pfann_debug_keep(self.handle, 1 if on else 0)

@@ -170,6 +170,37 @@ def test_encoder_vs_reference_golden(torch_cuda, name, fused):
     assert np.abs(emb2 - z["emb"]).max() < 1e-4
 
 
+def test_encoder_split_precision_matches_fp32(torch_cuda):
+    """Opt-in encoder arithmetic (pfann_set_encoder_precision = 1): conv products as three fp16 MFMA
+    terms of two-term operand splits, fp32 accumulation.  Must stay fp32-grade: embeddings within 2e-5
+    of the exact fp32-MFMA path on a batch large enough that the 128x128 GEMM tiles (the only ones
+    with a split instantiation) are used, and within the 1e-4 bar of the CPU oracle."""
+    from oracle import encoder as oe
+    from pfann_amd.engine import Engine
+    params = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                         "configs", "default.json")))
+    _, _, _, F, T = synth.model_dims(params)
+    sd = synth.make_state_dict(params, seed=123)
+    eng = Engine(params, 0, max_batch=512)
+    eng.load_state_dict(sd)
+    B = 512
+    x = (synth.normal(77, "t/split", B * F * T).reshape(B, F, T) * 3.0 - 6.0).astype(np.float32)
+    xt = torch_cuda.as_tensor(x).cuda()
+    assert eng.set_encoder_precision(0) == 0
+    e0 = eng.encode(xt, norm=True).cpu().numpy()
+    r0 = eng.encode(xt, norm=False).cpu().numpy()
+    assert eng.set_encoder_precision(1) == 1
+    e1 = eng.encode(xt, norm=True).cpu().numpy()
+    r1 = eng.encode(xt, norm=False).cpu().numpy()
+    assert eng.set_encoder_precision(0) == 0
+    d_emb, d_raw = np.abs(e1 - e0).max(), np.abs(r1 - r0).max() / max(1.0, np.abs(r0).max())
+    print("split vs fp32: emb %.3e raw(rel) %.3e" % (d_emb, d_raw))
+    assert np.isfinite(e1).all()
+    assert d_emb < 2e-5 and d_raw < 2e-5
+    ref = oe.encode(x[:6], sd, params, norm=True)
+    assert np.abs(e1[:6] - ref).max() < 1e-4
+
+
 def test_encoder_batch_independence_and_chunking(torch_cuda):
     """Batch 37 through max_batch=16 chunks equals per-sample results."""
     from pfann_amd.engine import Engine
