@@ -203,8 +203,12 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             if (FIRST) {
+                // the three log-mel taps of a row do not depend on the channel: with a uniform cursor they
+                // are fetched on the first K-tile of each filter tap only and stay in S.ra for the others
+                if (!UNI || c == 0 || kap == p.k_begin) {
 #pragma unroll
-                for (int t1 = 0; t1 < NA; ++t1) S.ra[i][t1] = buf_load1(srd_a, va[i][t1]);
+                    for (int t1 = 0; t1 < NA; ++t1) S.ra[i][t1] = buf_load1(srd_a, va[i][t1]);
+                }
             } else {
                 S.ra[i] = buf_load4(srd_a, va[i][0], so_c);
             }
