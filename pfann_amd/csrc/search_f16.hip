@@ -314,14 +314,22 @@ __global__ __launch_bounds__(256, 2) void scan_f16_qres_kernel(ScanParams p) {
     auto load_tile = [&](int64_t t, int bb) {
         const int64_t r0 = t * 128 * p.row_stride;
         const char *base = dbb + r0 * ROWB;
+        if ((t + 1) * 128 <= p.nrows) {      // whole tile in range (uniform): one 64-bit add per load
 #pragma unroll
-        for (int u = 0; u < NLD; ++u) {
-            // rows past the end: fetch the last row instead (their columns are masked by `nok`)
-            const bool ok = t * 128 + lrow[u] < p.nrows;
-            const char *src = ok ? base + goff[u] : dbb + last_row * ROWB + (goff[u] & (ROWB - 1));
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)&Bs[bb][(wave * NLD + u) * 256],
-                                             16, 0, 0);
+            for (int u = 0; u < NLD; ++u)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + goff[u]),
+                                                 (__attribute__((address_space(3))) void *)&Bs[bb][(wave * NLD + u) * 256],
+                                                 16, 0, 0);
+        } else {
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                // rows past the end: fetch the last row instead (their columns are masked by `nok`)
+                const bool ok = t * 128 + lrow[u] < p.nrows;
+                const char *src = ok ? base + goff[u] : dbb + last_row * ROWB + (goff[u] & (ROWB - 1));
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)&Bs[bb][(wave * NLD + u) * 256],
+                                                 16, 0, 0);
+            }
         }
     };
     if (t_lo < t_hi) load_tile(t_lo, 0);
