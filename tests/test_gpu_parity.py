@@ -85,14 +85,17 @@ def test_melspec_fused_mean_removal_matches_operator_form(torch_cuda):
     assert np.abs(a - b)[loud].max() < 1e-3
 
 
-@pytest.mark.parametrize("variant", ["naf", "log10max"])
+@pytest.mark.parametrize("variant", ["naf", "log10max", "fft512"])
 def test_melspec_variants(torch_cuda, variant):
-    """naf_mode / log10 / spec_norm='max' (melspec.py:27-30,38-49) against the oracle."""
+    """naf_mode / log10 / spec_norm='max' (melspec.py:27-30,38-49) against the oracle; "fft512": another
+    STFT size (radix-2 LDS FFT instead of the 8x8x8 register one, 63 frames: whole-tile output path)."""
     from oracle import melspec as om
     from pfann_amd.engine import Engine
     params = cfg("default")
     if variant == "naf":
         params.update(naf_mode=True, mel_log="log10")
+    elif variant == "fft512":
+        params.update(stft_n=512, stft_hop=128, n_mels=96)
     else:
         params.update(mel_log="log10", spec_norm="max")
     eng = Engine(params, 0)
