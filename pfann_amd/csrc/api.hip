@@ -671,7 +671,6 @@ int pfann_match(pfann_db *db, const float *q, const int64_t *labels, int k, cons
         if (db->match_scratch_bytes < need) {
             PF_HIP(hipStreamSynchronize((hipStream_t)stream));
             if (db->match_scratch) (void)hipFree(db->match_scratch);
-    if (db->emb_h) (void)hipFree(db->emb_h);
             db->match_scratch = nullptr; db->match_scratch_bytes = 0;
             PF_HIP(hipMalloc(&db->match_scratch, need));
             db->match_scratch_bytes = need;
