@@ -664,10 +664,11 @@ int pfann_match(pfann_db *db, const float *q, const int64_t *labels, int k, cons
     int P = 1;
     while (P < (int64_t)max_qlen * k) P <<= 1;
     a.pmax = P;
-    a.gkeys = nullptr; a.gscore = nullptr;
-    if (P > 8192) {     // longer than the LDS candidate buffer: per-query slabs in HBM
+    a.gkeys = nullptr; a.gscore = nullptr; a.ncand = nullptr; a.phase = 0;
+    const bool phased = nQ <= 16;      // a handful of queries: spread each one's candidate scoring over the GPU
+    if (P > 8192 || phased) {     // longer than the LDS candidate buffer, or phased: per-query slabs in HBM
         if ((int64_t)max_qlen * k > (1 << 22)) { set_error("match: query of %d rows x top_k %d is too long", max_qlen, k); return -1; }
-        const size_t need = (size_t)nQ * P * 12;
+        const size_t need = (size_t)nQ * P * 12 + (size_t)nQ * sizeof(int);
         if (db->match_scratch_bytes < need) {
             PF_HIP(hipStreamSynchronize((hipStream_t)stream));
             if (db->match_scratch) (void)hipFree(db->match_scratch);
@@ -677,6 +678,7 @@ int pfann_match(pfann_db *db, const float *q, const int64_t *labels, int k, cons
         }
         a.gkeys = reinterpret_cast<unsigned long long *>(db->match_scratch);
         a.gscore = reinterpret_cast<float *>(a.gkeys + (size_t)nQ * P);
+        if (phased) { a.ncand = reinterpret_cast<int *>(a.gscore + (size_t)nQ * P); a.phase = 1; }
     }
     a.results = results; a.song_scores = song_scores;
     return launch_match(a, (hipStream_t)stream);

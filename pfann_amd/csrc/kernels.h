@@ -79,6 +79,8 @@ struct RerankArgs {
     int fsm; float alpha; int mode; int only_owned;
     int pmax;               // next pow2 >= max_qlen * k (LDS sizing)
     unsigned long long *gkeys; float *gscore;   // HBM scratch [nQ][pmax] used instead of LDS when pmax > 8192
+    int *ncand;             // [nQ] scratch of the phased launch (few queries: scoring spread over the whole GPU)
+    int phase;              // 0: whole query in one workgroup; 1: candidates; 2: scores; 3: argmax (1-3 need gkeys)
     pfann_match_result *results; float *song_scores;
 };
 int launch_match(const RerankArgs &a, hipStream_t s);

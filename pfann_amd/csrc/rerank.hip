@@ -10,6 +10,7 @@
 //   -> first-wins strict-> argmax in the reference's own candidate order, so ties resolve
 //      to the smallest (song, offset) exactly as the reference does.
 #include "kernels.h"
+#include <algorithm>
 
 namespace pfann {
 
@@ -67,54 +68,77 @@ __global__ __launch_bounds__(NT) void match_kernel(RerankArgs a) {
     int P = 1;
     while (P < ntot) P <<= 1;
     if (P > a.pmax) {   // host sized the buffers for max_qlen: refuse rather than overrun
-        if (tid == 0) { pfann_match_result r; r.song = -2; r.offset = 0; r.shift = 0; r.n_cand = -1; r.score = -INFINITY; a.results[qi] = r; }
+        if (tid == 0 && a.phase <= 1) {
+            pfann_match_result r; r.song = -2; r.offset = 0; r.shift = 0; r.n_cand = -1; r.score = -INFINITY; a.results[qi] = r;
+            if (a.phase == 1) a.ncand[qi] = -1;
+        }
         return;
     }
     // candidate keys + sums live in LDS for ordinary queries and in an HBM scratch slab for very
     // long ones (same code: a workgroup's global stores are visible to it after __syncthreads)
-    unsigned long long *sk = a.gkeys ? a.gkeys + qi * (int64_t)a.pmax : sk_lds;
-    float *score = a.gkeys ? a.gscore + qi * (int64_t)a.pmax : reinterpret_cast<float *>(sk_lds + P);
+    // (phase 1 of the phased launch sorts in LDS when the list fits and only publishes the result)
+    const bool in_lds = a.gkeys == nullptr || (a.phase == 1 && a.pmax <= MAXC);
+    unsigned long long *sk = in_lds ? sk_lds : a.gkeys + qi * (int64_t)a.pmax;
+    float *score = in_lds ? reinterpret_cast<float *>(sk_lds + P) : a.gscore + qi * (int64_t)a.pmax;
 
-    // ---- candidates (database.py:133-138 / seqscore.cpp:49-60)
-    for (int i = tid; i < P; i += NT) {
-        unsigned long long key = SENT;
-        if (i < ntot) {
-            const int t = i / a.k;
-            const int64_t lab = a.labels[(q0 + t) * a.k + (i - t * a.k)];
-            if (lab >= 0) {
-                // largest s with song_pos[s] <= lab  (searchsorted side='right' - 1)
-                int lo = 0, hi = a.n_songs;   // song_pos has n_songs+1 entries; search [0, n_songs)
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (a.song_pos[mid] <= lab) lo = mid + 1; else hi = mid;
+    int nc;
+    if (a.phase <= 1) {
+        // ---- candidates (database.py:133-138 / seqscore.cpp:49-60)
+        for (int i = tid; i < P; i += NT) {
+            unsigned long long key = SENT;
+            if (i < ntot) {
+                const int t = i / a.k;
+                const int64_t lab = a.labels[(q0 + t) * a.k + (i - t * a.k)];
+                if (lab >= 0) {
+                    // largest s with song_pos[s] <= lab  (searchsorted side='right' - 1)
+                    int lo = 0, hi = a.n_songs;   // song_pos has n_songs+1 entries; search [0, n_songs)
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (a.song_pos[mid] <= lab) lo = mid + 1; else hi = mid;
+                    }
+                    const int song = lo - 1;
+                    const int tim = t / a.fsm, shift = t - tim * a.fsm;
+                    const int off = (int)(lab - a.song_pos[song] - tim);
+                    const bool owned = song >= a.song_lo && song < a.song_hi;
+                    if (song >= 0 && (owned || !a.only_owned)) key = pack_cand(a.mode, song, off, shift);
                 }
-                const int song = lo - 1;
-                const int tim = t / a.fsm, shift = t - tim * a.fsm;
-                const int off = (int)(lab - a.song_pos[song] - tim);
-                const bool owned = song >= a.song_lo && song < a.song_hi;
-                if (song >= 0 && (owned || !a.only_owned)) key = pack_cand(a.mode, song, off, shift);
             }
+            sk[i] = key;
         }
-        sk[i] = key;
+        __syncthreads();
+        // ---- sort ascending (== lexicographic candidate order of the reference)
+        bitonic_sort_keys<NT>(sk, P, tid);
+        // ---- dedup (np.unique / std::unique): blank repeats, re-sort, count survivors
+        int *dupf = reinterpret_cast<int *>(score);
+        for (int i = tid; i < P; i += NT) dupf[i] = (i > 0 && sk[i] == sk[i - 1]) ? 1 : 0;
+        __syncthreads();
+        for (int i = tid; i < P; i += NT) if (dupf[i]) sk[i] = SENT;
+        if (tid == 0) s_nc = 0;
+        __syncthreads();
+        bitonic_sort_keys<NT>(sk, P, tid);
+        for (int i = tid; i < P; i += NT)
+            if (sk[i] != SENT && (i + 1 == P || sk[i + 1] == SENT)) s_nc = i + 1;
+        __syncthreads();
+        nc = s_nc;
+        if (a.phase == 1) {          // phased launch: the sorted unique keys go to / stay in gkeys
+            if (in_lds) {
+                unsigned long long *gk = a.gkeys + qi * (int64_t)a.pmax;
+                for (int i = tid; i < nc; i += NT) gk[i] = sk[i];
+            }
+            if (tid == 0) a.ncand[qi] = nc;
+            return;
+        }
+    } else {
+        nc = a.ncand[qi];
+        if (nc < 0) return;
     }
-    __syncthreads();
-    // ---- sort ascending (== lexicographic candidate order of the reference)
-    bitonic_sort_keys<NT>(sk, P, tid);
-    // ---- dedup (np.unique / std::unique): blank repeats, re-sort, count survivors
-    int *dupf = reinterpret_cast<int *>(score);
-    for (int i = tid; i < P; i += NT) dupf[i] = (i > 0 && sk[i] == sk[i - 1]) ? 1 : 0;
-    __syncthreads();
-    for (int i = tid; i < P; i += NT) if (dupf[i]) sk[i] = SENT;
-    if (tid == 0) s_nc = 0;
-    __syncthreads();
-    bitonic_sort_keys<NT>(sk, P, tid);
-    for (int i = tid; i < P; i += NT)
-        if (sk[i] != SENT && (i + 1 == P || sk[i + 1] == SENT)) s_nc = i + 1;
-    __syncthreads();
-    const int nc = s_nc;
 
-    // ---- score every unique candidate: one wave each
-    for (int c = wave; c < nc; c += NT / 64) {
+    // ---- score every unique candidate: one wave each (phase 2: the candidates of a query are spread over
+    // gridDim.y workgroups, so a single query uses the whole GPU instead of one CU)
+    const int c_first = a.phase == 2 ? (int)blockIdx.y * (NT / 64) + wave : wave;
+    const int c_step = a.phase == 2 ? (int)gridDim.y * (NT / 64) : NT / 64;
+    if (a.phase != 3)
+    for (int c = c_first; c < nc; c += c_step) {
         const Cand cd = unpack_cand(a.mode, sk[c]);
         const int64_t start = a.song_pos[cd.song];
         const int slen = (int)(a.song_pos[cd.song + 1] - start);
@@ -139,6 +163,7 @@ __global__ __launch_bounds__(NT) void match_kernel(RerankArgs a) {
         else tot = tot / (float)max(sub_len, 1);
         if (lane == 0) score[c] = tot;
     }
+    if (a.phase == 2) return;
     __syncthreads();
 
     // ---- argmax, first-wins in candidate order (database.py:158-163 / seqscore.cpp:115-124)
@@ -229,6 +254,18 @@ int launch_match(const RerankArgs &a, hipStream_t s) {
         return -1;
     }
     ProfScope ps("seq_match", s);
+    if (a.phase == 1) {
+        // few queries: candidates (one workgroup per query) -> scores (all CUs) -> argmax
+        RerankArgs b = a;
+        PF_LAUNCH(match_kernel<1024>, dim3((unsigned)a.nQ), dim3(1024), a.pmax <= MAXC ? (size_t)a.pmax * 12 : 64, s, b);
+        b.phase = 2;
+        const unsigned chunks = (unsigned)std::min<int64_t>((a.pmax + 15) / 16, std::max<int64_t>(1, 2048 / a.nQ));
+        PF_LAUNCH(match_kernel<1024>, dim3((unsigned)a.nQ, chunks), dim3(1024), 64, s, b);
+        b.phase = 3;
+        PF_LAUNCH(match_kernel<1024>, dim3((unsigned)a.nQ), dim3(1024), 64, s, b);
+        PF_HIP(hipGetLastError());
+        return 0;
+    }
     if (a.gkeys != nullptr) {
         PF_LAUNCH(match_kernel<1024>, dim3((unsigned)a.nQ), dim3(1024), 64, s, a);
         PF_HIP(hipGetLastError());
