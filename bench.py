@@ -311,6 +311,27 @@ def main():
                   "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM, "unit": "GB/s",
                   "frac": round(gbs / PEAK_HBM, 4), "pass_us": round(us, 1),
                   "algorithmic_bytes": (r_hi - r_lo) * d * 4, "search_call_us": round(call_us, 1)}
+        # the whole path for ONE 10 s query (PCM in HBM -> decision on the host), one db pass per query
+        n1 = QUERY_SEGS
+        pcm1 = pcm_dev[:q_len].contiguous()
+        st1 = starts_dev[:n1].contiguous()
+        qs1, ql1 = np.zeros(1, np.int64), np.full(1, n1, np.int32)
+
+        def one():
+            e1 = eng.embed_windows(eng.pcm16_to_mono(pcm1), st1)
+            D1, I1 = index.search(e1, k)
+            return index.match(e1, I1, qs1, ql1)[0]
+        for _ in range(3):
+            r1 = one()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            r1 = one()
+        torch.cuda.synchronize()
+        lat = (time.perf_counter() - t1) / 20
+        single["one_query_end_to_end"] = {"ms": round(1e3 * lat, 3), "segments_per_s": round(n1 / lat, 1),
+                                          "same_decision_as_batched": bool(int(r1[0]["song"]) == int(res[0]["song"]) and
+                                                                           int(r1[0]["offset"]) == int(res[0]["offset"]))}
 
     # ------------------------------------------------------------------------- hit-rate
     hits = near = exact = 0
