@@ -2,10 +2,11 @@
 reference is single-device).  One process per GPU, `torch.distributed` backend "nccl"
 (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
 
-Per query batch there is exactly one exchange step, two tiny collectives:
-  1. every rank scans ITS shard for all query rows -> all_gather of the per-shard top-k
-     (score f32, global label i64)[Q,k] -> every rank merges to the GLOBAL top-k (needed for
-     parity: the reference's candidates come from the global list);
+Per query batch there is exactly one exchange step, small collectives only:
+  1. every rank scans ITS shard for all query rows -> all-to-all of the per-shard top-k
+     (score f32, global label i64)[Q,k] by query slice -> rank r merges slice r to the GLOBAL top-k
+     -> all_gather of the merged slices (needed for parity: the reference's candidates come from
+     the global list);
   2. every rank sequence-scores the candidates whose song it owns -> all_gather of the
      per-rank best (score, song, offset, shift) -> lexicographic argmax in the reference's
      candidate order (ties -> smallest (shift, song, offset)).
@@ -56,6 +57,16 @@ def all_gather_rows(x, group=None):
     return out
 
 
+def all_to_all_rows(x, group=None):
+    """x [world, ...]: slice r goes to rank r -> out [world, ...] with out[r] = what rank r sent here."""
+    if x.is_cuda and dist.get_backend(group) == "gloo":       # debugging on one GPU: stage through host
+        return all_to_all_rows(x.cpu(), group).to(x.device)
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    dist.all_to_all_single(out.view(-1), x.view(-1), group=group)
+    return out
+
+
 def all_gather_ragged(x, counts, group=None):
     """Rows split unevenly over ranks (counts[r] rows on rank r) -> concatenated [sum, ...]."""
     world = dist.get_world_size(group)
@@ -83,14 +94,27 @@ class ShardedIndex:
         return int(song_pos[lo]), int(song_pos[hi])
 
     def search_global(self, q):
-        """q [Q, d] (identical on all ranks) -> global (D, I) [Q, k], identical on all ranks."""
+        """q [Q, d] (identical on all ranks) -> global (D, I) [Q, k], identical on all ranks.
+        The merge is itself distributed: rank r merges the per-shard lists of query slice r (all-to-all),
+        then the merged slices are all-gathered -- every rank receives 2*Q*k entries instead of G*Q*k
+        (an all-gather of everything was 93 MB per rank and step at 8 GPUs) and merges 1/G of the rows."""
         D, I = self.b.search(q, self.k)
-        gD = all_gather_rows(D, self.group)                       # [G, Q, k]
-        gI = all_gather_rows(I, self.group)
-        Q = q.shape[0]
-        S = gD.permute(1, 0, 2).reshape(Q, self.world * self.k)   # rank-major: ascending labels on ties
-        L = gI.permute(1, 0, 2).reshape(Q, self.world * self.k)
-        return self.b.merge_topk(S, L, self.k)
+        G, k, Q = self.world, self.k, q.shape[0]
+        if G == 1:
+            return D, I
+        Qs = (Q + G - 1) // G
+        pad = Qs * G - Q
+        if pad:
+            D = torch.cat([D, torch.full((pad, k), -3.4028234663852886e38, dtype=D.dtype, device=D.device)])
+            I = torch.cat([I, torch.full((pad, k), -1, dtype=I.dtype, device=I.device)])
+        rD = all_to_all_rows(D.view(G, Qs, k), self.group)        # [source shard, my Qs queries, k]
+        rI = all_to_all_rows(I.view(G, Qs, k), self.group)
+        S = rD.permute(1, 0, 2).reshape(Qs, G * k)                # shard-major: ascending labels on ties
+        L = rI.permute(1, 0, 2).reshape(Qs, G * k)
+        Dm, Im = self.b.merge_topk(S.contiguous(), L.contiguous(), k)
+        gD = all_gather_rows(Dm, self.group).reshape(G * Qs, k)[:Q]
+        gI = all_gather_rows(Im, self.group).reshape(G * Qs, k)[:Q]
+        return gD.contiguous(), gI.contiguous()
 
     def query_batch(self, q, qstart, qlen):
         """-> structured array (song, offset, shift, score) per query, identical on all ranks."""
