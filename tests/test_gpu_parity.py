@@ -340,6 +340,22 @@ def test_search_topk_more_than_4096_survivors(torch_cuda, nq):
     _check_topk(torch_cuda, db.astype(np.float32), q.astype(np.float32), 100, True)
 
 
+@pytest.mark.parametrize("case", range(8))
+def test_search_topk_random_shapes(torch_cuda, case):
+    """Seeded random (n, d, nq, k) across the regimes (single-query kernel, generic batched kernel,
+    query-stationary sub-list kernel, ragged tiles, k up to 300) against the oracle."""
+    u = synth.uniform01(900 + case, "t/shape", 8)
+    d = 128 if u[0] < 0.6 else 64
+    n = int(2000 + u[1] ** 2 * 180000)
+    nq = [1, 19, 33, 70, 300, 1030, 1500, 2300][case]
+    k = int(1 + u[2] ** 2 * 299)
+    db = synth.unit_rows(910 + case, "t/rs", n, d)
+    q = synth.unit_rows(920 + case, "t/rsq", nq, d)
+    q[::3] = db[(np.arange(len(q[::3])) * 7919 + case) % n] + 0.3 * q[::3]
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    _check_topk(torch_cuda, db.astype(np.float32), q.astype(np.float32), k, True)
+
+
 def test_search_prefilter_near_ties_stay_exact(torch_cuda):
     """Adversarial for the fp16 pre-filter: thousands of rows whose exact scores differ by ~1e-6
     (far below fp16 resolution, 1e-3) around the k-th best.  The re-scoring window (2 eps below
