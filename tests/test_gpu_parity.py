@@ -456,8 +456,10 @@ def test_seq_score_c_abi_vs_oracle(torch_cuda, name):
         assert np.allclose(ss[:, 0], wss[:, 0], atol=2e-6)
 
 
-def test_match_batched_random_vs_oracle(torch_cuda):
-    """Many queries in one launch, real search output as labels, vs the python-path oracle."""
+@pytest.mark.parametrize("nq_total", [40, 7])
+def test_match_batched_random_vs_oracle(torch_cuda, nq_total):
+    """Many queries in one launch, real search output as labels, vs the python-path oracle
+    (7 queries: the phased launch that spreads each query's candidates over the whole GPU)."""
     from oracle import seqscore as osq
     from pfann_amd.database import DeviceIndex
     d = 128
@@ -469,7 +471,7 @@ def test_match_batched_random_vs_oracle(torch_cuda):
     idx.load(db, pos, 0)
     qs, qstart, qlen = [], [], []
     n = 0
-    for j in range(40):
+    for j in range(nq_total):
         s = (j * 37) % 300
         if key[s] < 25:
             s += 1
@@ -485,7 +487,7 @@ def test_match_batched_random_vs_oracle(torch_cuda):
     D, I = idx.search(qt, 100)
     res, _ = idx.match(qt, I, qstart, qlen, 1, 0.0, 0, False, False)
     In = I.cpu().numpy()
-    for j in range(40):
+    for j in range(nq_total):
         sl = slice(qstart[j], qstart[j] + qlen[j])
         score, (song, sec), _ = osq.query_embeddings_base(q[sl], In[sl], db, pos, 0.5, 1)
         assert int(res[j]["song"]) == song and int(res[j]["offset"]) * 0.5 == sec, j
