@@ -8,6 +8,8 @@ normalized=False, onesided=True) -> |.|**power -> fb^T @ spec, with fb[n_freqs, 
 the triangular bank built in fp32 from linspace(0, sr//2, n_freqs) and
 linspace(mel(f_min), mel(f_max), n_mels+2) as max(0, min(down, up)).
 Everything outside the transform follows melspec.py:33-50 line by line.
+Second opinion (not a pin): tests/test_oracle.py compares this restatement with
+transformers.audio_utils (an unrelated numpy/fp64 implementation of the same semantics).
 """
 import math
 

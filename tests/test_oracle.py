@@ -141,3 +141,35 @@ def test_melspec_restatement_self_consistency():
     assert m32.shape == (5, 256, 32)
     assert np.abs(m32 - m64).max() < 5e-3
     assert np.abs(m32 - m64).mean() < 1e-4
+
+
+def test_melspec_oracle_vs_independent_third_party():
+    """a2 cannot be pinned against torchaudio (absent, version unpinned).  Second opinion from an
+    unrelated implementation of the same documented semantics that IS installed here:
+    transformers.audio_utils (numpy, fp64): HTK mel bank without normalisation, periodic-hann STFT
+    with centre reflect padding, power 2, then ln(x + 1e-8).  The bank differs by the fp32-vs-fp64
+    construction only (<= 3.9e-5); the log-mel agrees to 1e-4 in the audible bins."""
+    au = pytest.importorskip("transformers.audio_utils")
+    from oracle import melspec as om
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = json.load(open(os.path.join(repo, "configs", "default.json")))
+    fb = np.asarray(om.mel_filterbank(p["sample_rate"], p["stft_n"], p["n_mels"], p["f_min"], p["f_max"]))
+    fb2 = au.mel_filter_bank(num_frequency_bins=p["stft_n"] // 2 + 1, num_mel_filters=p["n_mels"],
+                             min_frequency=p["f_min"], max_frequency=p["f_max"], sampling_rate=p["sample_rate"],
+                             norm=None, mel_scale="htk")
+    assert fb.shape == fb2.shape and np.abs(fb - fb2).max() < 5e-5
+    w = au.window_function(p["stft_n"], "hann", periodic=True)
+    for seed in (1, 2):
+        x = synth.normal(seed, "t/au", 8000).astype(np.float32)
+        x[2000:6000] += np.sin(np.arange(4000) * 2 * np.pi * (700 + 300 * seed) / 8000).astype(np.float32) * 3
+        x -= x.mean()
+        ref = om.melspec(x[None], p)[0]
+        xn = (x / max(np.linalg.norm(x), 1e-12)).astype(np.float64)
+        sp = au.spectrogram(xn, w, frame_length=p["stft_n"], hop_length=p["stft_hop"], fft_length=p["stft_n"],
+                            power=2.0, center=True, pad_mode="reflect", onesided=True, mel_filters=fb2,
+                            mel_floor=0.0, log_mel=None)
+        lm = np.log(sp + 1e-8)
+        assert ref.shape == lm.shape
+        loud = ref > ref.max() - 5.0
+        assert np.abs(ref - lm)[loud].max() < 3e-4, np.abs(ref - lm)[loud].max()
+        assert np.abs(ref - lm).max() < 3e-3
