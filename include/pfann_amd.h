@@ -147,13 +147,26 @@ int64_t pfann_db_ntotal(pfann_db *db);
 int pfann_db_load(pfann_db *db, const float *emb, int emb_is_device, int64_t n,
                   const int64_t *song_pos_host, int n_songs, int64_t label_base);
 
+/* Storage precision of the shard's rows; call BEFORE pfann_db_load.  Returns the mode in effect, <0 on error.
+ *   PFANN_DB_F32 (default): fp32 rows (+ an fp16 copy for the pre-filter below); every result is exact fp32.
+ *   PFANN_DB_F16: ONLY fp16 rows are kept (n*d*2 bytes, half the HBM footprint and half the bytes per scan
+ *     pass).  Search returns the k best s16 = sum_i fl16(q_i)*fl16(x_i) (exact products, fp32 accumulation on
+ *     v_mfma_f32_32x32x16_f16) with no fp32 re-scoring; the sequence matcher scores against the stored fp16
+ *     rows.  Approximate with respect to the fp32 path, like the reference's only fp16 precedent, faiss'
+ *     GpuMultipleClonerOptions.useFloat16 (database.py:101-104; cpp/faisscputest.cpp:97-108).  d % 8 == 0. */
+#define PFANN_DB_F32 0
+#define PFANN_DB_F16 1
+int pfann_db_set_storage(pfann_db *db, int mode);
+
 /* Batches of more than 64 query rows are scanned on the fp16 matrix cores with a rigorous error
  * margin and re-scored in exact fp32 (csrc/search_f16.hip): the result is the exact fp32 top-k
  * either way.  on=0 forces the all-fp32 scan.  Returns 1 if the pre-filter is now in use. */
 int pfann_db_set_prefilter(pfann_db *db, int on);
 
 /* Exact inner-product top-k of q_dev[nq][d] over the shard: D_dev[nq][k] descending,
- * I_dev[nq][k] int64 labels (+label_base); unfilled slots D=-FLT_MAX, I=-1. */
+ * I_dev[nq][k] int64 labels (+label_base); unfilled slots D=-FLT_MAX, I=-1.  Asynchronous on `stream`: the
+ * call never synchronises with the host (rows whose survivor lists overflow -- thousands of ties at the k-th
+ * score -- are recomputed exactly by a device-side fallback kernel). */
 int pfann_search_topk(pfann_db *db, const float *q_dev, int64_t nq, int k, float *D_dev,
                       int64_t *I_dev, void *stream);
 
@@ -186,7 +199,7 @@ int pfann_match(pfann_db *db, const float *q_dev, const int64_t *labels_dev, int
                 int frame_shift_mul, float score_alpha, int mode, int only_owned,
                 pfann_match_result *results_dev, float *song_scores_dev, void *stream);
 
-/* Bytes of the shard's fingerprint matrix (for roofline accounting). */
+/* Bytes of the shard's fingerprint matrix as stored (n*d*4, or n*d*2 with fp16 storage). */
 int64_t pfann_db_bytes(pfann_db *db);
 
 /* Timing hooks for bench.py: HIP events on the caller's stream around a tagged region.

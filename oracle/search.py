@@ -42,3 +42,23 @@ def flat_ip_topk_blas(query, db, k):
     D[:, :kk] = np.take_along_axis(ps, o, axis=1)
     I[:, :kk] = np.take_along_axis(part, o, axis=1)
     return D, I
+
+
+def flat_ip_topk_f16(query, db, k):
+    """fp16-storage semantics (faiss GpuMultipleClonerOptions.useFloat16, database.py:101-104): rows and
+    queries rounded to IEEE fp16, exact products, wide accumulation -- the k largest
+    s16 = sum_i fl16(q_i) * fl16(x_i).  Computed in float64 here (products of two fp16 are exact in fp32, so
+    an fp32-accumulating device differs only by summation rounding, ~1e-7 of the norm product)."""
+    q16 = np.asarray(query, np.float32).astype(np.float16).astype(np.float64)
+    x16 = np.asarray(db, np.float32).reshape(-1, q16.shape[1]).astype(np.float16).astype(np.float64)
+    nq, n = q16.shape[0], x16.shape[0]
+    D = np.full((nq, k), -np.finfo(np.float32).max, dtype=np.float64)
+    I = np.full((nq, k), -1, dtype=np.int64)
+    if n == 0:
+        return D, I
+    s = q16 @ x16.T
+    kk = min(k, n)
+    order = np.argsort(-s, axis=1, kind="stable")[:, :kk]
+    D[:, :kk] = np.take_along_axis(s, order, axis=1)
+    I[:, :kk] = order
+    return D, I

@@ -18,7 +18,7 @@ import torch
 from . import faissio
 from .engine import Engine
 from .musicdata import MusicDataset
-from .utils import StageTimer, read_config
+from .utils import StageTimer, init_logger, read_config
 
 
 def embed_files(engine, dataset, hop, batch_windows=2048, timer=None, norm=True):
@@ -87,6 +87,7 @@ def main(argv=None):
     else:
         params = read_config(configs)
     d = params["model"]["d"]
+    init_logger("builder")                                                 # builder.py:27-28
 
     print("loading model...")
     engine = Engine(params, 0, max_batch=int(os.environ.get("PFANN_MAX_BATCH", "1024")))
@@ -123,7 +124,9 @@ def main(argv=None):
     shutil.copyfile(file_list_for_db, os.path.join(dir_for_db, "songList.txt"))
     shutil.copyfile(configs, os.path.join(dir_for_db, "configs.json"))
     shutil.copyfile(model_pt, os.path.join(dir_for_db, "model.pt"))
-    print("stages:", {k: round(v, 3) for k, v in timer.t.items()}, "total %.3fs" % (time.time() - t0))
+    for name, secs in timer.t.items():                   # one stage per line, the format tools/stat.py:17 parses
+        print("%s %.6fs" % (name, secs))
+    print("total build time %.3fs" % (time.time() - t0))
     return 0
 
 

@@ -545,11 +545,15 @@ struct pfann_db {
     std::vector<int64_t> song_pos_h;
     int n_songs = 0, song_lo = 0, song_hi = 0;
     SearchWorkspace ws;
-    void *emb_h = nullptr;              // fp16 copy of the rows (pre-filter of the batched scan)
+    void *emb_h = nullptr;              // fp16 rows: a copy for the batched scan's pre-filter (fp32 storage), or the
+                                        // ONLY rows kept (fp16 storage)
+    int storage = PFANN_DB_F32;
     float xnorm_max = 0.f;
     bool prefilter = true;
     void *match_scratch = nullptr;      // long-query candidate slab (keys + sums), grown on demand
     size_t match_scratch_bytes = 0;
+    void *seq_scratch = nullptr;        // device buffers of the seq_score seam, kept between calls
+    size_t seq_scratch_bytes = 0;
 };
 
 extern "C" {
@@ -572,7 +576,9 @@ void pfann_db_destroy(pfann_db *db) {
     if (db->ws.overflow) (void)hipFree(db->ws.overflow);
     if (db->ws.thr_adj) { (void)hipFree(db->ws.thr_adj); (void)hipFree(db->ws.eps); }
     if (db->ws.qh) (void)hipFree(db->ws.qh);
+    if (db->ws.row_ovf) (void)hipFree(db->ws.row_ovf);
     if (db->match_scratch) (void)hipFree(db->match_scratch);
+    if (db->seq_scratch) (void)hipFree(db->seq_scratch);
     if (db->emb_h) (void)hipFree(db->emb_h);
     delete db;
 }
@@ -581,39 +587,74 @@ int pfann_db_set_prefilter(pfann_db *db, int on) {
     db->prefilter = on != 0;
     return (db->prefilter && db->emb_h != nullptr) ? 1 : 0;
 }
+int pfann_db_set_storage(pfann_db *db, int mode) {
+    if (mode != PFANN_DB_F32 && mode != PFANN_DB_F16) { set_error("pfann_db_set_storage: unknown mode %d", mode); return -1; }
+    if (db->n != 0 && mode != db->storage) { set_error("pfann_db_set_storage: call it before pfann_db_load"); return -1; }
+    if (mode == PFANN_DB_F16 && db->d % 8 != 0) { set_error("pfann_db_set_storage: fp16 rows need d %% 8 == 0 (d=%d)", db->d); return -1; }
+    db->storage = mode;
+    return mode;
+}
 int pfann_db_dim(pfann_db *db) { return db->d; }
 int64_t pfann_db_ntotal(pfann_db *db) { return db->n; }
-int64_t pfann_db_bytes(pfann_db *db) { return db->n * db->d * (int64_t)sizeof(float); }
+int64_t pfann_db_bytes(pfann_db *db) { return db->n * db->d * (int64_t)(db->storage == PFANN_DB_F16 ? 2 : 4); }
 
 int pfann_db_load(pfann_db *db, const float *emb, int emb_is_device, int64_t n, const int64_t *song_pos,
                   int n_songs, int64_t label_base) {
     PF_HIP(hipSetDevice(db->device));
     if (db->emb) { (void)hipFree(db->emb); db->emb = nullptr; }
     if (db->song_pos) { (void)hipFree(db->song_pos); db->song_pos = nullptr; }
-    db->n = n;
+    if (db->emb_h) { (void)hipFree(db->emb_h); db->emb_h = nullptr; }
+    db->n = 0;
     db->label_base = label_base;
     db->n_songs = n_songs;
-    if (n > 0) {
-        PF_HIP(hipMalloc(&db->emb, (size_t)n * db->d * sizeof(float)));
-        PF_HIP(hipMemcpy(db->emb, emb, (size_t)n * db->d * sizeof(float),
-                         emb_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
-    }
-    // fp16 copy + largest row norm for the batched scan's pre-filter (search_f16.hip)
-    if (db->emb_h) { (void)hipFree(db->emb_h); db->emb_h = nullptr; }
     db->xnorm_max = 0.f;
-    if (n > 0 && db->d % 8 == 0 && getenv("PFANN_NO_F16_PREFILTER") == nullptr) {
-        float *nm = nullptr;
+    if (n > 0 && db->storage == PFANN_DB_F16) {
+        // fp16-only storage: the fp32 rows pass through a bounded staging buffer and are never kept
+        float *nm = nullptr, *stage = nullptr;
+        const int64_t chunk = std::max<int64_t>(1, (64ll << 20) / ((int64_t)db->d * 4));
         PF_HIP(hipMalloc(&db->emb_h, (size_t)n * db->d * 2));
         PF_HIP(hipMalloc(&nm, sizeof(float)));
         PF_HIP(hipMemset(nm, 0, sizeof(float)));
-        if (launch_rows_to_half(db->emb, n, db->d, db->emb_h, nm, 0)) return -1;
+        if (!emb_is_device) PF_HIP(hipMalloc(&stage, (size_t)std::min(chunk, n) * db->d * sizeof(float)));
+        for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+            const int64_t nr = std::min(chunk, n - r0);
+            const float *src = emb + r0 * db->d;
+            if (!emb_is_device) {
+                PF_HIP(hipMemcpy(stage, src, (size_t)nr * db->d * sizeof(float), hipMemcpyHostToDevice));
+                src = stage;
+            }
+            if (launch_rows_to_half(src, nr, db->d, reinterpret_cast<char *>(db->emb_h) + (size_t)r0 * db->d * 2, nm, 0)) return -1;
+            PF_HIP(hipDeviceSynchronize());
+        }
         PF_HIP(hipMemcpy(&db->xnorm_max, nm, sizeof(float), hipMemcpyDeviceToHost));
         (void)hipFree(nm);
-        if (!(db->xnorm_max < 1.0e4f)) {       // fp16 range / NaN guard: keep the exact-fp32 scan only
+        if (stage) (void)hipFree(stage);
+        if (!(db->xnorm_max < 6.0e4f)) {
             (void)hipFree(db->emb_h);
             db->emb_h = nullptr;
+            set_error("db_load: rows with norm %g do not fit fp16 storage", (double)db->xnorm_max);
+            return -3;
+        }
+    } else if (n > 0) {
+        PF_HIP(hipMalloc(&db->emb, (size_t)n * db->d * sizeof(float)));
+        PF_HIP(hipMemcpy(db->emb, emb, (size_t)n * db->d * sizeof(float),
+                         emb_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+        // fp16 copy + largest row norm for the batched scan's pre-filter (search_f16.hip)
+        if (db->d % 8 == 0 && getenv("PFANN_NO_F16_PREFILTER") == nullptr) {
+            float *nm = nullptr;
+            PF_HIP(hipMalloc(&db->emb_h, (size_t)n * db->d * 2));
+            PF_HIP(hipMalloc(&nm, sizeof(float)));
+            PF_HIP(hipMemset(nm, 0, sizeof(float)));
+            if (launch_rows_to_half(db->emb, n, db->d, db->emb_h, nm, 0)) return -1;
+            PF_HIP(hipMemcpy(&db->xnorm_max, nm, sizeof(float), hipMemcpyDeviceToHost));
+            (void)hipFree(nm);
+            if (!(db->xnorm_max < 1.0e4f)) {       // fp16 range / NaN guard: keep the exact-fp32 scan only
+                (void)hipFree(db->emb_h);
+                db->emb_h = nullptr;
+            }
         }
     }
+    db->n = n;
     db->song_pos_h.assign(song_pos, song_pos + n_songs + 1);
     PF_HIP(hipMalloc(&db->song_pos, (size_t)(n_songs + 1) * sizeof(int64_t)));
     PF_HIP(hipMemcpy(db->song_pos, song_pos, (size_t)(n_songs + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
@@ -638,7 +679,7 @@ int pfann_search_topk(pfann_db *db, const float *q, int64_t nq, int k, float *D,
     const int64_t chunk = 16384;
     for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
         const int64_t n = std::min(chunk, nq - q0);
-        const int rc = search_topk(db->emb, db->prefilter ? db->emb_h : nullptr, db->xnorm_max, db->n, db->d,
+        const int rc = search_topk(db->emb, (db->prefilter || db->emb == nullptr) ? db->emb_h : nullptr, db->xnorm_max, db->n, db->d,
                                    db->label_base, q + q0 * db->d, n, k, D + q0 * k, I + q0 * k, db->ws,
                                    (hipStream_t)stream);
         if (rc) return rc;
@@ -657,7 +698,7 @@ int pfann_match(pfann_db *db, const float *q, const int64_t *labels, int k, cons
                 int only_owned, pfann_match_result *results, float *song_scores, void *stream) {
     PF_HIP(hipSetDevice(db->device));
     RerankArgs a;
-    a.db = db->emb; a.n = db->n; a.d = db->d; a.label_base = db->label_base;
+    a.db = db->emb; a.dbh = db->emb_h; a.n = db->n; a.d = db->d; a.label_base = db->label_base;
     a.song_pos = db->song_pos; a.n_songs = db->n_songs; a.song_lo = db->song_lo; a.song_hi = db->song_hi;
     a.q = q; a.labels = labels; a.k = k; a.qstart = qstart; a.qlen = qlen; a.nQ = nQ;
     a.fsm = frame_shift_mul; a.alpha = score_alpha; a.mode = mode; a.only_owned = only_owned;
@@ -693,44 +734,49 @@ int seq_score(void *index, const int64_t *song_pos, int n_songs, const float *qu
         set_error("seq_score: song_pos differs from the one the database handle was loaded with");
         return -1;
     }
-    if (query_len <= 0) return -1;
-    float *dq = nullptr, *dss = nullptr;
-    int64_t *dl = nullptr, *dqs = nullptr;
-    int32_t *dql = nullptr;
-    pfann_match_result *dres = nullptr, res;
-    int rc = -1;
+    if (query_len <= 0 || top_k <= 0) return -1;
+    // One device slab, kept in the handle between calls (grown on demand), laid out
+    //   [song_scores f32 n_songs*2 | result | qstart i64 | qlen i32 | query f32 | labels i64]
+    // and filled with ONE upload from a host image of everything but the score block; one download brings
+    // back (song_scores, result).  Per call: 1 memset + 1 H2D + the match launches + 1 D2H, no allocation.
     const size_t nq = (size_t)query_len;
+    const size_t ss_bytes = (size_t)std::max(n_songs, 1) * 2 * sizeof(float);
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_res = up16(ss_bytes), o_qs = o_res + up16(sizeof(pfann_match_result)), o_ql = o_qs + 16;
+    const size_t o_q = o_ql + 16, o_l = o_q + up16(nq * db->d * sizeof(float));
+    const size_t total = o_l + nq * top_k * sizeof(int64_t);
+    if (db->seq_scratch_bytes < total) {
+        if (db->seq_scratch) { (void)hipDeviceSynchronize(); (void)hipFree(db->seq_scratch); }
+        db->seq_scratch = nullptr; db->seq_scratch_bytes = 0;
+        if (hipMalloc(&db->seq_scratch, total + (total >> 2)) != hipSuccess) { set_error("seq_score: device allocation failed"); return -1; }
+        db->seq_scratch_bytes = total + (total >> 2);
+    }
+    char *dev = reinterpret_cast<char *>(db->seq_scratch);
+    static thread_local std::vector<char> host;
+    host.resize(std::max(total - o_qs, o_qs));
     const int64_t zero = 0;
     const int32_t ql = query_len;
-    std::vector<float> ss((size_t)n_songs * 2);
-    if (hipMalloc(&dq, nq * db->d * sizeof(float)) != hipSuccess) goto done;
-    if (hipMalloc(&dl, nq * top_k * sizeof(int64_t)) != hipSuccess) goto done;
-    if (hipMalloc(&dss, (size_t)std::max(n_songs, 1) * 2 * sizeof(float)) != hipSuccess) goto done;
-    if (hipMalloc(&dqs, sizeof(int64_t)) != hipSuccess) goto done;
-    if (hipMalloc(&dql, sizeof(int32_t)) != hipSuccess) goto done;
-    if (hipMalloc(&dres, sizeof(pfann_match_result)) != hipSuccess) goto done;
-    (void)hipMemcpy(dq, query, nq * db->d * sizeof(float), hipMemcpyHostToDevice);
-    (void)hipMemcpy(dl, labels, nq * top_k * sizeof(int64_t), hipMemcpyHostToDevice);
-    (void)hipMemset(dss, 0, (size_t)std::max(n_songs, 1) * 2 * sizeof(float));
-    (void)hipMemcpy(dqs, &zero, sizeof(int64_t), hipMemcpyHostToDevice);
-    (void)hipMemcpy(dql, &ql, sizeof(int32_t), hipMemcpyHostToDevice);
-    if (pfann_match(db, dq, dl, top_k, dqs, dql, 1, query_len, frame_shift_mul, score_alpha, 1, 0, dres, dss,
-                    nullptr) != 0) goto done;
-    if (hipMemcpy(&res, dres, sizeof(res), hipMemcpyDeviceToHost) != hipSuccess) goto done;
-    if (hipMemcpy(ss.data(), dss, ss.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) goto done;
-    if (res.song == -2) { set_error("seq_score: query_len*top_k too large for the LDS candidate buffer"); goto done; }
+    memcpy(host.data(), &zero, sizeof(zero));
+    memcpy(host.data() + (o_ql - o_qs), &ql, sizeof(ql));
+    memcpy(host.data() + (o_q - o_qs), query, nq * db->d * sizeof(float));
+    memcpy(host.data() + (o_l - o_qs), labels, nq * top_k * sizeof(int64_t));
+    if (hipMemsetAsync(dev, 0, ss_bytes, nullptr) != hipSuccess ||
+        hipMemcpyAsync(dev + o_qs, host.data(), total - o_qs, hipMemcpyHostToDevice, nullptr) != hipSuccess) {
+        set_error("seq_score: upload failed");
+        return -1;
+    }
+    if (pfann_match(db, reinterpret_cast<float *>(dev + o_q), reinterpret_cast<int64_t *>(dev + o_l), top_k,
+                    reinterpret_cast<int64_t *>(dev + o_qs), reinterpret_cast<int32_t *>(dev + o_ql), 1, query_len,
+                    frame_shift_mul, score_alpha, 1, 0, reinterpret_cast<pfann_match_result *>(dev + o_res),
+                    reinterpret_cast<float *>(dev), nullptr) != 0) return -1;
+    if (hipMemcpy(host.data(), dev, o_qs, hipMemcpyDeviceToHost) != hipSuccess) { set_error("seq_score: download failed"); return -1; }
+    pfann_match_result res;
+    memcpy(&res, host.data() + o_res, sizeof(res));
+    if (res.song == -2) { set_error("seq_score: query_len*top_k too large for the candidate buffer"); return -1; }
+    const float *ss = reinterpret_cast<const float *>(host.data());
     for (int s = 0; s < n_songs; ++s)            // seqscore.cpp:126-133 against the caller's slots
         if (ss[2 * s] > song_scores[2 * s]) { song_scores[2 * s] = ss[2 * s]; song_scores[2 * s + 1] = ss[2 * s + 1]; }
-    rc = res.song;
-done:
-    if (rc == -1 && g_err[0] == 0) set_error("seq_score: device allocation or copy failed");
-    if (dq) (void)hipFree(dq);
-    if (dl) (void)hipFree(dl);
-    if (dss) (void)hipFree(dss);
-    if (dqs) (void)hipFree(dqs);
-    if (dql) (void)hipFree(dql);
-    if (dres) (void)hipFree(dres);
-    return rc;
+    return res.song;
 }
 
 // ---- profiling ------------------------------------------------------------------------

@@ -56,15 +56,20 @@ struct SearchWorkspace {
     int *cnt = nullptr;     // [cap_q]
     float *cs = nullptr;    // [cap_q][cap_c]
     int64_t *cl = nullptr;  // [cap_q][cap_c]
-    int *overflow = nullptr;
+    int *overflow = nullptr;   // [0] unused, [1] rows left to the big select kernel, [2..3] spare
+    int *row_ovf = nullptr;    // [cap_q] set by a select kernel whose row lost survivors (a sub-list overflowed);
+                               // topk_fallback_kernel recomputes those rows exactly ON DEVICE and clears the flag:
+                               // no host round trip, no retry loop (allocated zeroed)
     // fp16 pre-filter path (search_f16.hip)
     float *thr_adj = nullptr;  // [cap_q] tau - eps
     float *eps = nullptr;      // [cap_q] per-row bound of |s16 - s|
     void *qh = nullptr;        // [cap_q][d] fp16 query rows
     int64_t qh_elems = 0;
 };
-// dbh != nullptr: fp16 copy of the rows for the pre-filter path (used for batches > 64 rows);
-// xnorm_max = largest row norm of db.
+// db != nullptr: fp32 rows, exact results; dbh != nullptr additionally: fp16 copy of the rows for the pre-filter path
+// (batches > 64 rows), xnorm_max = largest row norm of db.
+// db == nullptr (fp16-only storage, pfann_db_set_storage): scores are s16 = sum fl16(q_i) * fl16(x_i) accumulated in
+// fp32, no fp32 re-scoring.  Fully asynchronous on `s`: no host synchronisation inside.
 int search_topk(const float *db, const void *dbh, float xnorm_max, int64_t n, int d, int64_t label_base,
                 const float *q, int64_t nq, int k, float *D, int64_t *I, SearchWorkspace &ws, hipStream_t s);
 int topk_merge(const float *S, const int64_t *L, int64_t nq, int m, int k, float *D, int64_t *I,
@@ -72,7 +77,8 @@ int topk_merge(const float *S, const int64_t *L, int64_t nq, int m, int k, float
 
 // ---- rerank.hip ----------------------------------------------------------------------
 struct RerankArgs {
-    const float *db; int64_t n; int d; int64_t label_base;
+    const float *db; const void *dbh;   // fp32 rows, or (db == nullptr) fp16 rows
+    int64_t n; int d; int64_t label_base;
     const int64_t *song_pos; int n_songs; int song_lo, song_hi;  // owned songs [lo,hi)
     const float *q; const int64_t *labels; int k;
     const int64_t *qstart; const int32_t *qlen; int64_t nQ;
@@ -84,5 +90,7 @@ struct RerankArgs {
     pfann_match_result *results; float *song_scores;
 };
 int launch_match(const RerankArgs &a, hipStream_t s);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): the attribute is per device
+int ensure_dyn_lds(const void *func, int bytes);
 
 }  // namespace pfann

@@ -147,10 +147,16 @@ __global__ __launch_bounds__(NT) void match_kernel(RerankArgs a) {
         for (int j = 0; j < sub_len; ++j) {
             const int r = cd.off + j;
             if (r < 0 || r >= slen) continue;
-            const float *v = a.db + (start + r - a.label_base) * a.d;
+            const int64_t ro = (start + r - a.label_base) * a.d;
             const float *qv = a.q + (q0 + (int64_t)j * a.fsm + cd.shift) * a.d;
             float part = 0.f;
-            for (int e = lane; e < a.d; e += 64) part = fmaf(v[e], qv[e], part);
+            if (a.db != nullptr) {
+                const float *v = a.db + ro;
+                for (int e = lane; e < a.d; e += 64) part = fmaf(v[e], qv[e], part);
+            } else {                      // fp16-only storage: the stored rows are what a reconstruct() returns
+                const _Float16 *v = reinterpret_cast<const _Float16 *>(a.dbh) + ro;
+                for (int e = lane; e < a.d; e += 64) part = fmaf((float)v[e], qv[e], part);
+            }
             if (a.mode == 0) {
                 tot += part;
             } else {
@@ -243,12 +249,7 @@ int launch_match(const RerankArgs &a, hipStream_t s) {
     if (a.nQ <= 0) return 0;
     if (a.fsm < 1 || a.fsm > 32) { set_error("match: frame_shift_mul=%d outside 1..32", a.fsm); return -1; }
     if (a.n_songs >= (1 << 30)) { set_error("match: too many songs"); return -1; }
-    static bool attr_set = false;
-    if (!attr_set) {
-        PF_HIP(hipFuncSetAttribute((const void *)match_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   MAXC * 12));
-        attr_set = true;
-    }
+    if (ensure_dyn_lds((const void *)match_kernel<1024>, MAXC * 12)) return -1;
     if (a.pmax > MAXC && a.gkeys == nullptr) {
         set_error("match: max_qlen*top_k needs %d candidate slots > %d and no scratch was given", a.pmax, MAXC);
         return -1;

@@ -15,6 +15,8 @@
 //   * a list overflow on the final level (pathological ties / duplicates) raises tau from
 //     the captured survivors and rescans; it never degrades to an approximate answer.
 #include <algorithm>
+#include <utility>
+#include <vector>
 
 #include "search_common.h"
 
@@ -54,15 +56,18 @@ __global__ __launch_bounds__(256, 2) void scan_emit_kernel(ScanParams p) {
     // bounds-checked buffer loads (OOB lanes read 0); windows start at this block's first rows
     const int64_t mq0 = (int64_t)mt0 * BM;
     const __amdgpu_buffer_rsrc_t srd_q = make_srd(p.q + mq0 * p.d, (unsigned long long)(p.nq - mq0) * p.d * 4ull);
-    const int64_t row0 = n0 * p.row_stride;
-    const int64_t rows_left = (p.nrows - n0 - 1) * p.row_stride + 1;
-    const __amdgpu_buffer_rsrc_t srd_db = make_srd(p.db + row0 * p.d, (unsigned long long)rows_left * p.d * 4ull);
+    // one window per 32-row sub-tile: on a coarse sampling level of a large shard (row_stride up to 65536) the
+    // rows of one 128-row tile span more than the 2 GB a buffer offset can address, 32 rows never do
+    // (launch_scan checks 31 * row_stride * d * 4 < 2 GB)
+    __amdgpu_buffer_rsrc_t srd_db[BR];
     unsigned doff[BR];
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
-        const int64_t rl = rowq + 32 * j;
-        const unsigned long long off = (unsigned long long)rl * p.row_stride * p.d * 4ull;
-        doff[j] = (n0 + rl < p.nrows && off < 0x7FFF0000ull) ? (unsigned)off : BUF_OOB;
+        const int64_t nj = n0 + 32 * j;                       // first sampled row of the sub-tile
+        const int64_t left = p.nrows - nj;                    // sampled rows from there on
+        srd_db[j] = make_srd(p.db + (nj < p.nrows ? nj : 0) * p.row_stride * p.d,
+                             left > 0 ? (unsigned long long)((left - 1) * p.row_stride + 1) * p.d * 4ull : 0ull);
+        doff[j] = nj + rowq < p.nrows ? (unsigned)((unsigned long long)rowq * p.row_stride * p.d * 4ull) : BUF_OOB;
     }
     f32x4 ra[AR], rb[BR];
     // load cursor of the NEXT tile to fetch, all in 32-bit byte offsets inside the two windows
@@ -79,7 +84,8 @@ __global__ __launch_bounds__(256, 2) void scan_emit_kernel(ScanParams p) {
         for (int i = 0; i < AR; ++i)
             ra[i] = buf_load4(srd_q, (kok && lrow + 32 * i < q_rows_left) ? lbase + aoff[i] + (unsigned)lkap * 4u : BUF_OOB);
 #pragma unroll
-        for (int j = 0; j < BR; ++j) rb[j] = buf_load4(srd_db, kok ? doff[j] + (unsigned)lkap * 4u : BUF_OOB);
+        for (int j = 0; j < BR; ++j)
+            rb[j] = buf_load4(srd_db[j], (kok && doff[j] != BUF_OOB) ? doff[j] + (unsigned)lkap * 4u : BUF_OOB);
         lkap += BK;
         const bool wrap = lkap >= p.d;
         lkap = wrap ? col4 * 4 : lkap;
@@ -192,81 +198,111 @@ __global__ __launch_bounds__(256, 2) void scan_emit_kernel(ScanParams p) {
 // Small-batch scan (nq <= 32, d = 128 or 64): the HBM-bound regime (one 10 s query = 19 rows;
 // intensity Q/2 flop/byte).  Streaming design:
 //   * the query block lives in registers as MFMA A-fragments for the whole kernel;
-//   * every wave owns whole 32-row db tiles (16 KB contiguous at d = 128) and reads them with
-//     fully contiguous 1 KB-per-instruction buffer loads (HBM-friendly bursts, each byte once);
+//   * every wave owns a CONTIGUOUS, row-granular range of the (sampled) rows -- all waves stream the same
+//     number of bytes to within one row, so there is no tail of waves with one more tile than the others --
+//     and reads it in 32-row tiles with fully contiguous 1 KB-per-instruction buffer loads (each byte once);
+//     the buffer window is rebased per tile (scalar 64-bit math), so shards beyond 2 GB keep this path, and
+//     rows past the range read as zeros through the window's own range check (no per-lane predicates);
 //   * the tile is transposed to the MFMA B-fragment layout through a WAVE-PRIVATE padded LDS tile
-//     (pitch d+4 dwords: conflict-free ds_write_b128 / ds_read_b128), so there are no workgroup
+//     (pitch RB/4+4 dwords: conflict-free ds_write_b128 / ds_read_b128), so there are no workgroup
 //     barriers at all; the next tile is already in flight in registers while the current one is
-//     on the matrix cores;
-//   * a persistent grid (2 workgroups per CU) walks the tiles: no per-tile pipeline fill.
-// K order: MFMA step s of half h uses k = 8*(s>>2) + 4*h + (s&3)  (same map for both operands).
+//     on the matrix cores.
+// ELT = 4: fp32 rows, v_mfma_f32_32x32x2_f32 (exact fp32; K order: step s of half h uses
+//          k = 8*(s>>2) + 4*h + (s&3), same map for both operands);
+// ELT = 2: fp16 rows and fp16 query rows, v_mfma_f32_32x32x16_f16 with fp32 accumulation (fp16-only storage).
+// Both read 16-byte pieces j*32 + 16*h of a row, so the staging code is shared.
+// MODE 0: emit rows with score >= thr[m] into the row's 32 sub-lists (sub-list = tile index & 31, so a run
+//         of near-duplicate rows is spread over the lists and the same-address atomics over 32 counters);
+// MODE 1: no output but the MAXIMUM score of the wave's range per query row, gmax[m][wave]: the k-th best of
+//         these G = 4*gridDim.x group maxima is the score of a real row, hence a lower bound of the k-th best
+//         overall, and a sharp one (top rows rarely share a group) -- one sampled pass + a 2048-value select
+//         replace the two sampled scan+sort levels of the generic ladder;
+// MODE 2: dense (nrows <= CAP): every score is written at slot = row.
 // ------------------------------------------------------------------------------------
-template <int D>
+template <int D, int ELT, int MODE>
 __global__ __launch_bounds__(256, 2) void scan_small_kernel(ScanParams p) {
-    constexpr int KS = D / 8;                 // float4 fragment pieces per lane
-    constexpr int LD = D + 4;                 // LDS row pitch (dwords)
-    constexpr int RPI = 256 / D;              // db rows covered by one 1 KB wave instruction (2 or 4)
-    constexpr int NI = 32 / RPI;              // load instructions per 32-row tile (16 or 8)
+    constexpr int RB = D * ELT;               // bytes per row
+    constexpr int NP = RB / 32;               // 32-byte K pieces per row
+    constexpr int LD = RB / 4 + 4;            // LDS row pitch (dwords)
+    constexpr int RPI = 1024 / RB;            // db rows covered by one 1 KB wave instruction
+    constexpr int NI = 32 / RPI;              // load instructions per 32-row tile
+    constexpr int CPR = RB / 16;              // 16-byte chunks per row
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
     __shared__ __attribute__((aligned(16))) float tile_s[4 * 32 * LD];
     __shared__ __attribute__((aligned(16))) float thr_s[32];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lhalf = lane >> 5;
-    const int64_t n_tiles = (p.nrows + 31) / 32;
-    const int64_t gw = (int64_t)blockIdx.x * 4 + wave, nw = (int64_t)gridDim.x * 4;
-    if (tid < 32) thr_s[tid] = tid < p.nq ? (p.thr != nullptr ? p.thr[tid] : -INFINITY) : INFINITY;
-    __syncthreads();
+    const int W = (int)gridDim.x * 4, gw = (int)blockIdx.x * 4 + wave;
+    const int64_t r_lo = (int64_t)gw * p.nrows / W, r_hi = (int64_t)(gw + 1) * p.nrows / W;
+    if (MODE == 0) {
+        if (tid < 32) thr_s[tid] = tid < p.nq ? p.thr[tid] : INFINITY;
+        __syncthreads();
+    }
     float *ts = tile_s + wave * 32 * LD;
-    constexpr int NSUB = 32;
-    const int sub = blockIdx.x & (NSUB - 1);
 
-    f32x4 qa[KS];
+    const char *qb = reinterpret_cast<const char *>(p.q), *dbb = reinterpret_cast<const char *>(p.db);
+    f32x4 qa[NP];
 #pragma unroll
-    for (int j = 0; j < KS; ++j)
-        qa[j] = l31 < p.nq ? *reinterpret_cast<const f32x4 *>(p.q + (int64_t)l31 * p.d + 8 * j + 4 * lhalf)
+    for (int j = 0; j < NP; ++j)
+        qa[j] = l31 < p.nq ? *reinterpret_cast<const f32x4 *>(qb + (int64_t)l31 * RB + j * 32 + lhalf * 16)
                            : f32x4{0.f, 0.f, 0.f, 0.f};
-    const __amdgpu_buffer_rsrc_t srd_db =
-        make_srd(p.db, (unsigned long long)((p.nrows - 1) * p.row_stride + 1) * p.d * 4ull);
-    const unsigned row_bytes = (unsigned)(p.row_stride * p.d * 4);
-    // lane -> (row inside the instruction's RPI rows, float4 column)
-    const int lrow = lane / (D / 4), lcol = lane % (D / 4);
+    const unsigned srow = (unsigned)p.row_stride * RB;      // bytes between two sampled rows
+    const int lrow = lane / CPR, lcol = lane % CPR;         // lane -> (row inside the instruction's RPI rows, chunk)
+    unsigned loff[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) loff[j] = (unsigned)(j * RPI + lrow) * srow + (unsigned)lcol * 16u;
 
     f32x4 st[NI];                              // next tile, in flight
-    auto load_tile = [&](int64_t t) {
+    auto load_tile = [&](int64_t r0) {
+        const int64_t left = r_hi - r0;        // wave-uniform: rows of the range from this tile on
+        const int nv = left >= 32 ? 32 : (left > 0 ? (int)left : 0);
+        const __amdgpu_buffer_rsrc_t srd = make_srd(dbb + (nv > 0 ? r0 : 0) * (int64_t)srow,
+                                                    nv > 0 ? (unsigned long long)(nv - 1) * srow + RB : 0ull);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int64_t n = t * 32 + j * RPI + lrow;
-            const bool ok = t < n_tiles && n < p.nrows;
-            st[j] = buf_load4(srd_db, ok ? (unsigned)n * row_bytes + (unsigned)lcol * 16u : BUF_OOB);
-        }
+        for (int j = 0; j < NI; ++j) st[j] = buf_load4(srd, loff[j]);
     };
-    load_tile(gw);
-    for (int64_t t = gw; t < n_tiles; t += nw) {
-        // registers -> wave-private LDS tile (previous tile's fragment reads are complete:
-        // their results fed MFMAs already issued), then put the next tile in flight
+    float mx[16];
+    if (MODE == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx[r] = -INFINITY;
+    }
+    load_tile(r_lo);
+    for (int64_t r0 = r_lo; r0 < r_hi; r0 += 32) {
+        // registers -> wave-private LDS tile (the previous tile's fragment reads are complete: their
+        // results fed MFMAs already issued), then put the next tile in flight
 #pragma unroll
         for (int j = 0; j < NI; ++j)
             *reinterpret_cast<f32x4 *>(&ts[(j * RPI + lrow) * LD + lcol * 4]) = st[j];
-        load_tile(t + nw);                     // past the end: all lanes out of range, reads zeros
+        load_tile(r0 + 32);                    // past the range: empty window, reads zeros, no traffic
         __builtin_amdgcn_sched_barrier(0);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-        for (int j = 0; j < KS; ++j) {
+        for (int j = 0; j < NP; ++j) {
             const f32x4 xb = *reinterpret_cast<const f32x4 *>(&ts[l31 * LD + 8 * j + 4 * lhalf]);
+            if (ELT == 4) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[j][e], xb[e], acc, 0, 0, 0);
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[j][e], xb[e], acc, 0, 0, 0);
+            } else {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, qa[j]), __builtin_bit_cast(f16x8, xb),
+                                                             acc, 0, 0, 0);
+            }
         }
-        // acc[r]: query row (r&3)+8*(r>>2)+4*lhalf, db row t*32 + l31
-        const int64_t n = t * 32 + l31;
-        const bool nok = n < p.nrows;
+        // acc[r]: query row (r&3)+8*(r>>2)+4*lhalf, sampled row r0 + l31
+        const int64_t n = r0 + l31;
+        const bool nok = n < r_hi;
         const unsigned row = (unsigned)(n * p.row_stride);
-        if (p.thr == nullptr) {
+        if (MODE == 2) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
                 if (nok && m < p.nq) p.keys[(int64_t)m * CAP + n] = pack_key(acc[r], row);
             }
+        } else if (MODE == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx[r] = fmaxf(mx[r], nok ? acc[r] : -INFINITY);
         } else {
             bool any = false;
 #pragma unroll
@@ -276,13 +312,15 @@ __global__ __launch_bounds__(256, 2) void scan_small_kernel(ScanParams p) {
                 for (int e = 0; e < 4; ++e) any |= acc[4 * g + e] >= th[e];
             }
             if (__any(any && nok)) {
+                constexpr int NSUB = 32;
+                const int sub = (int)(r0 >> 5) & (NSUB - 1);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
                     if (nok && acc[r] >= thr_s[m]) {
                         // same-address returning atomics serialise (~0.2 us each): with <= 32 query
                         // rows one counter per row would take ~1600 hits, so each row has NSUB
-                        // sub-lists (CAP/NSUB slots each) picked by workgroup id
+                        // sub-lists (CAP/NSUB slots each)
                         const int pos = atomicAdd(&p.cnt[m * NSUB + sub], 1);
                         if (pos < CAP / NSUB) p.keys[(int64_t)m * CAP + sub * (CAP / NSUB) + pos] = pack_key(acc[r], row);
                     }
@@ -290,19 +328,168 @@ __global__ __launch_bounds__(256, 2) void scan_small_kernel(ScanParams p) {
             }
         }
     }
+    if (MODE == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = mx[r];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));     // the half's 32 lanes
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+            if (l31 == 0 && m < p.nq) p.gmax[(int64_t)m * W + gw] = v;
+        }
+    }
+}
+
+// k-th largest of the G group maxima of every query row (MSB radix select, 4 x 8 bits, LDS histogram) ->
+// thr[m]; also zeroes the row's survivor counters for the pass that follows.
+__global__ __launch_bounds__(256) void group_max_select_kernel(const float *__restrict__ gmax, int G, int k,
+                                                               float *__restrict__ thr, int *__restrict__ cnt, int ncnt) {
+    constexpr int GMAX = 4096;
+    __shared__ unsigned sv[GMAX];
+    __shared__ int hist[256];
+    __shared__ int s_bin, s_kk;
+    const int64_t m = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < ncnt; i += 256) cnt[m * ncnt + i] = 0;
+    for (int i = tid; i < G; i += 256) sv[i] = ~f2ord(gmax[m * G + i]);          // ascending = descending score
+    __syncthreads();
+    if (G < k) { if (tid == 0) thr[m] = -INFINITY; return; }
+    unsigned prefix = 0;
+    int kk = k;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < G; i += 256) {
+            const unsigned hi = sv[i];
+            if (pass == 0 || (hi >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(hi >> shift) & 255], 1);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+            const int sum4 = c0 + c1 + c2 + c3;
+            int incl = sum4;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += v;
+            }
+            const int excl = incl - sum4;
+            if (excl < kk && kk <= incl) {          // exactly one lane
+                int rem = kk - excl, bin = 4 * lane;
+                if (rem > c0) { rem -= c0; ++bin; if (rem > c1) { rem -= c1; ++bin; if (rem > c2) { rem -= c2; ++bin; } } }
+                s_bin = bin;
+                s_kk = rem;
+            }
+        }
+        __syncthreads();
+        prefix |= (unsigned)s_bin << shift;
+        kk = s_kk;
+    }
+    if (tid == 0) thr[m] = ord2f(~prefix);
+}
+
+// ------------------------------------------------------------------------------------
+// Exact fallback for rows whose survivor lists overflowed (row_ovf[m] != 0): thousands of rows tying at the
+// k-th score, or hundreds of near-duplicates landing in one sub-list.  ONE workgroup per flagged row streams the
+// whole shard and keeps a running top-k (LDS buffer of FB keys; when it fills, sort, keep the best k, raise the
+// cut to the k-th key).  Keys order by (score desc, row asc), so ties cannot stall it.  Slow (one workgroup reads
+// N*d bytes) but it only ever runs for pathological rows, it is exact, and it keeps the host out of the loop:
+// pfann_search_topk never synchronises, never retries and cannot fail with "lists keep overflowing".
+// Unflagged rows cost one 4-byte read.  ELT = 4: fp32 rows; ELT = 2: fp16 rows, query rounded to fp16.
+// ------------------------------------------------------------------------------------
+template <int ELT>
+__global__ __launch_bounds__(256) void topk_fallback_kernel(int *__restrict__ row_ovf, const float *__restrict__ q,
+                                                            const void *__restrict__ dbv, int64_t n, int d, int k,
+                                                            float *__restrict__ D, int64_t *__restrict__ I,
+                                                            int64_t label_base) {
+    constexpr int FB = 2048, RPP = 128;           // buffer slots; rows per pass (32 row groups x 4)
+    __shared__ unsigned long long buf[FB];
+    __shared__ float qs[1024];
+    __shared__ int s_cnt;
+    __shared__ unsigned long long s_T;
+    const int64_t m = blockIdx.x;
+    if (row_ovf[m] == 0) return;
+    const int tid = threadIdx.x, sub = tid & 7, grp = tid >> 3;
+    for (int e = tid; e < d; e += 256) qs[e] = ELT == 4 ? q[m * d + e] : (float)(_Float16)q[m * d + e];
+    if (tid == 0) { s_cnt = 0; s_T = ~0ull; }
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += RPP) {
+        const unsigned long long T = s_T;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t row = base + u * 32 + grp;
+            float part = 0.f;
+            if (row < n) {
+                for (int e = sub * 4; e < d; e += 32) {
+                    float x0, x1, x2, x3;
+                    if (ELT == 4) {
+                        const float4 x4 = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(dbv) + row * d + e);
+                        x0 = x4.x; x1 = x4.y; x2 = x4.z; x3 = x4.w;
+                    } else {
+                        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                        const f16x4 h4 = *reinterpret_cast<const f16x4 *>(reinterpret_cast<const _Float16 *>(dbv) + row * d + e);
+                        x0 = (float)h4[0]; x1 = (float)h4[1]; x2 = (float)h4[2]; x3 = (float)h4[3];
+                    }
+                    part = fmaf(x0, qs[e], part); part = fmaf(x1, qs[e + 1], part);
+                    part = fmaf(x2, qs[e + 2], part); part = fmaf(x3, qs[e + 3], part);
+                }
+            }
+            part += __shfl_xor(part, 1, 64);
+            part += __shfl_xor(part, 2, 64);
+            part += __shfl_xor(part, 4, 64);
+            if (sub == 0 && row < n) {
+                const unsigned long long key = pack_key(part, (unsigned)row);
+                if (key < T) buf[atomicAdd(&s_cnt, 1)] = key;       // s_cnt <= FB - RPP before the pass
+            }
+        }
+        __syncthreads();
+        if (s_cnt > FB - RPP || base + RPP >= n) {                    // block-uniform
+            const int c = s_cnt;
+            for (int i = c + tid; i < FB; i += 256) buf[i] = ~0ull;
+            __syncthreads();
+            bitonic_sort_u64(buf, FB, tid, 256);
+            if (tid == 0) {
+                s_cnt = c < k ? c : k;
+                s_T = c >= k ? buf[k - 1] : ~0ull;
+            }
+            __syncthreads();
+        }
+    }
+    const int c = s_cnt;
+    for (int i = tid; i < k; i += 256) {
+        if (i < c) {
+            D[m * k + i] = ord2f(~(unsigned)(buf[i] >> 32));
+            I[m * k + i] = (int64_t)(unsigned)(buf[i] & 0xFFFFFFFFu) + label_base;
+        } else {
+            D[m * k + i] = -3.4028234663852886e38f;
+            I[m * k + i] = -1;
+        }
+    }
+    if (tid == 0) row_ovf[m] = 0;
+}
+
+int launch_topk_fallback(SearchWorkspace &ws, const float *q, const float *db, const void *dbh, int64_t n, int d,
+                         int64_t nq, int k, float *D, int64_t *I, int64_t label_base, hipStream_t s) {
+    if (d > 1024) { set_error("search_topk: d=%d > 1024", d); return -1; }
+    ProfScope ps("topk_fallback", s);
+    if (db != nullptr) PF_LAUNCH(topk_fallback_kernel<4>, dim3((unsigned)nq), dim3(256), 0, s, ws.row_ovf, q, (const void *)db, n, d, k, D, I, label_base);
+    else PF_LAUNCH(topk_fallback_kernel<2>, dim3((unsigned)nq), dim3(256), 0, s, ws.row_ovf, q, dbh, n, d, k, D, I, label_base);
+    PF_HIP(hipGetLastError());
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------
 // Per-query exact select: bitonic sort of the (<= CAP) packed survivors in LDS.
 //   mode 0: write thr[m] = k-th best score (or -inf when fewer than k survivors)
 //   mode 1: write D[m][k], I[m][k] (+label_base); pad with -FLT_MAX / -1
-// overflow[0] is set when a final-level list overflowed.
+// row_ovf[m] is set when a final-level list of row m overflowed.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void select_kernel(const unsigned long long *__restrict__ keys,
                                                       const int *__restrict__ cnt, int k, int mode,
                                                       float *__restrict__ thr, float *__restrict__ D,
                                                       int64_t *__restrict__ I, int64_t label_base,
-                                                      int *overflow, int nsub) {
+                                                      int *row_ovf, int nsub) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
     __shared__ int s_off[130];
     const int64_t m = blockIdx.x;
@@ -319,7 +506,7 @@ __global__ __launch_bounds__(1024) void select_kernel(const unsigned long long *
         }
         s_off[nsub] = run;
         s_off[129] = over ? 1 : 0;
-        if (over && mode == 1) atomicExch(overflow, 1);
+        if (over && mode == 1) row_ovf[m] = 1;      // topk_fallback_kernel recomputes this row
     }
     __syncthreads();
     const int n = s_off[nsub];
@@ -346,40 +533,47 @@ __global__ __launch_bounds__(1024) void select_kernel(const unsigned long long *
                 I[m * k + i] = -1;
             }
         }
-        // on overflow, publish the raised threshold for the rescan
-        if (over && tid == 0 && thr != nullptr && n >= k) thr[m] = ord2f(~(unsigned)(skeys[k - 1] >> 32));
     }
 }
+
 
 __global__ void fill_int_kernel(int *p, int v, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember (kernel, device) pairs already done
+int ensure_dyn_lds(const void *func, int bytes) {
+    static std::vector<std::pair<const void *, int>> done;       // callers hold the API's single-thread contract
+    int dev = 0;
+    PF_HIP(hipGetDevice(&dev));
+    for (auto &e : done) if (e.first == func && e.second == dev) return 0;
+    PF_HIP(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.emplace_back(func, dev);
+    return 0;
+}
+
+// generic scan (any nq, any d): fp32 MFMA tiles, one survivor list per row
 static int launch_scan(const float *db, int64_t n, int d, int64_t stride, const float *q, int64_t nq,
-                       const float *thr, SearchWorkspace &ws, int *nsub_out, hipStream_t s) {
+                       const float *thr, SearchWorkspace &ws, hipStream_t s) {
     ScanParams p;
     p.q = q; p.db = db; p.nq = nq; p.d = d;
     p.row_stride = stride;
     p.nrows = (n + stride - 1) / stride;
     p.thr = thr; p.cnt = ws.cnt; p.keys = reinterpret_cast<unsigned long long *>(ws.cl);
-    const bool small = nq <= 32 && (d == 128 || d == 64) && (uint64_t)p.nrows * stride * d * 4 < 0x7FFF0000ull;
-    p.nsub = (small && thr != nullptr) ? 32 : 1;
-    *nsub_out = p.nsub;
+    p.nsub = 1; p.gmax = nullptr;
+    if ((unsigned long long)31 * stride * d * 4ull >= 0x7FFF0000ull) {
+        set_error("scan: sampling stride %lld x d %d exceeds the 2 GB window of a 32-row sub-tile", (long long)stride, d);
+        return -1;
+    }
     if (thr == nullptr) {
         if (p.nrows > CAP) { set_error("scan: dense level with %lld rows > %d", (long long)p.nrows, CAP); return -1; }
         PF_LAUNCH(fill_int_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, s, ws.cnt, (int)p.nrows, nq);
     } else {
-        PF_HIP(hipMemsetAsync(ws.cnt, 0, sizeof(int) * nq * p.nsub, s));
+        PF_HIP(hipMemsetAsync(ws.cnt, 0, sizeof(int) * nq, s));
     }
     ProfScope ps(stride == 1 ? "scan_topk" : "scan_topk_sample", s, 2.0 * (double)nq * p.nrows * d);
-    if (small) {
-        // HBM-bound regime: persistent streaming kernel, 2 blocks per CU
-        const int64_t tiles = (p.nrows + 31) / 32;
-        const unsigned grid = (unsigned)std::min<int64_t>(512, (tiles + 3) / 4);
-        if (d == 128) PF_LAUNCH((scan_small_kernel<128>), dim3(grid), dim3(256), 0, s, p);
-        else PF_LAUNCH((scan_small_kernel<64>), dim3(grid), dim3(256), 0, s, p);
-    } else if (nq <= 32) {
+    if (nq <= 32) {
         p.n_tiles_m = 1;
         PF_LAUNCH((scan_emit_kernel<32, 128, 32, 32, 1>), dim3((unsigned)cdiv(p.nrows, 128)), dim3(256), 0, s, p);
     } else if (nq <= 64) {
@@ -402,31 +596,28 @@ static int launch_scan(const float *db, int64_t n, int d, int64_t stride, const 
 
 static int launch_select(SearchWorkspace &ws, int64_t nq, int k, int mode, float *D, int64_t *I,
                          int64_t label_base, int nsub, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        PF_HIP(hipFuncSetAttribute((const void *)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   CAP * 8));
-        attr_set = true;
-    }
+    if (ensure_dyn_lds((const void *)select_kernel, CAP * 8)) return -1;
     ProfScope ps("topk_select", s);
     PF_LAUNCH(select_kernel, dim3((unsigned)nq), dim3(1024), CAP * 8, s,
                        reinterpret_cast<const unsigned long long *>(ws.cl), ws.cnt, k, mode, ws.thr, D, I,
-                       label_base, ws.overflow, nsub);
+                       label_base, ws.row_ovf, nsub);
     PF_HIP(hipGetLastError());
     return 0;
 }
 
 static int ensure_ws(SearchWorkspace &ws, int64_t nq) {
     if (ws.cap_q >= nq) return 0;
-    if (ws.thr) { (void)hipFree(ws.thr); (void)hipFree(ws.cnt); (void)hipFree(ws.cl); }
-    if (!ws.overflow) PF_HIP(hipMalloc(&ws.overflow, 4 * sizeof(int)));    // [0] overflow flag, [1] rows left to the big select kernel
+    if (ws.thr) { (void)hipFree(ws.thr); (void)hipFree(ws.cnt); (void)hipFree(ws.cl); (void)hipFree(ws.row_ovf); }
+    if (!ws.overflow) PF_HIP(hipMalloc(&ws.overflow, 4 * sizeof(int)));    // [1] rows left to the big select kernel
     const int64_t cap = nq < 64 ? 64 : nq;
     if (ws.thr_adj) { (void)hipFree(ws.thr_adj); (void)hipFree(ws.eps); }
     PF_HIP(hipMalloc(&ws.thr_adj, sizeof(float) * cap));
     PF_HIP(hipMalloc(&ws.eps, sizeof(float) * cap));
     PF_HIP(hipMalloc(&ws.thr, sizeof(float) * cap));
-    PF_HIP(hipMalloc(&ws.cnt, sizeof(int) * (cap < 32 ? 32 : cap) * 64));      // up to 64 sub-lists per row
+    PF_HIP(hipMalloc(&ws.cnt, sizeof(int) * cap * 64));      // up to 64 sub-lists per row
     PF_HIP(hipMalloc(&ws.cl, sizeof(unsigned long long) * cap * CAP));
+    PF_HIP(hipMalloc(&ws.row_ovf, sizeof(int) * cap));
+    PF_HIP(hipMemset(ws.row_ovf, 0, sizeof(int) * cap));     // kept zero by topk_fallback_kernel afterwards
     ws.cap_q = cap;
     ws.cap_c = CAP;
     return 0;
@@ -435,6 +626,58 @@ static int ensure_ws(SearchWorkspace &ws, int64_t nq) {
 __global__ void fill_empty_kernel(float *D, int64_t *I, int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) { D[i] = -3.4028234663852886e38f; I[i] = -1; }
+}
+
+// ---- small batches (nq <= 32, d = 64 / 128): the HBM-bound streaming path ------------------------------
+//   n <= CAP            : one dense pass (every score kept) + select;
+//   otherwise           : group-maximum pass over every R-th row (2048 groups) -> k-th best group maximum = tau
+//                         (radix select of 2048 values) -> full pass emitting scores >= tau into 32 sub-lists per
+//                         row (~R*k survivors) -> 256-thread radix select + rank sort.
+// Four short launches around the one pass that reads the shard; no host synchronisation.
+template <int ELT>
+static int search_small(const void *rows, int64_t n, int d, const void *qrows, int64_t nq, int k, float *D, int64_t *I,
+                        int64_t label_base, const float *q32, SearchWorkspace &ws, hipStream_t s) {
+    ScanParams p;
+    p.q = reinterpret_cast<const float *>(qrows); p.db = reinterpret_cast<const float *>(rows);
+    p.nq = nq; p.d = d; p.cnt = ws.cnt; p.keys = reinterpret_cast<unsigned long long *>(ws.cl);
+    p.n_tiles_m = 1; p.gmax = nullptr; p.thr = nullptr;
+    const double bytes_per_row = (double)d * ELT;
+#define PF_SMALL(MODE, GRID)                                                                                  \
+    do {                                                                                                      \
+        if (d == 128) PF_LAUNCH((scan_small_kernel<128, ELT, MODE>), dim3(GRID), dim3(256), 0, s, p);         \
+        else PF_LAUNCH((scan_small_kernel<64, ELT, MODE>), dim3(GRID), dim3(256), 0, s, p);                    \
+        PF_HIP(hipGetLastError());                                                                            \
+    } while (0)
+    if (n <= CAP) {
+        p.row_stride = 1; p.nrows = n; p.nsub = 1;
+        PF_LAUNCH(fill_int_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, s, ws.cnt, (int)n, nq);
+        {
+            ProfScope ps("scan_topk", s, n * bytes_per_row);
+            PF_SMALL(2, (unsigned)std::min<int64_t>(512, cdiv(n, 128)));
+        }
+        return launch_select(ws, nq, k, 1, D, I, label_base, 1, s);
+    }
+    constexpr int GRID = 512, W = GRID * 4;            // persistent: 2 workgroups per CU; W groups in the sampled pass
+    int64_t R = k <= 128 ? 16 : (k <= 512 ? 4 : 2);    // expected survivors of the full pass ~ R * k
+    if (R > n / W) R = n / W;                          // at least one sampled row per group (n > CAP = 4 W)
+    p.row_stride = R; p.nrows = (n + R - 1) / R; p.nsub = 1;
+    p.gmax = reinterpret_cast<float *>(ws.cl);         // [nq][W] floats; the keys are written after tau is known
+    {
+        ProfScope ps("scan_topk_sample", s, p.nrows * bytes_per_row);
+        PF_SMALL(1, GRID);
+    }
+    {
+        ProfScope ps("topk_group_select", s);
+        PF_LAUNCH(group_max_select_kernel, dim3((unsigned)nq), dim3(256), 0, s, p.gmax, W, k, ws.thr, ws.cnt, 32);
+        PF_HIP(hipGetLastError());
+    }
+    p.row_stride = 1; p.nrows = n; p.nsub = 32; p.thr = ws.thr; p.gmax = nullptr;
+    {
+        ProfScope ps("scan_topk", s, n * bytes_per_row);
+        PF_SMALL(0, GRID);
+    }
+#undef PF_SMALL
+    return launch_select_rescore(ws, nq, k, 1, D, I, label_base, q32, nullptr, d, 32, 0, s);
 }
 
 int search_topk(const float *db, const void *dbh, float xnorm_max, int64_t n, int d, int64_t label_base,
@@ -448,11 +691,30 @@ int search_topk(const float *db, const void *dbh, float xnorm_max, int64_t n, in
         PF_HIP(hipGetLastError());
         return 0;
     }
+    if (db == nullptr && dbh == nullptr) { set_error("search_topk: no rows"); return -1; }
     if (ensure_ws(ws, nq)) return -1;
+    const bool half_only = db == nullptr;               // fp16-only storage: s16 scores are final
+    const bool need_qh = half_only || (dbh != nullptr && nq > 64);
+    if (need_qh) {
+        if (ws.qh_elems < nq * d) {
+            if (ws.qh) { PF_HIP(hipStreamSynchronize(s)); (void)hipFree(ws.qh); }
+            ws.qh = nullptr; ws.qh_elems = 0;
+            PF_HIP(hipMalloc(&ws.qh, (size_t)nq * d * 2));
+            ws.qh_elems = nq * d;
+        }
+        if (launch_q_prep(q, nq, d, xnorm_max, ws.qh, ws.eps, ws.row_ovf, s)) return -1;
+    }
+    if (nq <= 32 && (d == 128 || d == 64)) {
+        int rc;
+        if (half_only) rc = search_small<2>(dbh, n, d, ws.qh, nq, k, D, I, label_base, q, ws, s);
+        else rc = search_small<4>(db, n, d, q, nq, k, D, I, label_base, q, ws, s);
+        if (rc) return rc;
+        return launch_topk_fallback(ws, q, db, dbh, n, d, nq, k, D, I, label_base, s);
+    }
+    // ---- generic ladder: the shard is scanned at strides R^L .. R, 1; the coarsest level keeps everything
     // sampling ratio per level: expected survivors ~ R*k per query, kept <= CAP/4
     // (R = 8 and 4 were measured for the batched path too: more passes and selects cost more than the
     // shorter survivor lists save)
-    const bool batched = dbh != nullptr && nq > 64;
     const int R = k <= 128 ? 16 : (k <= 512 ? 4 : 2);
     int levels = 0;
     int64_t stride = 1;
@@ -460,63 +722,33 @@ int search_topk(const float *db, const void *dbh, float xnorm_max, int64_t n, in
     // 1/8 shard of 1 M rows would otherwise sort 8192 keys per row); it still holds > 4096/R >= k rows
     const int64_t DENSE_CAP = 4096;
     while ((n + stride - 1) / stride > DENSE_CAP) { stride *= R; ++levels; }
-    PF_HIP(hipMemsetAsync(ws.overflow, 0, sizeof(int), s));
-    if (batched) {
-        // ---- fp16 pre-filter + exact fp32 re-scoring (search_f16.hip): same levels, same exact result
-        if (ws.qh_elems < nq * d) {
-            if (ws.qh) (void)hipFree(ws.qh);
-            ws.qh = nullptr; ws.qh_elems = 0;
-            PF_HIP(hipMalloc(&ws.qh, (size_t)nq * d * 2));
-            ws.qh_elems = nq * d;
-        }
-        if (launch_q_prep(q, nq, d, xnorm_max, ws.qh, ws.eps, s)) return -1;
+    if (need_qh) {
+        // ---- fp16 MFMA scan (search_f16.hip).  fp32 storage: pre-filter with a rigorous margin + exact fp32
+        // re-scoring (same exact result); fp16-only storage: eps = 0, the s16 scores are the result
+        const int rescore = half_only ? 0 : 1;
         const float *ta = nullptr;
         for (int lev = levels; lev >= 1; --lev) {
             int nsub = 1;
             if (launch_scan_f16(dbh, n, d, stride, ws.qh, nq, ta, ws, true, &nsub, s)) return -1;
-            if (launch_select_rescore(ws, nq, k, 0, nullptr, nullptr, 0, q, db, d, nsub, s)) return -1;
+            if (launch_select_rescore(ws, nq, k, 0, nullptr, nullptr, 0, q, db, d, nsub, rescore, s)) return -1;
             ta = ws.thr_adj;
             stride /= R;
         }
-        for (int attempt = 0; attempt < 4; ++attempt) {
-            int nsub = 1;
-            // a retry means some sub-list overflowed (e.g. hundreds of near-duplicate rows in one place):
-            // fall back to one list of CAP entries per row
-            if (launch_scan_f16(dbh, n, d, 1, ws.qh, nq, ta, ws, attempt == 0, &nsub, s)) return -1;
-            if (launch_select_rescore(ws, nq, k, 1, D, I, label_base, q, db, d, nsub, s)) return -1;
-            int ovf = 0;
-            PF_HIP(hipMemcpyAsync(&ovf, ws.overflow, sizeof(int), hipMemcpyDeviceToHost, s));
-            PF_HIP(hipStreamSynchronize(s));
-            if (!ovf) return 0;
-            if (ta == nullptr) { set_error("search_topk: survivor list overflow without threshold"); return -1; }
-            PF_HIP(hipMemsetAsync(ws.overflow, 0, sizeof(int), s));
-        }
-        set_error("search_topk: survivor lists keep overflowing (more than %d rows tie at the k-th score?)", CAP);
-        return -4;
+        int nsub = 1;
+        if (launch_scan_f16(dbh, n, d, 1, ws.qh, nq, ta, ws, true, &nsub, s)) return -1;
+        if (launch_select_rescore(ws, nq, k, 1, D, I, label_base, q, db, d, nsub, rescore, s)) return -1;
+        return launch_topk_fallback(ws, q, db, dbh, n, d, nq, k, D, I, label_base, s);
     }
-    PF_HIP(hipMemsetAsync(ws.overflow, 0, sizeof(int), s));
     const float *thr = nullptr;
     for (int lev = levels; lev >= 1; --lev) {
-        int nsub = 1;
-        if (launch_scan(db, n, d, stride, q, nq, thr, ws, &nsub, s)) return -1;
-        if (launch_select(ws, nq, k, 0, nullptr, nullptr, 0, nsub, s)) return -1;
+        if (launch_scan(db, n, d, stride, q, nq, thr, ws, s)) return -1;
+        if (launch_select(ws, nq, k, 0, nullptr, nullptr, 0, 1, s)) return -1;
         thr = ws.thr;
         stride /= R;
     }
-    for (int attempt = 0; attempt < 4; ++attempt) {
-        int nsub = 1;
-        if (launch_scan(db, n, d, 1, q, nq, thr, ws, &nsub, s)) return -1;
-        if (launch_select(ws, nq, k, 1, D, I, label_base, nsub, s)) return -1;
-        int ovf = 0;
-        PF_HIP(hipMemcpyAsync(&ovf, ws.overflow, sizeof(int), hipMemcpyDeviceToHost, s));
-        PF_HIP(hipStreamSynchronize(s));
-        if (!ovf) return 0;
-        // survivors overflowed a list: thresholds were raised by select_kernel; rescan
-        if (thr == nullptr) { set_error("search_topk: survivor list overflow without threshold"); return -1; }
-        PF_HIP(hipMemsetAsync(ws.overflow, 0, sizeof(int), s));
-    }
-    set_error("search_topk: survivor lists keep overflowing (more than %d rows tie at the k-th score?)", CAP);
-    return -4;
+    if (launch_scan(db, n, d, 1, q, nq, thr, ws, s)) return -1;
+    if (launch_select(ws, nq, k, 1, D, I, label_base, 1, s)) return -1;
+    return launch_topk_fallback(ws, q, db, dbh, n, d, nq, k, D, I, label_base, s);
 }
 
 // ------------------------------------------------------------------------------------
@@ -555,12 +787,7 @@ int topk_merge(const float *S, const int64_t *L, int64_t nq, int m, int k, float
     if (m > 16384) { set_error("topk_merge: m=%d > 16384", m); return -1; }
     int P = 1;
     while (P < m) P <<= 1;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PF_HIP(hipFuncSetAttribute((const void *)merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   16384 * 8));
-        attr_set = true;
-    }
+    if (ensure_dyn_lds((const void *)merge_kernel, 16384 * 8)) return -1;
     ProfScope ps("topk_merge", s);
     PF_LAUNCH(merge_kernel, dim3((unsigned)nq), dim3(1024), (size_t)P * 8, s, S, L, m, k, D, I);
     PF_HIP(hipGetLastError());

@@ -33,6 +33,7 @@ struct ScanParams {
     unsigned long long *keys;  // [nq][CAP]
     int n_tiles_m;
     int nsub;                // survivor sub-lists per query row (small-batch kernel: 32), else 1
+    float *gmax;             // small-batch kernel, group-maximum mode: [nq][gridDim.x * 4]
 };
 
 
@@ -54,10 +55,13 @@ __device__ inline void bitonic_sort_u64(unsigned long long *s, int P, int tid, i
 
 // ---- fp16 pre-filter path (search_f16.hip) ------------------------------------------------
 int launch_rows_to_half(const float *x, int64_t n, int d, void *xh, float *norm_max_dev, hipStream_t s);
-int launch_q_prep(const float *q, int64_t nq, int d, float xnorm_max, void *qh, float *eps, hipStream_t s);
+int launch_q_prep(const float *q, int64_t nq, int d, float xnorm_max, void *qh, float *eps, int *row_ovf, hipStream_t s);
 int launch_scan_f16(const void *dbh, int64_t n, int d, int64_t stride, const void *qh, int64_t nq,
                     const float *thr_adj, SearchWorkspace &ws, bool allow_sublists, int *nsub_out, hipStream_t s);
+// rescore = 1: survivors within 2 eps of the k-th best approximate score are re-scored in exact fp32 from db32;
+// rescore = 0: the keys' scores are final (eps is not read)
 int launch_select_rescore(SearchWorkspace &ws, int64_t nq, int k, int mode, float *D, int64_t *I, int64_t label_base,
-                          const float *q32, const float *db32, int d, int nsub, hipStream_t s);
+                          const float *q32, const float *db32, int d, int nsub, int rescore, hipStream_t s);
+
 
 }  // namespace pfann

@@ -6,8 +6,13 @@
 //
 //   1. db rows and query rows are rounded to fp16 once (db at load, queries per call);
 //      s16 = sum fl16(q_i) * fl16(x_i) with exact products and fp32 accumulation;
-//   2. |s16 - s| <= eps_m := 1.05e-3 * ||q_m|| * max_n ||x_n|| + 1e-6   (2 * 2^-11 relative per
-//      product from the two roundings, subnormal and accumulation terms included, Cauchy-Schwarz);
+//   2. |s16 - s| <= eps_m := 1.05e-3 * ||q_m|| * X + 3.1e-8 * sqrt(d) * (||q_m|| + X),  X = max_n ||x_n||:
+//      each rounding is |dv| <= max(2^-11 |v|, 2^-25) (normal / subnormal fp16), so
+//      sum |fl(q_i) fl(x_i) - q_i x_i| <= 2^-10 sum |q_i x_i| + 2^-25 (||q||_1 + ||x||_1) + 2nd order
+//      <= 2^-10 ||q|| ||x|| + 2^-25 sqrt(d) (||q|| + ||x||) (Cauchy-Schwarz); the factor 1.05e-3 > 2^-10 = 9.77e-4
+//      leaves room for the second-order term (2^-22) and the fp32 accumulation (d 2^-24 relative, d <= 1024).
+//      Both terms scale with the norms: the bound holds for any db scale, not only unit-norm rows.  A query row
+//      whose fp16 image would overflow (||q|| >= 6e4, or NaN) is flagged for the exact device fallback instead;
 //   3. the scan emits row n for query m iff  s16 >= tau_m - eps_m,  tau_m being a lower bound of
 //      the query's k-th best EXACT score (from the sampled levels, as in search.hip): every row
 //      of the true top-k survives;
@@ -53,23 +58,28 @@ int launch_rows_to_half(const float *x, int64_t n, int d, void *xh, float *norm_
 }
 
 __global__ void q_prep_kernel(const float *__restrict__ q, int64_t nq, int d, float xnorm_max,
-                              _Float16 *__restrict__ qh, float *__restrict__ eps) {
+                              _Float16 *__restrict__ qh, float *__restrict__ eps, int *__restrict__ row_ovf) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= nq) return;
     float ss = 0.f;
     for (int e = lane; e < d; e += 64) {
         const float v = q[row * d + e];
-        qh[row * d + e] = (_Float16)v;
         ss = fmaf(v, v, ss);
     }
     ss = wave_sum(ss);
-    if (lane == 0) eps[row] = 1.05e-3f * sqrtf(ss) * xnorm_max + 1e-6f;
+    const bool bad = !(ss < 3.6e9f);                       // ||q|| >= 6e4 or NaN: outside fp16's range
+    for (int e = lane; e < d; e += 64) qh[row * d + e] = bad ? (_Float16)0.f : (_Float16)q[row * d + e];
+    if (lane == 0) {
+        const float nq2 = sqrtf(ss);
+        eps[row] = 1.05e-3f * nq2 * xnorm_max + 3.1e-8f * sqrtf((float)d) * (nq2 + xnorm_max);
+        if (bad) row_ovf[row] = 1;                          // recomputed exactly by topk_fallback_kernel
+    }
 }
 
-int launch_q_prep(const float *q, int64_t nq, int d, float xnorm_max, void *qh, float *eps, hipStream_t s) {
+int launch_q_prep(const float *q, int64_t nq, int d, float xnorm_max, void *qh, float *eps, int *row_ovf, hipStream_t s) {
     PF_LAUNCH(q_prep_kernel, dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, s, q, nq, d, xnorm_max,
-                       reinterpret_cast<_Float16 *>(qh), eps);
+                       reinterpret_cast<_Float16 *>(qh), eps, row_ovf);
     PF_HIP(hipGetLastError());
     return 0;
 }
@@ -110,15 +120,16 @@ __global__ __launch_bounds__(256, 2) void scan_f16_kernel(ScanParams p) {
     const char *qb = reinterpret_cast<const char *>(p.q), *dbb = reinterpret_cast<const char *>(p.db);
     const int64_t mq0 = (int64_t)mt0 * BM;
     const __amdgpu_buffer_rsrc_t srd_q = make_srd(qb + mq0 * row_bytes, (unsigned long long)(p.nq - mq0) * row_bytes);
-    const int64_t row0 = n0 * p.row_stride;
-    const int64_t rows_left = (p.nrows - n0 - 1) * p.row_stride + 1;
-    const __amdgpu_buffer_rsrc_t srd_db = make_srd(dbb + row0 * row_bytes, (unsigned long long)rows_left * row_bytes);
+    // one window per 32-row sub-tile (see scan_emit_kernel): offsets stay below 2 GB at any level stride
+    __amdgpu_buffer_rsrc_t srd_db[BR];
     unsigned doff[BR];
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
-        const int64_t rl = rowq + 32 * j;
-        const unsigned long long off = (unsigned long long)rl * p.row_stride * row_bytes;
-        doff[j] = (n0 + rl < p.nrows && off < 0x7FFF0000ull) ? (unsigned)off : BUF_OOB;
+        const int64_t nj = n0 + 32 * j;
+        const int64_t left = p.nrows - nj;
+        srd_db[j] = make_srd(dbb + (nj < p.nrows ? nj : 0) * p.row_stride * row_bytes,
+                             left > 0 ? (unsigned long long)((left - 1) * p.row_stride + 1) * row_bytes : 0ull);
+        doff[j] = nj + rowq < p.nrows ? (unsigned)((unsigned long long)rowq * p.row_stride * row_bytes) : BUF_OOB;
     }
     f32x4 ra[AR], rb[BR];
     const int q_rows_left = (int)((p.nq - mq0) < (int64_t)QT * BM ? (p.nq - mq0) : (int64_t)QT * BM);
@@ -135,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void scan_f16_kernel(ScanParams p) {
         for (int i = 0; i < AR; ++i)
             ra[i] = buf_load4(srd_q, (kok && lrow + 32 * i < q_rows_left) ? lbase + aoff[i] + lkb : BUF_OOB);
 #pragma unroll
-        for (int j = 0; j < BR; ++j) rb[j] = buf_load4(srd_db, kok ? doff[j] + lkb : BUF_OOB);
+        for (int j = 0; j < BR; ++j) rb[j] = buf_load4(srd_db[j], (kok && doff[j] != BUF_OOB) ? doff[j] + lkb : BUF_OOB);
         lkb += 128u;
         const bool wrap = lkb >= row_bytes;
         lkb = wrap ? (unsigned)col4 * 16u : lkb;
@@ -449,8 +460,10 @@ __global__ __launch_bounds__(256) void select_rescore_small_kernel(const unsigne
                                                                    float *__restrict__ thr, float *__restrict__ thr_adj,
                                                                    const float *__restrict__ eps, float *__restrict__ D,
                                                                    int64_t *__restrict__ I, int64_t label_base,
-                                                                   int *overflow, const float *__restrict__ q32,
-                                                                   const float *__restrict__ db32, int d, int nsub) {
+                                                                   int *overflow, int *__restrict__ row_ovf,
+                                                                   const float *__restrict__ q32,
+                                                                   const float *__restrict__ db32, int d, int nsub,
+                                                                   int rescore) {
     constexpr int NT = 256, KPT = SMALL_N / NT;
     __shared__ __attribute__((aligned(16))) unsigned long long skeys[SMALL_N];
     __shared__ int s_n2, s_bin, s_kk;
@@ -481,7 +494,7 @@ __global__ __launch_bounds__(256) void select_rescore_small_kernel(const unsigne
         return;
     }
     const bool over = s_off[65] != 0;
-    if (over && mode == 1 && tid == 0) atomicExch(overflow, 1);
+    if (over && mode == 1 && tid == 0) row_ovf[m] = 1;           // topk_fallback_kernel recomputes this row
     if (nsub == 1) {
         for (int i = tid; i < n; i += NT) skeys[i] = keys[m * CAP + i];
     } else {
@@ -492,7 +505,7 @@ __global__ __launch_bounds__(256) void select_rescore_small_kernel(const unsigne
         }
     }
     __syncthreads();
-    const float e2 = 2.0f * eps[m];
+    const float e2 = rescore ? 2.0f * eps[m] : 0.f;
     if (n <= k) {
         if (tid == 0) s_n2 = n;
         __syncthreads();
@@ -545,6 +558,7 @@ __global__ __launch_bounds__(256) void select_rescore_small_kernel(const unsigne
     const int n2 = s_n2;
     // exact fp32 scores: 4 threads per candidate, 64 candidates in flight per pass
     const float *qv = q32 + m * d;
+    if (rescore)
     for (int c0 = 0; c0 < n2; c0 += NT / 4) {
         const int c = c0 + (tid >> 2), sub = tid & 3;
         float part = 0.f;
@@ -588,7 +602,8 @@ __global__ __launch_bounds__(256) void select_rescore_small_kernel(const unsigne
         if (tid == 0) {
             const float t = n2 >= k ? ord2f(~(unsigned)(skeys[k - 1] >> 32)) : -INFINITY;
             thr[m] = t;
-            thr_adj[m] = fmaxf(t - eps[m], -1000.f * eps[m]);   // finite: below every possible score
+            // finite (the scan's accumulators start at -thr_adj): below every possible score
+            thr_adj[m] = fmaxf(rescore ? t - eps[m] : t, -1000.f * eps[m]);
         }
     } else {
         for (int i = tid; i < k; i += NT) {
@@ -600,11 +615,6 @@ __global__ __launch_bounds__(256) void select_rescore_small_kernel(const unsigne
                 D[m * k + i] = -3.4028234663852886e38f;
                 I[m * k + i] = -1;
             }
-        }
-        if (over && tid == 0 && n2 >= k) {          // raised threshold for the rescan
-            const float t = ord2f(~(unsigned)(skeys[k - 1] >> 32));
-            thr[m] = t;
-            thr_adj[m] = fmaxf(t - eps[m], -1000.f * eps[m]);
         }
     }
 }
@@ -619,9 +629,10 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(const unsigned lon
                                                               float *__restrict__ thr, float *__restrict__ thr_adj,
                                                               const float *__restrict__ eps, float *__restrict__ D,
                                                               int64_t *__restrict__ I, int64_t label_base,
-                                                              int *overflow, const float *__restrict__ q32,
+                                                              int *overflow, int *__restrict__ row_ovf,
+                                                              const float *__restrict__ q32,
                                                               const float *__restrict__ db32, int d, int nsub,
-                                                              int skip_small) {
+                                                              int skip_small, int rescore) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
     __shared__ int s_n2;
     __shared__ int s_off[66];
@@ -649,7 +660,7 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(const unsigned lon
     const int n = s_off[nsub];
     if (skip_small && n <= SMALL_N) return;          // done by select_rescore_small_kernel
     const bool over = s_off[65] != 0;
-    if (over && mode == 1 && tid == 0) atomicExch(overflow, 1);
+    if (over && mode == 1 && tid == 0) row_ovf[m] = 1;           // topk_fallback_kernel recomputes this row
     int P = 1;
     while (P < n) P <<= 1;
     if (nsub == 1) {
@@ -663,7 +674,7 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(const unsigned lon
     }
     __syncthreads();
     // candidates that can still belong to the exact top-k: s16 >= (k-th best s16) - 2 eps
-    const float e2 = 2.0f * eps[m];
+    const float e2 = rescore ? 2.0f * eps[m] : 0.f;
     unsigned long long *ck = skeys;               // the candidates end up in ck[0 .. n2)
     if (n <= k) {
         if (tid == 0) s_n2 = n;
@@ -732,6 +743,7 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(const unsigned lon
     // exact fp32 scores, all candidates of a pass in flight together: 8 threads per candidate, each a
     // strided set of float4 chunks (a row is read as whole 128-byte lines), fixed reduction order
     const float *qv = q32 + m * d;
+    if (rescore)
     for (int c0 = 0; c0 < n2; c0 += 128) {
         const int c = c0 + (tid >> 3), sub = tid & 7;
         float part = 0.f;
@@ -775,7 +787,7 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(const unsigned lon
         if (tid == 0) {
             const float t = n2 >= k ? ord2f(~(unsigned)(ck[k - 1] >> 32)) : -INFINITY;
             thr[m] = t;
-            thr_adj[m] = fmaxf(t - eps[m], -1000.f * eps[m]);   // finite: below every possible score
+            thr_adj[m] = fmaxf(rescore ? t - eps[m] : t, -1000.f * eps[m]);
         }
     } else {
         for (int i = tid; i < k; i += 1024) {
@@ -788,30 +800,20 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(const unsigned lon
                 I[m * k + i] = -1;
             }
         }
-        if (over && tid == 0 && n2 >= k) {          // raised threshold for the rescan
-            const float t = ord2f(~(unsigned)(ck[k - 1] >> 32));
-            thr[m] = t;
-            thr_adj[m] = fmaxf(t - eps[m], -1000.f * eps[m]);
-        }
     }
 }
 
 int launch_select_rescore(SearchWorkspace &ws, int64_t nq, int k, int mode, float *D, int64_t *I, int64_t label_base,
-                          const float *q32, const float *db32, int d, int nsub, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        PF_HIP(hipFuncSetAttribute((const void *)select_rescore_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   CAP * 8));
-        attr_set = true;
-    }
-    ProfScope ps("topk_select_rescore", s);
+                          const float *q32, const float *db32, int d, int nsub, int rescore, hipStream_t s) {
+    if (ensure_dyn_lds((const void *)select_rescore_kernel, CAP * 8)) return -1;
+    ProfScope ps(rescore ? "topk_select_rescore" : "topk_select_radix", s);
     PF_HIP(hipMemsetAsync(ws.overflow + 1, 0, sizeof(int), s));
     PF_LAUNCH(select_rescore_small_kernel, dim3((unsigned)nq), dim3(256), 0, s,
               reinterpret_cast<const unsigned long long *>(ws.cl), ws.cnt, k, mode, ws.thr, ws.thr_adj, ws.eps, D,
-              I, label_base, ws.overflow, q32, db32, d, nsub);
+              I, label_base, ws.overflow, ws.row_ovf, q32, db32, d, nsub, rescore);
     PF_LAUNCH(select_rescore_kernel, dim3((unsigned)nq), dim3(1024), CAP * 8, s,
                        reinterpret_cast<const unsigned long long *>(ws.cl), ws.cnt, k, mode, ws.thr, ws.thr_adj, ws.eps, D,
-                       I, label_base, ws.overflow, q32, db32, d, nsub, 1);
+                       I, label_base, ws.overflow, ws.row_ovf, q32, db32, d, nsub, 1, rescore);
     PF_HIP(hipGetLastError());
     return 0;
 }

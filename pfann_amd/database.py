@@ -10,6 +10,8 @@ contract, python-path semantics (cpp_accelerate=False, database.py:12).
 import ctypes
 import json
 import os
+import struct
+import time
 
 import numpy as np
 import torch
@@ -26,7 +28,10 @@ def song_pos_from_key(landmark_key):
 class DeviceIndex:
     """One shard of fingerprints on one GPU + its search / match kernels."""
 
-    def __init__(self, d, device=0):
+    def __init__(self, d, device=0, storage="f32"):
+        """storage "f32" (default; exact fp32 results) or "f16": only fp16 rows are kept and searched on the fp16
+        matrix cores without fp32 re-scoring (half the footprint and scan bytes; approximate like faiss'
+        useFloat16, database.py:101-104)."""
         _l.require_gpu()
         self.lib = _l.load()
         self.d = d
@@ -34,6 +39,8 @@ class DeviceIndex:
         self.handle = self.lib.pfann_db_create(d, device)
         if not self.handle:
             raise _l.PfannError("pfann_db_create failed: " + _l.last_error())
+        self.storage = storage
+        _l.check(self.lib.pfann_db_set_storage(self.handle, {"f32": 0, "f16": 1}[storage]), "pfann_db_set_storage")
         self.ntotal = 0
         self.label_base = 0
         self.n_songs = 0
@@ -125,13 +132,14 @@ def _fine_to_time(fine, fsm, hop_size):
 
 
 class Database:
-    def __init__(self, dir_for_db, indexer_params, hop_size, device=0, d=None):
+    def __init__(self, dir_for_db, indexer_params, hop_size, device=0, d=None, storage=None):
         self.dir_for_db = dir_for_db
         self.params = indexer_params
         self.top_k = self.params["top_k"]
         self.frame_shift_mul = self.params.get("frame_shift_mul", 1)
         self.hop_size = hop_size
         self.score_alpha = self.params.get("score_alpha", 0)
+        self.timer = None          # a utils.StageTimer: query_batch then reports 'search' and 'rerank' separately
 
         self.songList = read_file_list(os.path.join(dir_for_db, "songList.txt"))
         key = np.fromfile(os.path.join(dir_for_db, "landmarkKey"), dtype=np.int32)
@@ -143,8 +151,8 @@ class Database:
         if os.path.exists(lv):
             try:
                 emb, _ = faissio.read_index_flat(lv)
-            except ValueError as x:
-                print(x)
+            except (ValueError, struct.error, OSError, IndexError) as x:   # not a flat index / truncated file
+                print("landmarkValue unusable (%s): falling back to the raw embeddings file" % x)
         if emb is None:                                         # database.py:96-97 fallback
             if d is None:
                 cfg = os.path.join(dir_for_db, "configs.json")
@@ -152,15 +160,26 @@ class Database:
             emb = np.fromfile(os.path.join(dir_for_db, "embeddings"), dtype=np.float32).reshape(-1, d)
         self.d = emb.shape[1] if emb.ndim == 2 and emb.shape[0] else (d or emb.shape[-1])
         assert emb.shape[0] == self.song_pos[-1], "embeddings rows != sum(landmarkKey)"
-        self.index = DeviceIndex(self.d, device)
+        # "use_float16" in the indexer params (or PFANN_DB_STORAGE=f16) selects fp16-only storage: the knob the
+        # reference hard-codes as co.useFloat16 = True for its GPU index (database.py:101-104)
+        if storage is None:
+            storage = os.environ.get("PFANN_DB_STORAGE") or ("f16" if self.params.get("use_float16", False) else "f32")
+        self.index = DeviceIndex(self.d, device, storage)
         self.index.load(emb, self.song_pos, 0)
 
     # ---- batched form ------------------------------------------------------------------
     def query_batch(self, emb, qstart, qlen, want_song_scores=False, mode=0):
         """emb: torch cuda [sum(qlen), d] unit-norm rows; -> list of (score, (song, time), song_score|None)."""
+        tm_1 = time.time()
         D, I = self.index.search(emb, self.top_k)
+        if self.timer is not None:
+            torch.cuda.synchronize(self.index.device)     # stage split as database.py:165 logs it
+        tm_2 = time.time()
         res, ss = self.index.match(emb, I, qstart, qlen, self.frame_shift_mul, self.score_alpha, mode,
                                    False, want_song_scores)
+        if self.timer is not None:                        # match() ends with the D2H of the results
+            self.timer.add("search", tm_2 - tm_1)
+            self.timer.add("rerank", time.time() - tm_2)
         ss_np = ss.cpu().numpy() if ss is not None else None
         out = []
         fsm = self.frame_shift_mul

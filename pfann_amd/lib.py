@@ -51,6 +51,7 @@ SYMBOLS = {
     "pfann_db_create": (c_void_p, [c_int, c_int]),
     "pfann_db_destroy": (None, [c_void_p]),
     "pfann_db_set_prefilter": (c_int, [c_void_p, c_int]),
+    "pfann_db_set_storage": (c_int, [c_void_p, c_int]),
     "pfann_db_dim": (c_int, [c_void_p]),
     "pfann_db_ntotal": (c_int64, [c_void_p]),
     "pfann_db_bytes": (c_int64, [c_void_p]),

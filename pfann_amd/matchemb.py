@@ -1,8 +1,13 @@
 """Matcher over pre-extracted embeddings, drop-in for the reference's matchemb.py:
     python matchemb.py <query embedding dir> <database dir> <result file>
 Reads `query_embeddings` / `query_index` / `queryList.txt` (matchemb.py:33,47-51), searches and
-sequence-matches on the MI355X in batches, writes the matcher's three outputs.  A query with
-zero rows (load error at extraction) gets the matcher's `error` row."""
+sequence-matches on the MI355X in batches, writes the matcher's three outputs.
+
+Zero-row queries (query_index row (pos, 0): the file failed to load at extraction, extractemb.py:70-73):
+the reference hands the empty array to Database.query_embeddings (matchemb.py:60-66), where
+np.concatenate([]) at database.py:140 raises ValueError and the run aborts -- it has no defined output for
+them.  This tool instead writes the row matcher.py itself writes for the same unreadable file
+(matcher.py:94-107: answer "error", score -inf, time 0, a zero score block) and carries on."""
 import os
 import sys
 import time

@@ -19,7 +19,7 @@ from .builder import embed_files
 from .database import Database
 from .engine import Engine
 from .musicdata import MusicDataset
-from .utils import StageTimer, read_config
+from .utils import StageTimer, get_logger, init_logger, read_config
 
 
 class ResultWriter:
@@ -58,6 +58,7 @@ def main(argv=None):
         return 1
     file_list_for_query, dir_for_db, result_file = argv[1], argv[2], argv[3]
     params = read_config(os.path.join(dir_for_db, "configs.json"))
+    init_logger("matcher")                                                 # matcher.py:31-32
 
     print("loading model...")
     engine = Engine(params, 0, max_batch=int(os.environ.get("PFANN_MAX_BATCH", "1024")))
@@ -69,6 +70,7 @@ def main(argv=None):
 
     dataset = MusicDataset(file_list_for_query, params)
     timer = StageTimer()
+    db.timer = timer
     tm_0 = time.time()
     group = int(os.environ.get("PFANN_QUERY_GROUP", "64"))
     out = ResultWriter(result_file, len(db.songList))
@@ -78,11 +80,10 @@ def main(argv=None):
         good = [(i, n, e) for i, n, e in items if n]
         results = {}
         if good:
-            with timer.stage("search+rerank"):
-                emb = torch.cat([e for _, _, e in good])
-                qlen = [n for _, n, _ in good]
-                qstart = np.concatenate([[0], np.cumsum(qlen)[:-1]])
-                res = db.query_batch(emb, qstart, qlen, want_song_scores=True)
+            emb = torch.cat([e for _, _, e in good])
+            qlen = [n for _, n, _ in good]
+            qstart = np.concatenate([[0], np.cumsum(qlen)[:-1]])
+            res = db.query_batch(emb, qstart, qlen, want_song_scores=True)    # times "search" and "rerank"
             for (i, _, _), r in zip(good, res):
                 results[i] = r
         with timer.stage("output answer"):
@@ -105,7 +106,9 @@ def main(argv=None):
             buf = []
     emit(buf)
     out.close()
-    print("stages:", {k: round(v, 3) for k, v in timer.t.items()})
+    for name, secs in timer.t.items():                   # one stage per line, the format tools/stat.py:17 parses
+        print("%s %.6fs" % (name, secs))
+    get_logger().info("total query time %.6fs", time.time() - tm_0)
     print("total query time %.6fs" % (time.time() - tm_0))
     return 0
 

@@ -28,16 +28,32 @@ def get_logger():
     return _logger
 
 
+def init_logger(app_name):
+    """logs/<app>-<date>.log with the reference's record format (simpleutils.py:72-85), so the reference's
+    tools/stat.py:17 can aggregate the stage lines this package logs ('<stage> <seconds>s')."""
+    import datetime
+    import os
+    os.makedirs("logs", exist_ok=True)
+    name = app_name + "-" + datetime.datetime.now().strftime("%Y%m%d-%H%M%S")
+    _logger.setLevel(logging.INFO)
+    handler = logging.FileHandler("logs/%s.log" % name, encoding="utf8")
+    handler.setFormatter(logging.Formatter("[%(asctime)s] [%(processName)s/%(levelname)s] %(message)s"))
+    _logger.addHandler(handler)
+    return "logs/%s.log" % name
+
+
 class StageTimer:
-    """Accumulates wall time per stage under the reference's stage names
-    (tools/stat.py:17: load, resample, stereo to mono, compute embedding, search, rerank,
-    output answer, total query time)."""
+    """Wall time per stage under the reference's stage names (tools/stat.py:17: load, resample, stereo to mono,
+    compute embedding, search, rerank, output answer, total query time).  Every measurement is also logged as
+    its own '<stage> %.6fs' record (the reference logs them per file, musicdata.py:70,91, builder.py:103,
+    matcher.py:131,165, database.py:165; here a record covers one batch of files), one stage per line."""
 
     def __init__(self):
         self.t = {}
 
     def add(self, name, dt):
         self.t[name] = self.t.get(name, 0.0) + dt
+        _logger.info("%s %.6fs", name, dt)
 
     class _Ctx:
         def __init__(self, owner, name):

@@ -119,11 +119,34 @@ def elu_full_params():
     return p
 
 
+def strides_pow2_params():
+    """Per-block strides (model.py:83-85) as tools/convert_naf_to_pfann.py:82-110 writes them for a converted
+    model: ELU, activation before LN, full conv2; a stride-1 conv1 in block 1 (pad (1,1) with T > 1) and
+    early size-1 axes.  Every Fo*To stays a power of two, so the LayerNorm-fused GEMM path applies."""
+    p = json.load(open(os.path.join(REPO, "configs/tiny.json")))
+    st = [2, 1, 2, 2, 2, 2, 1, 1]
+    p["model"].update(conv_activation="ELU", relu_after_bn=False, fuller=True,
+                      strides=[[[1, st[i]], [2, 1]] for i in range(8)])
+    return p
+
+
+def strides_np2_params():
+    """Stride 3 along F in block 0 (256 -> 86 -> 43 -> ...): Fo*To is NOT a power of two, which the fused
+    path does not support -- the library must fall back to the separate-LayerNorm kernels and say so."""
+    p = json.load(open(os.path.join(REPO, "configs/tiny.json")))
+    sf = [3, 2, 2, 2, 2, 2, 2, 2]
+    st = [2, 2, 2, 2, 2, 1, 1, 1]
+    p["model"].update(fuller=True, strides=[[[1, st[i]], [sf[i], 1]] for i in range(8)])
+    return p
+
+
 def gen_encoder():
     from model import FpNetwork
     cases = {k: json.load(open(os.path.join(REPO, v))) for k, v in ENCODER_CASES.items()}
     cases["nafstyle"] = naf_style_params()
     cases["elu_full"] = elu_full_params()
+    cases["strides_pow2"] = strides_pow2_params()
+    cases["strides_np2"] = strides_np2_params()
     for name, params in cases.items():
         d, h, u, F, T = synth.model_dims(params)
         net = FpNetwork(d, h, u, F, T, params["model"])
@@ -264,8 +287,72 @@ def gen_database():
     np.savez_compressed(os.path.join(OUT, "database.npz"), **out)
 
 
+# ----------------------------------------------------------------------- evaluator
+def accuracy_cases():
+    """Two seeded (expected.csv, *_detail.csv) pairs in the formats genquery.py:139-160 and matcher.py:84,158-163
+    write, with every branch of tools/accuracy.py:24-45: wrong song, right song off by 0.2 / 0.25 / 0.3 / 0.5 /
+    0.75 s, negative times, 'error' rows, paths whose basenames carry the match (accuracy.py:14,28-31)."""
+    cases = {}
+    for ci, (n, seed) in enumerate([(40, 31), (257, 32)]):
+        u = synth.uniform01(seed, "golden/acc", 4 * n).reshape(4, n)
+        gt, pr = [["query", "answer", "time", "snr"]], [["query", "answer", "score", "time", "part_scores"]]
+        for j in range(n):
+            song = int(u[0, j] * 23)
+            tm = round(float(u[1, j]) * 20.0, 3)
+            q = "/data/q%d/query%04d.wav" % (ci, j)
+            gt.append([q, "/music/a/song%03d.wav" % song, repr(tm), "0"])
+            kind = int(u[2, j] * 9)
+            ans = "/other/prefix/song%03d.wav" % (song if kind != 0 else (song + 1) % 23)
+            dt = [0.0, 0.0, 0.2, -0.25, 0.3, -0.5, 0.75, 0.0, -0.1][kind]
+            if kind == 7:
+                pr.append([os.path.basename(q), "error", "-inf", "0"])
+            else:
+                pr.append(["rel/" + os.path.basename(q), ans, repr(float(u[3, j])), repr(tm + dt)])
+        cases["acc%d" % ci] = (gt, pr)
+    return cases
+
+
+def _csv_text(rows):
+    import csv
+    import io
+    buf = io.StringIO()
+    csv.writer(buf).writerows(rows)
+    return buf.getvalue()
+
+
+def gen_accuracy():
+    """Runs the reference's tools/accuracy.py (a script: argparse at import) on the seeded pairs and stores its
+    three printed lines.  Only the csv INPUTS (regenerated from seeds in the test) and the printed OUTPUT are data
+    of this repo; the script itself is executed from /root/reference."""
+    import contextlib
+    import io
+    import runpy
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        for name, (gt, pr) in accuracy_cases().items():
+            g, p = os.path.join(td, name + "_expected.csv"), os.path.join(td, name + "_detail.csv")
+            open(g, "w", newline="").write(_csv_text(gt))
+            open(p, "w", newline="").write(_csv_text(pr))
+            argv, sys.argv = sys.argv, ["accuracy.py", g, p]
+            buf = io.StringIO()
+            try:
+                with contextlib.redirect_stdout(buf):
+                    runpy.run_path(os.path.join(REF, "tools", "accuracy.py"), run_name="__main__")
+            finally:
+                sys.argv = argv
+            out[name] = buf.getvalue()
+            print("accuracy", name, repr(buf.getvalue()))
+    json.dump(out, open(os.path.join(OUT, "accuracy.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     os.makedirs("logs", exist_ok=True)
-    gen_encoder()
-    gen_segmenter()
-    gen_database()
+    which = sys.argv[1:] or ["encoder", "segmenter", "database", "accuracy"]
+    if "encoder" in which:
+        gen_encoder()
+    if "segmenter" in which:
+        gen_segmenter()
+    if "database" in which:
+        gen_database()
+    if "accuracy" in which:
+        gen_accuracy()

@@ -17,6 +17,15 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def oracle_embed(path, params, sd):
+    """The oracle pipeline for one file: segmenter -> mel -> encoder (unit-norm rows)."""
+    from oracle import encoder as oe
+    from oracle import melspec as om
+    from oracle import segmenter as osg
+    segs = osg.load_segments(path, params)
+    return oe.encode(om.melspec(segs, params), sd, params)
+
+
 @pytest.mark.parametrize("cfgname", ["tiny", "default"])
 def test_builder_and_matcher_cli_vs_oracle(tmp_path, cfgname):
     import torch
@@ -164,6 +173,28 @@ def test_extractemb_matchemb_seam_and_accuracy(tmp_path):
         assert d1 == d2
         qi = np.fromfile(os.path.join(str(tmp_path / ("emb" + snr)), "query_index"), dtype=np.int64).reshape(-1, 2)
         assert qi.shape[0] == (13 if snr == "20" else 12) and (qi[:12, 1] == 9).all()
+        # the seam's files against the ORACLE (not against the product itself): query_index is the running
+        # (start, count) table of extractemb.py:66-84, query_embeddings the oracle pipeline's unit-norm rows
+        assert np.array_equal(qi[:12, 0], np.arange(12) * 9)
+        qe = np.fromfile(os.path.join(str(tmp_path / ("emb" + snr)), "query_embeddings"), dtype=np.float32).reshape(-1, 16)
+        assert qe.shape[0] == 12 * 9
+        qfiles = [ln.strip() for ln in open(os.path.join(qd, "list.txt"))][:12]
+        ref = np.concatenate([oracle_embed(f, params, sd) for f in qfiles])
+        assert np.abs(qe - ref).max() < 1e-4, np.abs(qe - ref).max()
+        assert np.abs(np.linalg.norm(qe, axis=1) - 1).max() < 1e-5
+        # ... and matchemb's decisions against the oracle's search + sequence matcher on those oracle rows
+        from oracle import search as osr
+        from oracle import seqscore as osq
+        dbe = np.fromfile(os.path.join(db, "embeddings"), dtype=np.float32).reshape(-1, 16)
+        pos = osq.song_pos_from_key(np.fromfile(os.path.join(db, "landmarkKey"), dtype=np.int32))
+        det = list(csv.reader(open(os.path.splitext(r2)[0] + "_detail.csv", newline="")))[1:]
+        music = [ln.strip() for ln in open(os.path.join(data, "music.txt"))]
+        for j in range(12):
+            qj = qe[j * 9:(j + 1) * 9]
+            _, I = osr.flat_ip_topk(qj, dbe, params["indexer"]["top_k"])
+            sc, (song, sec), _ = osq.query_embeddings_base(qj, I, dbe, pos, params["hop_size"], 1)
+            assert det[j][1] == music[song] and float(det[j][3]) == sec, j
+            assert abs(float(det[j][2]) - sc) < 2e-5, j
         if snr == "20":
             assert qi[12, 1] == 0                                   # unreadable file: (pos, 0)
             lines = [ln for ln in open(os.path.splitext(r1)[0] + "_detail.csv", newline="")]

@@ -132,7 +132,7 @@ def test_pcm16_to_mono_and_segment_embed(torch_cuda):
 
 # ------------------------------------------------------------------------------- encoder
 @pytest.mark.parametrize("fused", [True, False])
-@pytest.mark.parametrize("name", ["tiny", "nafstyle", "n640d64", "seg", "default", "elu_full"])
+@pytest.mark.parametrize("name", ["tiny", "nafstyle", "n640d64", "seg", "default", "elu_full", "strides_pow2", "strides_np2"])
 def test_encoder_vs_reference_golden(torch_cuda, name, fused):
     """a3-a5: embeddings within 1e-4 of the reference's own outputs (golden), and every one
     of the 16 sub-layer activations against the oracle -- for both encoder paths
@@ -146,7 +146,10 @@ def test_encoder_vs_reference_golden(torch_cuda, name, fused):
     eng = Engine(params, 0, max_batch=8)
     eng.load_state_dict(sd)
     if eng.set_fused_layernorm(fused) != fused:
-        pytest.skip("fused LayerNorm path needs full conv2 layers (fuller=true)")
+        # depthwise conv2 (fuller=false) or a non-power-of-two Fo*To (strides_np2): the library keeps the
+        # separate-LayerNorm kernels and reports it through the return value (and a one-line notice)
+        assert name in ("nafstyle", "n640d64", "seg", "strides_np2"), "fused path unexpectedly refused for " + name
+        pytest.skip("fused LayerNorm path not available for this model (reported by pfann_set_fused_layernorm)")
     eng.debug_keep(True)
     x = mg.encoder_inputs(F, T)
     xt = torch_cuda.as_tensor(x).cuda()
@@ -309,7 +312,7 @@ def test_search_topk_large_batch_sublists(torch_cuda, n, d, nq, k):
 
 def test_search_topk_sublist_overflow_falls_back(torch_cuda):
     """More near-identical rows inside ONE interleaved db slice than a sub-list holds (256 at 32
-    slices): the final pass must notice the overflow and redo the scan with one list per row."""
+    slices): the rows that lost survivors are recomputed exactly by the device-side fallback kernel."""
     d, n, nq = 128, 60000, 1100
     db = synth.unit_rows(43, "t/of", n, d)
     c = synth.unit_rows(44, "t/ofc", 1, d)
@@ -374,6 +377,122 @@ def test_search_prefilter_near_ties_stay_exact(torch_cuda):
     s = np.sort((q[:1].astype(np.float32) @ base.astype(np.float32).T)[0])[::-1]
     assert s[99] - s[149] < 1e-3
 
+
+
+# ------------------------------------------------------------ round-2 search additions
+def test_search_small_batch_sublist_overflow_device_fallback(torch_cuda):
+    """Small-batch path (nq <= 32): 900 near-identical rows exactly 32 tiles apart land in one or two of a query
+    row's 32 sub-lists (256 slots each), and 9000 rows tying EXACTLY at the top overflow every list of their query
+    row.  Both rows are recomputed exactly by the device-side fallback kernel (no host retry, no error); exact ties
+    resolve to ascending row ids like the oracle's stable sort."""
+    d, n = 64, 1000000
+    rng = np.random.default_rng(61)
+    db = rng.standard_normal((n, d)).astype(np.float32)
+    c = rng.standard_normal((2, d)).astype(np.float32)
+    db[50000:59000] = c[0]                                   # 9000 identical rows: all tie at score 1
+    for u in range(900):                                     # rows 32 tiles apart -> same sub-list (tile & 31)
+        lo = 70001 + u * 32 * 32
+        db[lo] = c[1] + 0.01 * db[lo]
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    q = np.concatenate([c, rng.standard_normal((17, d)).astype(np.float32)])
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    D, I = _check_topk(torch_cuda, db, q.astype(np.float32), 300)
+    assert np.array_equal(I[0, :300], np.arange(50000, 50300))          # exact ties -> lowest rows first
+    # the same handle semantics again: the per-row flags were cleared by the fallback kernel
+    _check_topk(torch_cuda, db, q[2:].astype(np.float32), 100)
+
+
+def test_search_all_scores_tie_zero_query(torch_cuda):
+    """q = 0: every row scores 0, the survivor lists overflow at any threshold; exact answer = rows 0..k-1."""
+    d, n = 128, 30000
+    db = synth.unit_rows(64, "t/zq", n, d).astype(np.float32)
+    for nq in (3, 100):
+        q = np.zeros((nq, d), np.float32)
+        q[-1] = db[77]
+        D, I = _check_topk(torch_cuda, db, q, 50)
+        assert np.array_equal(I[0], np.arange(50)) and I[-1, 0] == 77
+
+
+def test_search_prefilter_margin_scales_with_norms(torch_cuda):
+    """The fp16 pre-filter's margin must hold for non-unit rows too: db rows of norm ~40 and queries of norm
+    ~25 with thousands of exact scores 1e-3 relative apart around the k-th best; and a query row far outside
+    fp16's range (norm 3e5) is answered exactly through the fallback instead of through inf/NaN halves."""
+    d, n, nq = 128, 60000, 96
+    base = synth.unit_rows(71, "t/ms", n, d).astype(np.float64)
+    c = synth.unit_rows(72, "t/msc", 1, d).astype(np.float64)[0]
+    base[1000:4000] = c + 0.02 * base[1000:4000]
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    base *= (20.0 + 40.0 * synth.uniform01(73, "t/msn", n).astype(np.float64))[:, None]
+    q = synth.unit_rows(74, "t/msq", nq, d).astype(np.float64)
+    q[:40] = c + 0.05 * q[:40]
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q *= 25.0
+    q[50] *= 12000.0
+    from oracle import search as osr
+    from pfann_amd.database import DeviceIndex
+    db32, q32 = base.astype(np.float32), q.astype(np.float32)
+    idx = DeviceIndex(d, 0)
+    idx.load(db32, np.array([0, n], np.int64), 0)
+    assert idx.set_prefilter(True)
+    D, I = idx.search(torch_cuda.as_tensor(q32).cuda(), 100)
+    D, I = D.cpu().numpy(), I.cpu().numpy()
+    s = q.astype(np.float64) @ base.T
+    for r in range(nq):
+        kth = np.sort(s[r])[::-1][99]
+        tol = 4e-7 * np.linalg.norm(q[r]) * 60.0               # fp32 rounding of scores of this magnitude
+        got = s[r, I[r]]
+        assert (got >= kth - tol).all(), "row %d returned a row below the k-th best" % r
+        assert np.abs(D[r] - got).max() < 4 * tol
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(7, 128, 19, 100), (5000, 128, 19, 100), (100000, 128, 19, 100),
+                                      (90000, 64, 1, 20), (150000, 128, 130, 100), (70001, 64, 1100, 100),
+                                      (40000, 128, 40, 300)])
+def test_search_fp16_storage(torch_cuda, n, d, nq, k):
+    """fp16-only storage (pfann_db_set_storage(db, PFANN_DB_F16)): the result is the top-k by
+    s16 = sum fl16(q_i) fl16(x_i) -- against the oracle's float64 evaluation of exactly that (scores to fp32
+    summation rounding; label sets identical except ties at the k-th score) on every regime (small-batch
+    streaming kernel, generic and query-stationary batched kernels)."""
+    from oracle import search as osr
+    from pfann_amd.database import DeviceIndex
+    db = synth.unit_rows(81, "t/h%d" % n, n, d).astype(np.float32)
+    q = synth.unit_rows(82, "t/hq%d" % n, nq, d)
+    q[::3] = db[(np.arange(len(q[::3])) * 7919) % n] * 0.8 + 0.2 * q[::3]
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    idx = DeviceIndex(d, 0, storage="f16")
+    idx.load(db, np.array([0, n], np.int64), 0)
+    assert idx.lib.pfann_db_bytes(idx.handle) == n * d * 2
+    D, I = idx.search(torch_cuda.as_tensor(q).cuda(), k)
+    D, I = D.cpu().numpy(), I.cpu().numpy()
+    Dr, Ir = osr.flat_ip_topk_f16(q, db, k)
+    kk = min(k, n)
+    assert (I[:, kk:] == -1).all() and (I[:, :kk] >= 0).all()
+    assert (np.diff(D[:, :kk], axis=1) <= 0).all()
+    assert np.abs(D[:, :kk] - Dr[:, :kk]).max() < 2e-6
+    x16 = db.astype(np.float16).astype(np.float64)
+    q16 = q.astype(np.float16).astype(np.float64)
+    for r in range(nq):
+        a, b = set(I[r, :kk].tolist()), set(Ir[r, :kk].tolist())
+        for lab in a ^ b:
+            assert abs(float(x16[lab] @ q16[r]) - Dr[r, kk - 1]) < 2e-6, "row %d label %d not a k-th tie" % (r, lab)
+
+
+def test_match_on_fp16_storage_uses_stored_rows(torch_cuda):
+    """Sequence matcher over fp16-only storage: scores are dot products with the STORED (fp16-rounded) rows."""
+    from oracle import seqscore as osq
+    from pfann_amd.database import DeviceIndex
+    z = np.load(os.path.join(G, "database.npz"))
+    name = "random_noisy"
+    db, q, labels = z[name + "_db"], z[name + "_q"], z[name + "_labels"]
+    pos = osq.song_pos_from_key(z[name + "_key"])
+    idx = DeviceIndex(db.shape[1], 0, storage="f16")
+    idx.load(db, pos, 0)
+    res, ss = idx.match(torch_cuda.as_tensor(q).cuda(), torch_cuda.as_tensor(labels).cuda(), [0], [q.shape[0]],
+                        want_song_scores=True)
+    db16 = db.astype(np.float16).astype(np.float32)
+    score, (song, sec), ss_ref = osq.query_embeddings_base(q, labels, db16, pos, 0.5, 1)
+    assert int(res[0]["song"]) == song and int(res[0]["offset"]) * 0.5 == sec
+    assert abs(float(res[0]["score"]) - score) < 1e-6
 
 
 def test_topk_merge(torch_cuda):

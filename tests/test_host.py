@@ -210,3 +210,20 @@ def test_accuracy_tool(tmp_path):
                   "/x/q2.wav,/y/s2.wav,0.8,5.5\r\n/x/q3.wav,/y/s9.wav,0.7,0.0\r\n/x/q4.wav,/y/s4.wav,0.6,8.0\r\n")
     r = accuracy.evaluate(str(gt), str(pr))
     assert r == dict(total=4, song=3, near=2, exact=1)
+
+
+@pytest.mark.parametrize("case", ["acc0", "acc1"])
+def test_accuracy_tool_prints_what_the_reference_prints(tmp_path, case):
+    """f2 pinned: tests/golden/accuracy.json holds the stdout of the REFERENCE's tools/accuracy.py (run by
+    make_golden.py:gen_accuracy) on seeded csv pairs covering wrong songs, 0.2/0.25/0.3/0.5/0.75 s offsets,
+    'error' rows and differing path prefixes; tools/accuracy.py must print the same three lines."""
+    import make_golden as mg
+    want = json.load(open(os.path.join(REPO, "tests", "golden", "accuracy.json")))[case]
+    gt, pr = mg.accuracy_cases()[case]
+    g, p = tmp_path / "expected.csv", tmp_path / "x_detail.csv"
+    g.write_text(mg._csv_text(gt), newline="")
+    p.write_text(mg._csv_text(pr), newline="")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "accuracy.py"), str(g), str(p)],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == want

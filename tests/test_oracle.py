@@ -13,7 +13,7 @@ from pfann_amd import synth
 G = os.path.join(os.path.dirname(__file__), "golden")
 
 
-@pytest.mark.parametrize("name", ["default", "seg", "n640d64", "tiny", "nafstyle", "elu_full"])
+@pytest.mark.parametrize("name", ["default", "seg", "n640d64", "tiny", "nafstyle", "elu_full", "strides_pow2", "strides_np2"])
 def test_encoder_matches_reference(name):
     z = np.load(os.path.join(G, "encoder_%s.npz" % name))
     params = json.loads(str(z["params"]))
