@@ -198,11 +198,13 @@ __global__ __launch_bounds__(256, 2) void scan_emit_kernel(ScanParams p) {
 // Small-batch scan (nq <= 32, d = 128 or 64): the HBM-bound regime (one 10 s query = 19 rows;
 // intensity Q/2 flop/byte).  Streaming design:
 //   * the query block lives in registers as MFMA A-fragments for the whole kernel;
-//   * every wave owns a CONTIGUOUS, row-granular range of the (sampled) rows -- all waves stream the same
-//     number of bytes to within one row, so there is no tail of waves with one more tile than the others --
-//     and reads it in 32-row tiles with fully contiguous 1 KB-per-instruction buffer loads (each byte once);
-//     the buffer window is rebased per tile (scalar 64-bit math), so shards beyond 2 GB keep this path, and
-//     rows past the range read as zeros through the window's own range check (no per-lane predicates);
+//   * a persistent grid (2 workgroups per CU) walks the 32-row tiles round-robin -- at any moment the chip reads
+//     one moving window of a few tens of MB (2048 far-apart streams measured 20 % slower: TLB reach) -- for as
+//     many WHOLE rounds as there are; the rows left over (less than one round) are split row-granularly over
+//     all waves, so no wave runs a whole extra tile while the others idle (5 % of a 1 M-row pass);
+//   * tiles are read with fully contiguous 1 KB-per-instruction buffer loads (each byte once); the buffer window
+//     is rebased per tile (scalar 64-bit math), so shards beyond 2 GB keep this path, and rows past the end of
+//     a piece read as zeros through the window's own range check (no per-lane predicates);
 //   * the tile is transposed to the MFMA B-fragment layout through a WAVE-PRIVATE padded LDS tile
 //     (pitch RB/4+4 dwords: conflict-free ds_write_b128 / ds_read_b128), so there are no workgroup
 //     barriers at all; the next tile is already in flight in registers while the current one is
@@ -211,8 +213,11 @@ __global__ __launch_bounds__(256, 2) void scan_emit_kernel(ScanParams p) {
 //          k = 8*(s>>2) + 4*h + (s&3), same map for both operands);
 // ELT = 2: fp16 rows and fp16 query rows, v_mfma_f32_32x32x16_f16 with fp32 accumulation (fp16-only storage).
 // Both read 16-byte pieces j*32 + 16*h of a row, so the staging code is shared.
-// MODE 0: emit rows with score >= thr[m] into the row's 32 sub-lists (sub-list = tile index & 31, so a run
-//         of near-duplicate rows is spread over the lists and the same-address atomics over 32 counters);
+// MODE 0: emit rows with score >= thr[m] into the row's 32 sub-lists.  Survivors (about one per tile) are first
+//         collected in a per-workgroup LDS list (wave ballot + one LDS atomic per hit group): a returning GLOBAL
+//         atomic per survivor stalled the wave for an L2 round trip per tile and cost 12 us of a 109 us pass
+//         (measured by ablation).  When the workgroup has streamed its share it reserves space in the global
+//         sub-lists with one atomic per query row and copies its entries out;
 // MODE 1: no output but the MAXIMUM score of the wave's range per query row, gmax[m][wave]: the k-th best of
 //         these G = 4*gridDim.x group maxima is the score of a real row, hence a lower bound of the k-th best
 //         overall, and a sharp one (top rows rarely share a group) -- one sampled pass + a 2048-value select
@@ -228,25 +233,27 @@ __global__ __launch_bounds__(256, 2) void scan_small_kernel(ScanParams p) {
     constexpr int NI = 32 / RPI;              // load instructions per 32-row tile
     constexpr int CPR = RB / 16;              // 16-byte chunks per row
     typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    constexpr int NSUB = 32, LCAP = 1024;     // sub-lists per query row; slots of the workgroup's LDS survivor list
     __shared__ __attribute__((aligned(16))) float tile_s[4 * 32 * LD];
     __shared__ __attribute__((aligned(16))) float thr_s[32];
+    __shared__ unsigned long long l_key[MODE == 0 ? LCAP : 1];
+    __shared__ unsigned short l_m[MODE == 0 ? LCAP : 2];
+    __shared__ int l_n, l_hist[32], l_base[32];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lhalf = lane >> 5;
     const int W = (int)gridDim.x * 4, gw = (int)blockIdx.x * 4 + wave;
-    const int64_t r_lo = (int64_t)gw * p.nrows / W, r_hi = (int64_t)(gw + 1) * p.nrows / W;
-    if (MODE == 0) {
-        if (tid < 32) thr_s[tid] = tid < p.nq ? p.thr[tid] : INFINITY;
-        __syncthreads();
-    }
+    // pieces of this wave: tiles gw, gw + W, ... of the whole rounds, then its share of the left-over rows
+    const int64_t rounds = (p.nrows / 32) / W;
+    const int64_t tail0 = rounds * W * 32, tail = p.nrows - tail0;
+    const int64_t tl_lo = tail0 + (int64_t)gw * tail / W, tl_hi = tail0 + (int64_t)(gw + 1) * tail / W;
+    const int64_t n_tl = (tl_hi - tl_lo + 31) / 32;           // tail tiles of this wave (usually 0 or 1)
+    const int64_t n_pieces = rounds + n_tl;
+    // piece i -> [first row, end row)
+    auto piece_lo = [&](int64_t i) { return i < rounds ? ((int64_t)gw + i * W) * 32 : tl_lo + (i - rounds) * 32; };
+    auto piece_hi = [&](int64_t i) { return i < rounds ? ((int64_t)gw + i * W) * 32 + 32 : tl_hi; };
     float *ts = tile_s + wave * 32 * LD;
-
     const char *qb = reinterpret_cast<const char *>(p.q), *dbb = reinterpret_cast<const char *>(p.db);
-    f32x4 qa[NP];
-#pragma unroll
-    for (int j = 0; j < NP; ++j)
-        qa[j] = l31 < p.nq ? *reinterpret_cast<const f32x4 *>(qb + (int64_t)l31 * RB + j * 32 + lhalf * 16)
-                           : f32x4{0.f, 0.f, 0.f, 0.f};
     const unsigned srow = (unsigned)p.row_stride * RB;      // bytes between two sampled rows
     const int lrow = lane / CPR, lcol = lane % CPR;         // lane -> (row inside the instruction's RPI rows, chunk)
     unsigned loff[NI];
@@ -254,27 +261,42 @@ __global__ __launch_bounds__(256, 2) void scan_small_kernel(ScanParams p) {
     for (int j = 0; j < NI; ++j) loff[j] = (unsigned)(j * RPI + lrow) * srow + (unsigned)lcol * 16u;
 
     f32x4 st[NI];                              // next tile, in flight
-    auto load_tile = [&](int64_t r0) {
-        const int64_t left = r_hi - r0;        // wave-uniform: rows of the range from this tile on
+    auto load_tile = [&](int64_t i) {
+        const int64_t r0 = i < n_pieces ? piece_lo(i) : 0;
+        const int64_t left = i < n_pieces ? piece_hi(i) - r0 : 0;   // wave-uniform: rows of the piece from r0 on
         const int nv = left >= 32 ? 32 : (left > 0 ? (int)left : 0);
         const __amdgpu_buffer_rsrc_t srd = make_srd(dbb + (nv > 0 ? r0 : 0) * (int64_t)srow,
                                                     nv > 0 ? (unsigned long long)(nv - 1) * srow + RB : 0ull);
+        // streamed once: non-temporal (no L2 / Infinity-Cache allocation): 512 MB in 78 us instead of 90 us in
+        // a bare read loop of this shape (tools/ubench/membw.hip)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) st[j] = buf_load4(srd, loff[j]);
+        for (int j = 0; j < NI; ++j)
+            st[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)loff[j], 0, /*aux: nt*/ 2));
     };
     float mx[16];
     if (MODE == 1) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx[r] = -INFINITY;
     }
-    load_tile(r_lo);
-    for (int64_t r0 = r_lo; r0 < r_hi; r0 += 32) {
+    load_tile(0);                              // the stream starts before anything else is fetched
+    if (MODE == 0) {
+        if (tid < 32) { thr_s[tid] = tid < p.nq ? p.thr[tid] : INFINITY; l_hist[tid] = 0; }
+        if (tid == 0) l_n = 0;
+        __syncthreads();
+    }
+    f32x4 qa[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j)
+        qa[j] = l31 < p.nq ? *reinterpret_cast<const f32x4 *>(qb + (int64_t)l31 * RB + j * 32 + lhalf * 16)
+                           : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int64_t pi = 0; pi < n_pieces; ++pi) {
+        const int64_t r0 = piece_lo(pi), r_hi = piece_hi(pi);
         // registers -> wave-private LDS tile (the previous tile's fragment reads are complete: their
         // results fed MFMAs already issued), then put the next tile in flight
 #pragma unroll
         for (int j = 0; j < NI; ++j)
             *reinterpret_cast<f32x4 *>(&ts[(j * RPI + lrow) * LD + lcol * 4]) = st[j];
-        load_tile(r0 + 32);                    // past the range: empty window, reads zeros, no traffic
+        load_tile(pi + 1);                     // past the last piece: empty window, reads zeros, no traffic
         __builtin_amdgcn_sched_barrier(0);
         f32x16 acc;
 #pragma unroll
@@ -312,20 +334,49 @@ __global__ __launch_bounds__(256, 2) void scan_small_kernel(ScanParams p) {
                 for (int e = 0; e < 4; ++e) any |= acc[4 * g + e] >= th[e];
             }
             if (__any(any && nok)) {
-                constexpr int NSUB = 32;
-                const int sub = (int)(r0 >> 5) & (NSUB - 1);
+                const int sub = (int)blockIdx.x & (NSUB - 1);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-                    if (nok && acc[r] >= thr_s[m]) {
-                        // same-address returning atomics serialise (~0.2 us each): with <= 32 query
-                        // rows one counter per row would take ~1600 hits, so each row has NSUB
-                        // sub-lists (CAP/NSUB slots each)
-                        const int pos = atomicAdd(&p.cnt[m * NSUB + sub], 1);
-                        if (pos < CAP / NSUB) p.keys[(int64_t)m * CAP + sub * (CAP / NSUB) + pos] = pack_key(acc[r], row);
+                    const bool sv = nok && acc[r] >= thr_s[m];
+                    const unsigned long long mask = __ballot(sv);
+                    if (mask != 0ull) {                                     // wave-uniform
+                        int base = 0;
+                        if (lane == (int)__builtin_ctzll(mask)) base = atomicAdd(&l_n, (int)__builtin_popcountll(mask));
+                        base = __builtin_amdgcn_readlane(base, (int)__builtin_ctzll(mask));
+                        const int pos = base + (int)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                        if (sv) {
+                            const unsigned long long key = pack_key(acc[r], row);
+                            if (pos < LCAP) {
+                                l_key[pos] = key;
+                                l_m[pos] = (unsigned short)m;
+                            } else {                                        // LDS list full (pathological): straight out
+                                const int gp = atomicAdd(&p.cnt[m * NSUB + sub], 1);
+                                if (gp < CAP / NSUB) p.keys[(int64_t)m * CAP + sub * (CAP / NSUB) + gp] = key;
+                            }
+                        }
                     }
                 }
             }
+        }
+    }
+    if (MODE == 0) {
+        // the workgroup's survivors -> the global sub-lists: one reservation per query row
+        __syncthreads();
+        const int sub = (int)blockIdx.x & (NSUB - 1);
+        const int n_l = l_n < LCAP ? l_n : LCAP;
+        for (int i = tid; i < n_l; i += 256) atomicAdd(&l_hist[l_m[i]], 1);
+        __syncthreads();
+        if (tid < 32) {
+            const int c = l_hist[tid];
+            l_base[tid] = c > 0 ? atomicAdd(&p.cnt[tid * NSUB + sub], c) : 0;
+            l_hist[tid] = 0;                                               // reused as the per-row cursor
+        }
+        __syncthreads();
+        for (int i = tid; i < n_l; i += 256) {
+            const int m = l_m[i];
+            const int gp = l_base[m] + atomicAdd(&l_hist[m], 1);
+            if (gp < CAP / NSUB) p.keys[(int64_t)m * CAP + sub * (CAP / NSUB) + gp] = l_key[i];
         }
     }
     if (MODE == 1) {
