@@ -7,6 +7,10 @@ int16 PCM is already resident in HBM:
     PCM -> mono float -> 1 s windows (0.5 s hop) -> log-mel -> CNN encoder -> unit-norm
     128-d fingerprints -> exact inner-product top-100 over the db -> sequence matcher
     -> (song, offset) decisions on the host.
+The database is REAL: every one of the 16,950 synthetic songs (1,000,050 segments) is embedded by the path itself,
+through the builder's own loop (pfann_amd.builder.embed_files, host PCM in -> fingerprints in HBM), whose throughput
+is reported as `builder`.  `value` is timed with the query PCM resident in HBM (the contract's definition); the same
+step with the PCM handed over in pinned host memory (H2D inside the timed region) is reported as `pcie_inclusive`.
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -46,7 +50,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--queries", type=int, default=512, help="10 s queries per step (whole job)")
     ap.add_argument("--db-songs", type=int, default=16950, help="16950 x 59 = 1,000,050 segments")
-    ap.add_argument("--real-songs", type=int, default=48)
+    ap.add_argument("--filler-db", action="store_true",
+                    help="round-1 style database (48 real songs + seeded unit-norm filler rows): scan-only studies")
     ap.add_argument("--snr", type=float, default=0.0)
     ap.add_argument("--max-batch", type=int, default=9728,
                     help="encoder chunk (segments); 9728 = the whole step in one chunk: 29 GB of activations, and the\n"
@@ -55,7 +60,7 @@ def main():
     ap.add_argument("--encoder-precision", type=int, default=0, choices=[0, 1],
                     help="0: exact fp32 MFMA (default, the headline); 1: opt-in 3-term fp16 split (pfann_set_encoder_precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-alt", action="store_true", help="skip the informational split-precision run")
+    ap.add_argument("--no-alt", action="store_true", help="skip the informational fp16-storage run")
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--dump-decisions", default=None, help="write (song, offset, score) per query as .npy (rank 0)")
     args = ap.parse_args()
@@ -99,33 +104,59 @@ def main():
     d, k = params["model"]["d"], params["indexer"]["top_k"]
     t_setup = time.time()
     eng = Engine(params, local_rank, max_batch=args.max_batch)
-    eng.load_state_dict(synth.make_state_dict(params, seed=123))
+    # seeded weights, output bias calibrated so that an untrained network's fingerprints spread over the sphere
+    # (pfann_amd/synth.py: make_state_dict_calibrated); identical constants on every box
+    sd = synth.make_state_dict_calibrated(params, seed=123)
+    eng.load_state_dict(sd)
     if args.encoder_precision:
         assert eng.set_encoder_precision(args.encoder_precision) == args.encoder_precision
 
     # ---------------------------------------------------------------- database (untimed)
+    from pfann_amd.builder import embed_files
     n_songs = args.db_songs
     song_pos = np.arange(n_songs + 1, dtype=np.int64) * SEG_PER_SONG
     n_rows = int(song_pos[-1])
-    real_ids = np.unique(np.linspace(0, n_songs - 1, args.real_songs).astype(np.int64))
-    songs = {int(s): synth.make_song(int(s)) for s in real_ids}
     s_lo, s_hi = shard_songs(song_pos, emu if emu > 1 else world)[rank]
     r_lo, r_hi = int(song_pos[s_lo]), int(song_pos[s_hi])
-    gen = torch.Generator(device=dev)
     shard = torch.empty((r_hi - r_lo, d), device=dev, dtype=torch.float32)
-    blk = 1 << 18
-    for gb in range(r_lo // blk, (r_hi + blk - 1) // blk):   # seeded filler rows: unit-norm Gaussian, generated in
-        b0, b1 = gb * blk, min((gb + 1) * blk, n_rows)        # fixed global blocks so every --gpus N sees the same db
-        gen.manual_seed(1234567 + gb)
-        x = torch.randn((b1 - b0, d), device=dev, generator=gen)
-        x = x / x.norm(dim=1, keepdim=True)
-        lo, hi = max(b0, r_lo), min(b1, r_hi)
-        shard[lo - r_lo:hi - r_lo] = x[lo - b0:hi - b0]
-    for s in real_ids:                                     # real songs embedded by the hot path itself
-        if s_lo <= s < s_hi:
-            e = eng.embed_wav(eng.pcm16_to_mono(songs[int(s)]), 4000)
-            assert e.shape[0] == SEG_PER_SONG
-            shard[int(song_pos[s]) - r_lo: int(song_pos[s + 1]) - r_lo] = e
+
+    class PcmList:                       # what builder.embed_files needs of a MusicDataset: files + load_pcm(i)
+        def __init__(self, ids, pcm_host):
+            self.files = ["synthetic song %d" % i for i in ids]
+            self.pcm = pcm_host
+
+        def load_pcm(self, i):
+            return self.pcm[i]           # int16 [n] in pinned HOST memory: the builder uploads it
+
+        def __len__(self):
+            return len(self.files)
+
+    builder_s, builder_segs = 0.0, 0
+    if args.filler_db:
+        gen = torch.Generator(device=dev)
+        blk = 1 << 18
+        for gb in range(r_lo // blk, (r_hi + blk - 1) // blk):
+            b0, b1 = gb * blk, min((gb + 1) * blk, n_rows)
+            gen.manual_seed(1234567 + gb)
+            x = torch.randn((b1 - b0, d), device=dev, generator=gen)
+            x = x / x.norm(dim=1, keepdim=True)
+            lo, hi = max(b0, r_lo), min(b1, r_hi)
+            shard[lo - r_lo:hi - r_lo] = x[lo - b0:hi - b0]
+    CH = 256                             # songs per generated chunk (123 MB of PCM)
+    real_ids = range(s_lo, s_hi) if not args.filler_db else \
+        [int(v) for v in np.unique(np.linspace(0, n_songs - 1, 48).astype(np.int64)) if s_lo <= v < s_hi]
+    host_buf = torch.empty((CH, SEG_PER_SONG * 4000 + 4000), dtype=torch.int16).pin_memory()
+    for c0 in range(0, len(real_ids), CH):
+        ids = list(real_ids[c0:c0 + CH])
+        host_buf[:len(ids)].copy_(synth.make_songs_torch(ids, 30.0, device=dev))      # synthesised on the device
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for i, n_seg, e in embed_files(eng, PcmList(ids, host_buf), 4000, batch_windows=args.max_batch):
+            assert n_seg == SEG_PER_SONG
+            shard[int(song_pos[ids[i]]) - r_lo: int(song_pos[ids[i] + 1]) - r_lo] = e
+        torch.cuda.synchronize()
+        builder_s += time.perf_counter() - tb
+        builder_segs += len(ids) * SEG_PER_SONG
     index = DeviceIndex(d, local_rank)
     index.load(shard, song_pos, r_lo)
     if world > 1 or emu > 1:
@@ -133,28 +164,38 @@ def main():
 
     # ----------------------------------------------------------------- queries (untimed)
     Q = args.queries
-    q_song = [int(real_ids[j % len(real_ids)]) for j in range(Q)]
-    q_pcm, q_off = [], []
-    for j in range(Q):
-        pcm, off = synth.make_query(songs[q_song[j]], j, 10.0, args.snr)
-        q_pcm.append(pcm)
-        q_off.append(off)
-    q_len = q_pcm[0].shape[0]
+    if args.filler_db:
+        all_real = np.unique(np.linspace(0, n_songs - 1, 48).astype(np.int64))
+        q_song = [int(all_real[j % len(all_real)]) for j in range(Q)]
+    else:
+        q_song = [int((j * 7919 + 13) % n_songs) for j in range(Q)]        # spread over the whole db
+    q_pcm_t, q_off_t = [], []
+    for c0 in range(0, Q, CH):
+        ids = q_song[c0:c0 + CH]
+        qp, qo = synth.make_queries_torch(synth.make_songs_torch(ids, 30.0, device=dev), list(range(c0, c0 + len(ids))),
+                                          10.0, args.snr)
+        q_pcm_t.append(qp)
+        q_off_t.append(qo)
+    q_pcm_all = torch.cat(q_pcm_t)                                          # [Q, 80000] int16 on the device
+    q_off = torch.cat(q_off_t).cpu().numpy()
+    q_len = q_pcm_all.shape[1]
     my_q = split_even(Q, emu if emu > 1 else world)[rank]
     q_counts = [(hi - lo) * QUERY_SEGS for lo, hi in split_even(Q, world)]
-    pcm_dev = torch.as_tensor(np.concatenate(q_pcm[my_q[0]:my_q[1]]) if my_q[1] > my_q[0]
-                              else np.zeros(0, np.int16)).to(dev)          # resident in HBM
+    pcm_dev = q_pcm_all[my_q[0]:my_q[1]].reshape(-1).contiguous()          # resident in HBM
+    pcm_host = pcm_dev.cpu().pin_memory()                                   # the same bytes as a host hand-over
     starts = (np.arange(my_q[1] - my_q[0], dtype=np.int64)[:, None] * q_len +
               np.arange(QUERY_SEGS, dtype=np.int64)[None, :] * 4000).reshape(-1)
     starts_dev = torch.as_tensor(starts).to(dev)
     qstart = np.arange(Q, dtype=np.int64) * QUERY_SEGS
     qlen = np.full(Q, QUERY_SEGS, dtype=np.int32)
     torch.cuda.synchronize()
-    log("[rank %d] setup %.1fs: shard rows %d (songs %d..%d), %d queries/step" %
-        (rank, time.time() - t_setup, r_hi - r_lo, s_lo, s_hi, Q))
+    log("[rank %d] setup %.1fs: shard rows %d (songs %d..%d, %d embedded by the builder loop in %.2f s), %d queries/step" %
+        (rank, time.time() - t_setup, r_hi - r_lo, s_lo, s_hi, builder_segs // SEG_PER_SONG, builder_s, Q))
 
-    def step():
-        wav = eng.pcm16_to_mono(pcm_dev)
+    cur_index = [index]
+
+    def step(from_host=False):
+        wav = eng.pcm16_to_mono(pcm_host.to(dev, non_blocking=True) if from_host else pcm_dev)
         emb = eng.embed_windows(wav, starts_dev)
         if emu > 1:
             emb = emb.repeat(emu, 1)[: Q * QUERY_SEGS].contiguous()
@@ -162,8 +203,8 @@ def main():
         if world > 1:
             emb = all_gather_ragged(emb, q_counts)
             return sharded.query_batch(emb, qstart, qlen), emb
-        D, I = index.search(emb, k)
-        res, _ = index.match(emb, I, qstart, qlen)
+        D, I = cur_index[0].search(emb, k)
+        res, _ = cur_index[0].match(emb, I, qstart, qlen)
         return res, emb
 
     def fence():
@@ -195,25 +236,47 @@ def main():
     n_seg = Q * QUERY_SEGS
     value = n_seg * args.steps / elapsed
 
-    # ---- informational: the opt-in split-precision encoder (never `value`): same step, 2 timed runs
+    # ---- the same step with the query PCM handed over in pinned host memory (never `value`)
+    pcie = None
+    if emu <= 1:
+        step(True)
+        fence()
+        tp = time.perf_counter()
+        for _ in range(args.steps):
+            step(True)
+        fence()
+        el = time.perf_counter() - tp
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        pcie = {"value": round(n_seg * args.steps / el, 1), "unit": "segments/s", "ms_per_step": round(1e3 * el / args.steps, 3),
+                "what": "same step, int16 query PCM in pinned host memory, H2D (%.1f MB/step/rank) inside the timed region"
+                        % (pcm_host.numel() * 2 / 1e6)}
+
+    # ---- informational: fp16-only storage of the same db (BASELINE config 5's "fp16 embeddings"; never `value`)
     alt = None
-    if world == 1 and emu <= 1 and not args.encoder_precision and not args.no_alt:
-        if eng.set_encoder_precision(1) == 1:
-            step()
-            torch.cuda.synchronize()
-            ta = time.perf_counter()
-            for _ in range(2):
-                res_alt, emb_alt = step()
-            torch.cuda.synchronize()
-            el = (time.perf_counter() - ta) / 2
-            same = int(np.sum((res_alt["song"] == res["song"]) & (res_alt["offset"] == res["offset"])))
-            alt = {"encoder_precision_1": {
-                "what": "conv products as 3 fp16-MFMA terms of 2-term operand splits (2^-22 relative), fp32 accumulate; "
-                        "pfann_set_encoder_precision(ctx, 1); NOT the headline value",
-                "value": round(n_seg / el, 1), "unit": "segments/s", "ms_per_step": round(1e3 * el, 3),
-                "max_abs_embedding_diff_vs_fp32_path": float((emb_alt - emb).abs().max().item()),
-                "decisions_identical_to_fp32_path": "%d/%d" % (same, Q)}}
-        eng.set_encoder_precision(0)
+    if world == 1 and emu <= 1 and not args.no_alt:
+        idx16 = DeviceIndex(d, local_rank, storage="f16")
+        idx16.load(shard, song_pos, r_lo)
+        cur_index[0] = idx16
+        step()
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for _ in range(args.steps):
+            res16, _ = step()
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - ta) / args.steps
+        cur_index[0] = index
+        same = int(np.sum((res16["song"] == res["song"]) & (res16["offset"] == res["offset"])))
+        hit16 = int(np.sum(res16["song"] == np.asarray(q_song)))
+        alt = {"fp16_db": {
+            "what": "pfann_db_set_storage(PFANN_DB_F16): only fp16 rows kept (%d MB instead of %d MB), fp16-MFMA scan without "
+                    "fp32 re-scoring, sequence scores over the stored rows; approximate like faiss useFloat16 "
+                    "(database.py:101-104); NOT the headline value" % ((r_hi - r_lo) * d * 2 >> 20, (r_hi - r_lo) * d * 4 >> 20),
+            "value": round(n_seg / el, 1), "unit": "segments/s", "ms_per_step": round(1e3 * el, 3),
+            "decisions_identical_to_fp32_db": "%d/%d" % (same, Q), "top1_hit_rate": round(hit16 / Q, 4)}}
+        del idx16
 
     # ------------------------------------------------------------ per-kernel event times
     kernels = {}
@@ -293,6 +356,13 @@ def main():
     if prof and world == 1:
         import ctypes
         q19 = emb[:QUERY_SEGS].contiguous()
+        if os.environ.get("PFANN_BENCH_SLEEP"):
+            time.sleep(float(os.environ["PFANN_BENCH_SLEEP"]))
+        if os.environ.get("PFANN_BENCH_FREE"):
+            del eng
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
         for _ in range(30):                    # short kernels separated by host syncs: let the clocks settle
             index.search(q19, k)
         lib.pfann_prof_reset()
@@ -358,18 +428,19 @@ def main():
         if int(res[j]["song"]) == q_song[j]:
             hits += 1
             tm = int(res[j]["offset"]) * 0.5
-            near += abs(tm - q_off[j]) <= 0.5
-            exact += abs(tm - q_off[j]) <= 0.25
+            near += abs(tm - float(q_off[j])) <= 0.5
+            exact += abs(tm - float(q_off[j])) <= 0.25
     # ------------------------------------------- CPU baseline + decision parity (rank 0)
     cpu = None
     parity = None
+    seam_info = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import encoder as oe
         from oracle import melspec as om
         from oracle import native, search as osr, segmenter as osg
         nq_cpu = min(args.cpu_queries, Q)
         db_host = shard.cpu().numpy()
-        sd = synth.make_state_dict(params, seed=123)
+        q_pcm = q_pcm_all[:nq_cpu].cpu().numpy()
         native.lib()
         tc = time.perf_counter()
         agree = 0
@@ -386,6 +457,32 @@ def main():
                          "mel+encoder, BLAS sgemm + argpartition top-%d, C seq_score; host has %d logical cores"
                          % (nq_cpu, nq_cpu * QUERY_SEGS, n_rows, k, os.cpu_count())}
         parity = {"queries": nq_cpu, "identical_song_and_offset": int(agree)}
+        # the reference's own native seam (cpp/seqscore.cpp:32-43 via database.py:178-189): host pointers in, best song
+        # out, against the same call on the oracle's C restatement (OpenMP over candidates) on the host cores
+        import ctypes
+        q1 = np.ascontiguousarray(emb[:QUERY_SEGS].cpu().numpy())
+        _, I1 = index.search(emb[:QUERY_SEGS].contiguous(), k)
+        lab1 = np.ascontiguousarray(I1.cpu().numpy())
+        f32p, i64p = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int64)
+
+        def seam():
+            ss = np.zeros((n_songs, 2), np.float32)
+            return lib.seq_score(index.handle, song_pos.ctypes.data_as(i64p), n_songs, q1.ctypes.data_as(f32p), QUERY_SEGS,
+                                 lab1.ctypes.data_as(i64p), k, ss.ctypes.data_as(f32p), 1, 0.0), ss
+        b_gpu, ss_gpu = seam()
+        t1 = time.perf_counter()
+        for _ in range(50):
+            seam()
+        seam_us = 1e6 * (time.perf_counter() - t1) / 50
+        b_cpu, ss_cpu = native.seq_score(db_host, song_pos, q1, lab1, 1, 0.0)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            native.seq_score(db_host, song_pos, q1, lab1, 1, 0.0)
+        seam_cpu_us = 1e6 * (time.perf_counter() - t1) / 5
+        seam_info = {"gpu_call_us": round(seam_us, 1), "cpu_oracle_call_us": round(seam_cpu_us, 1),
+                     "same_best_song": bool(b_gpu == b_cpu), "max_abs_score_diff": float(np.abs(ss_gpu - ss_cpu)[:, 0].max()),
+                     "what": "seq_score(index, song_pos, n_songs, query[19x128], labels[19x100], song_scores, 1, 0) with host "
+                             "pointers, as database.py:178-189 calls it; device scratch cached in the handle"}
 
     if rank == 0 and args.dump_decisions:
         np.save(args.dump_decisions, np.stack([res["song"].astype(np.float64), res["offset"].astype(np.float64),
@@ -400,15 +497,25 @@ def main():
             "dtype_note": "all results exact fp32 (fp32 MFMA encoder; batched scan pre-filtered on fp16 MFMA with a rigorous "
                           "margin, then re-scored in fp32)",
             "data": "synthetic",
-            "config": {"workload": "%d-segment db (%d songs x %d segs, %d real synthetic songs + unit-norm filler rows), "
-                                   "%d x 10 s queries/step at SNR %g dB (%d segments), configs/default.json encoder "
-                                   "(d=128,h=1024,u=32,fuller), top_k=100" %
-                                   (n_rows, n_songs, SEG_PER_SONG, len(real_ids), Q, args.snr, n_seg),
+            "config": {"workload": ("%d-segment db = %d real synthetic 30 s songs x %d segments, every one embedded by the hot path "
+                                    "(builder loop)" % (n_rows, n_songs, SEG_PER_SONG) if not args.filler_db else
+                                    "%d-segment db (%d songs x %d segs, 48 real synthetic songs + unit-norm filler rows)"
+                                    % (n_rows, n_songs, SEG_PER_SONG)) +
+                                   "; %d x 10 s queries/step at SNR %g dB (%d segments), configs/default.json encoder "
+                                   "(d=128,h=1024,u=32,fuller; seeded weights with calibrated output bias), top_k=100" %
+                                   (Q, args.snr, n_seg),
                        "db_rows": n_rows, "queries_per_step": Q, "segments_per_step": n_seg,
                        "parallelism": "song-sharded db x%d" % world, "max_batch": args.max_batch},
             "top1_hit_rate": round(hits / Q, 4), "top1_near_0.5s": round(near / Q, 4),
             "top1_exact_0.25s": round(exact / Q, 4),
             "roofline": roofline, "single_query_scan_roofline": single, "cpu_baseline": cpu, "oracle_decision_parity": parity,
+            "builder": None if not builder_segs else {
+                "value": round(builder_segs / builder_s, 1), "unit": "segments/s", "segments": builder_segs,
+                "seconds": round(builder_s, 3),
+                "what": "pfann_amd.builder.embed_files over this rank's songs: int16 PCM in pinned host memory -> H2D -> mono -> "
+                        "windows -> log-mel -> encoder -> unit-norm fingerprints in HBM (builder.py:75-103's loop), "
+                        "%d windows per launch group" % args.max_batch},
+            "pcie_inclusive": pcie, "seq_score_seam": seam_info,
             "alt_modes": alt,
             "kernels": {t: {kk: (float("%.4g" % vv) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                         for t, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},

@@ -206,3 +206,116 @@ def unit_rows(seed: int, name: str, n: int, d: int) -> np.ndarray:
     x = normal(seed, name, n * d).reshape(n, d).astype(np.float64)
     x /= np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-12)
     return x.astype(np.float32)
+
+
+# ------------------------------------------------- large-scale synthetic audio (torch, any device)
+# BASELINE configs 2-5 need 10 k - 100 k songs and thousands of queries: the numpy generators above
+# (~40 ms per song) would take an hour, so the same kind of signal is generated with torch ops that run on the
+# GPU box's device (100 k songs in seconds) -- and on the CPU here, for the calibration constants below.
+# Everything is a pure function of integer ids (splitmix64 in wrapping int64 arithmetic); fp64 phases.
+_SM1, _SM2, _SM3 = -7046029254386353131, -4658895280553007687, -7723592293110705685   # splitmix64 constants as int64
+
+
+def _lsr(x, s):
+    return (x >> s) & ((1 << (64 - s)) - 1)
+
+
+def _hash64(x):
+    x = x + _SM1
+    x = (x ^ _lsr(x, 30)) * _SM2
+    x = (x ^ _lsr(x, 27)) * _SM3
+    return x ^ _lsr(x, 31)
+
+
+def _u01_t(h, which=0):
+    """24-bit uniform in [0,1) from bits [40,64) (which=0) or [8,32) (which=1) of a hash, float64."""
+    import torch
+    bits = _lsr(h, 40) if which == 0 else (_lsr(h, 8) & 0xFFFFFF)
+    return bits.to(torch.float64) * (1.0 / (1 << 24))
+
+
+def make_songs_torch(song_ids, seconds=30.0, sr=8000, device="cpu"):
+    """-> int16 [S, n] mono songs: 8 partials of piecewise notes (0.9 - 3.4 s) with FM and AM in 300-3800 Hz
+    plus -20 dB white noise, peak-normalised; song s is a pure function of its id."""
+    import torch
+    ids = torch.as_tensor(song_ids, dtype=torch.int64, device=device).reshape(-1, 1)        # [S,1]
+    n = int(seconds * sr)
+    t = torch.arange(n, dtype=torch.int64, device=device).reshape(1, -1)                     # [1,n]
+    x = torch.zeros((ids.shape[0], n), dtype=torch.float32, device=device)
+    two_pi = 2.0 * math.pi
+    for p in range(8):
+        hp = _hash64(ids * 1000003 + p * 7919 + 17)                                          # per (song, partial)
+        L = int((0.9 + 0.36 * p) * sr)
+        off = (_u01_t(hp) * L).to(torch.int64)                                               # [S,1]
+        amp = (0.3 + 0.7 * _u01_t(hp, 1)).to(torch.float32)
+        tt = t + off
+        note, tau = tt // L, (tt % L).to(torch.float64) / sr                                 # [S,n]
+        h1 = _hash64(ids * 2000003 + p * 104729 + note * 15485863 + 29)
+        h2 = _hash64(h1 + 0x5851F42D)
+        f0 = 300.0 + 3500.0 * _u01_t(h1)
+        fm_rate, fm_depth = 0.5 + 4.0 * _u01_t(h1, 1), 2.0 * _u01_t(h2)
+        ph0 = _u01_t(h2, 1)
+        h3 = _hash64(h2 + 0x2545F491)
+        am_rate, am_ph = 0.3 + 2.0 * _u01_t(h3), _u01_t(h3, 1)
+        turns = f0 * tau + ph0
+        phase = (two_pi * (turns - torch.floor(turns))).to(torch.float32) + \
+            (fm_depth.to(torch.float32) * torch.sin((two_pi * fm_rate * tau).to(torch.float32)))
+        am = 0.6 + 0.4 * torch.sin((two_pi * (am_rate * tau + am_ph)).to(torch.float32))
+        x += amp * am * torch.sin(phase)
+        del h1, h2, h3, f0, fm_rate, fm_depth, ph0, am_rate, am_ph, turns, phase, am, note, tau, tt
+    x /= x.square().mean(dim=1, keepdim=True).sqrt().clamp_min(1e-9)
+    hn = _hash64(ids * 4294967311 + t)
+    hn2 = _hash64(hn + 0x632BE5AB)
+    nz = ((_u01_t(hn) + _u01_t(hn, 1) + _u01_t(hn2) + _u01_t(hn2, 1) - 2.0) * math.sqrt(3.0)).to(torch.float32)
+    x += 0.1 * nz
+    x /= x.abs().amax(dim=1, keepdim=True) + 1e-12
+    return torch.round(x * 32000.0).to(torch.int16)
+
+
+def make_queries_torch(song_pcm, query_ids, seconds=10.0, snr_db=0.0, sr=8000):
+    """song_pcm int16 [Q, n] (row j = the source song of query j), query_ids [Q] -> (int16 [Q, sel] queries,
+    float64 [Q] offsets in seconds): random crop (genquery.py:42-53), white noise at snr_db by the formula of
+    datautil/noise.py:96-109, peak normalise (genquery.py:94), 16-bit quantise.  Seeded by 9000 + query id."""
+    import torch
+    dev = song_pcm.device
+    Q, n = song_pcm.shape
+    sel = int(seconds * sr)
+    assert n >= sel
+    qid = torch.as_tensor(query_ids, dtype=torch.int64, device=dev).reshape(-1, 1) + 9000
+    off = (_u01_t(_hash64(qid * 6700417 + 5)) * max(n - sel, 1)).to(torch.int64)            # [Q,1]
+    t = torch.arange(sel, dtype=torch.int64, device=dev).reshape(1, -1)
+    x = torch.gather(song_pcm, 1, off + t).to(torch.float32) / 32768.0
+    h = _hash64(qid * 4294967311 + t + (1 << 40))
+    u1, u2 = _u01_t(h).clamp_min(2.0 ** -25), _u01_t(h, 1)
+    nz = (torch.sqrt(-2.0 * torch.log(u1)) * torch.cos(2.0 * math.pi * u2)).to(torch.float32)
+    vol_x = x.square().mean(dim=1, keepdim=True).clamp_min(1e-12).sqrt()
+    vol_n = nz.square().mean(dim=1, keepdim=True).clamp_min(1e-12).sqrt()
+    y = x + (vol_x / vol_n * (10.0 ** (-snr_db / 20.0))) * nz
+    y /= y.abs().amax(dim=1, keepdim=True) + 1e-12
+    return torch.round(y * 32767.0).to(torch.int16), off.reshape(-1).to(torch.float64) / sr
+
+
+# An UNTRAINED FpNetwork maps every input to nearly the same point (pairwise cosine 0.986 +- 0.003 between
+# segments of different songs with the seeded weights above: ReLU + LayerNorm stacks contract angles), which makes a
+# large "real" database degenerate: every score within 0.02 of every other.  No trained weights exist here, so for
+# the large-scale workloads the seeded state_dict is CALIBRATED the way data-dependent initialisers do it: the head's
+# output bias g.linear2.bias is shifted by minus the mean un-normalised output over a calibration set (24 synthetic
+# songs, computed once by tools/make_synth_calib.py with the CPU oracle and stored in synth_calib.json), so the
+# embeddings spread over the sphere (cosine between different songs 0.00 +- 0.15).  Same architecture, same
+# arithmetic; the constants are data shipped with the package, so weights are identical on every box.
+def calib_key(params, seed):
+    m = params["model"]
+    return "d%d_h%d_u%d_fuller%d_%s_seed%d" % (m["d"], m["h"], m["u"], 1 if m.get("fuller", False) else 0,
+                                                m.get("conv_activation", "ReLU"), seed)
+
+
+def make_state_dict_calibrated(params, seed=123):
+    import json
+    import os
+    sd = make_state_dict(params, seed)
+    table = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "synth_calib.json")))
+    key = calib_key(params, seed)
+    if key not in table:
+        raise KeyError("no calibration constants for %s: run tools/make_synth_calib.py" % key)
+    sd["g.linear2.bias"] = (sd["g.linear2.bias"].astype(np.float64) - np.asarray(table[key], np.float64)).astype(np.float32)
+    return sd

@@ -13,7 +13,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_json_contract_small():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1",
-                        "--queries", "16", "--db-songs", "400", "--real-songs", "8", "--cpu-queries", "4"],
+                        "--queries", "16", "--db-songs", "400", "--cpu-queries", "4"],
                        capture_output=True, text=True, timeout=900, cwd=REPO)
     assert r.returncode == 0, r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -32,13 +32,16 @@ def test_bench_json_contract_small():
     par = out["oracle_decision_parity"]
     assert par["identical_song_and_offset"] == par["queries"]
     assert out["top1_hit_rate"] > 0.5
+    assert out["builder"]["value"] > 0 and out["pcie_inclusive"]["value"] > 0
+    assert out["alt_modes"]["fp16_db"]["decisions_identical_to_fp32_db"].endswith("/16")
+    assert out["seq_score_seam"]["same_best_song"] is True
 
 
 def test_two_rank_sharded_path_matches_single_gpu(tmp_path):
     """N>1 on the real kernels: 2 ranks sharing this box's GPU (gloo-staged collectives, debugging
     aid) must reach exactly the single-GPU decisions."""
     import numpy as np
-    common = ["--steps", "1", "--warmup", "0", "--queries", "24", "--db-songs", "600", "--real-songs", "8",
+    common = ["--steps", "1", "--warmup", "0", "--queries", "24", "--db-songs", "600",
               "--no-cpu-baseline", "--no-prof", "--max-batch", "512"]
     one = str(tmp_path / "one.npy")
     two = str(tmp_path / "two.npy")

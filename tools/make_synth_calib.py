@@ -1,0 +1,41 @@
+#!/usr/bin/env python
+"""Calibration constants of pfann_amd.synth.make_state_dict_calibrated: mean un-normalised head output of the seeded
+FpNetwork over 24 synthetic songs (torch generator on the CPU, oracle encoder), per config.
+    python tools/make_synth_calib.py          (build container only; writes pfann_amd/synth_calib.json)"""
+import json
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from oracle import encoder as oe, melspec as om, segmenter as osg  # noqa: E402
+from pfann_amd import synth  # noqa: E402
+
+
+def main():
+    out = {}
+    for cfg in ("default", "n640d64", "tiny"):
+        params = json.load(open(os.path.join(REPO, "configs", cfg + ".json")))
+        sd = synth.make_state_dict(params, seed=123)
+        pcm = synth.make_songs_torch(np.arange(24) * 4099 + 7, seconds=12.0).numpy()
+        raws = []
+        for s in range(pcm.shape[0]):
+            segs = osg.segment(osg.pcm_to_mono(pcm[s][:, None]), 8000, 4000)
+            raws.append(oe.encode(om.melspec(segs, params), sd, params, norm=False))
+        R = np.concatenate(raws).astype(np.float64)
+        mu = R.mean(0)
+        Z = R - mu
+        E = Z / np.linalg.norm(Z, axis=1, keepdims=True)
+        G = E @ E.T
+        n = raws[0].shape[0]
+        diff = np.concatenate([G[a * n:(a + 1) * n, b * n:(b + 1) * n].ravel() for a in range(24) for b in range(24) if a != b])
+        print(cfg, "rows", R.shape[0], "|mean| %.4f  per-dim std %.5f  ->  cos between songs after centring %.3f +- %.3f"
+              % (np.linalg.norm(mu), R.std(0).mean(), diff.mean(), diff.std()))
+        out[synth.calib_key(params, 123)] = [float(v) for v in mu]
+    json.dump(out, open(os.path.join(REPO, "pfann_amd", "synth_calib.json"), "w"), indent=0)
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,9 @@ from pfann_amd.database import DeviceIndex
 
 def main(n=1000050, d=128, nq=19, k=100, iters=30):
     dev = torch.device("cuda", 0)
+    if os.environ.get("SCAN_PREALLOC_GB"):          # does what was allocated before the db change the pass time?
+        dummy = torch.empty(int(float(os.environ["SCAN_PREALLOC_GB"]) * (1 << 30)), dtype=torch.uint8, device=dev)
+        dummy.fill_(1)
     g = torch.Generator(device=dev); g.manual_seed(1)
     db = torch.randn((n, d), device=dev, generator=g); db /= db.norm(dim=1, keepdim=True)
     q = db[torch.arange(nq, device=dev) * 977 + 5] * 0.8 + 0.2 * torch.randn((nq, d), device=dev, generator=g)
