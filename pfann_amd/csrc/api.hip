@@ -168,6 +168,9 @@ pfann_ctx *pfann_create(const pfann_config *cfg, int device) {
         c->buf_elems[i & 1] = std::max(c->buf_elems[i & 1], e);
     }
     c->fused = fused_supported(c->sub, 16) && getenv("PFANN_NO_FUSE") == nullptr;
+    if (!c->fused && cfg->fuller && getenv("PFANN_NO_FUSE") == nullptr)
+        fprintf(stderr, "pfann_amd: this model's layer shapes (an Fo*To that is not a power of two, or channel counts not "
+                        "multiples of 4) are outside the LayerNorm-fused GEMM path; using the separate-LayerNorm kernels\n");
     if (getenv("PFANN_STREAMS")) pfann_set_streams(c, atoi(getenv("PFANN_STREAMS")));
     for (int i = 0; i < 16; ++i) {
         const SubLayer &L = c->sub[i];

@@ -176,6 +176,43 @@ def test_encoder_vs_reference_golden(torch_cuda, name, fused):
     assert np.abs(emb2 - z["emb"]).max() < 1e-4
 
 
+@pytest.mark.parametrize("fused", [True, False])
+def test_encoder_large_mean_activations(torch_cuda, fused):
+    """LayerNorm statistics under a large mean-to-std ratio (the fused path combines fp32 per-tile
+    (sum, sum of squares) partials as E[z^2] - mean^2): LayerNorm biases x20 (activations entering every conv sit
+    far from zero) and every conv bias +3 (pre-LayerNorm mean several std away from 0).  Same 1e-4 embedding bar
+    against the CPU oracle (torch layer_norm, two-pass), and every sub-layer activation within 2e-4 relative."""
+    from oracle import encoder as oe
+    from pfann_amd.engine import Engine
+    params = cfg("default")
+    _, _, _, F, T = synth.model_dims(params)
+    sd = synth.make_state_dict(params, seed=321)
+    for name in sd:
+        if ".ln" in name and name.endswith(".bias"):
+            sd[name] = (sd[name] * 20.0).astype(np.float32)
+        if ".conv" in name and name.endswith(".bias"):
+            sd[name] = (sd[name] + 3.0).astype(np.float32)
+    eng = Engine(params, 0, max_batch=8)
+    eng.load_state_dict(sd)
+    assert eng.set_fused_layernorm(fused) == fused
+    eng.debug_keep(True)
+    x = mg.encoder_inputs(F, T)
+    xt = torch_cuda.as_tensor(x).cuda()
+    emb = eng.encode(xt, norm=True).cpu().numpy()
+    taps_ref = []
+    ref = oe.encode(x, sd, params, norm=True, taps=taps_ref)
+    ratios, worst = [], 0.0
+    for i, tr in enumerate(taps_ref):
+        tg = eng.debug_activation(i, x.shape[0])
+        e = np.abs(tg - tr).max() / max(1.0, np.abs(tr).max())
+        worst = max(worst, e)
+    print("large-mean (%s): emb err %.3e, worst tap rel err %.3e" % ("fused" if fused else "unfused", np.abs(emb - ref).max(), worst))
+    assert worst < 2e-4
+    assert np.abs(emb - ref).max() < 1e-4
+    eng.debug_keep(False)
+    assert np.abs(eng.encode(xt, norm=True).cpu().numpy() - ref).max() < 1e-4
+
+
 def test_encoder_split_precision_matches_fp32(torch_cuda):
     """Opt-in encoder arithmetic (pfann_set_encoder_precision = 1): conv products as three fp16 MFMA
     terms of two-term operand splits, fp32 accumulation.  Must stay fp32-grade: embeddings within 2e-5
