@@ -199,6 +199,17 @@ int pfann_match(pfann_db *db, const float *q_dev, const int64_t *labels_dev, int
                 int frame_shift_mul, float score_alpha, int mode, int only_owned,
                 pfann_match_result *results_dev, float *song_scores_dev, void *stream);
 
+/* Song-sharded multi-GPU retrieval, winner selection without the host (no reference counterpart):
+ * pfann_match_pack turns this rank's results_dev[nQ] (from pfann_match with only_owned=1, python path) into one
+ * 128-bit key per query, keys_dev[nQ][2] = (hi, lo) uint64, whose unsigned lexicographic order is the reference's
+ * preference -- higher score first, ties to the smallest (shift, song, offset), the order of its np.unique-sorted
+ * candidate list (database.py:129,140,158-163); a query without candidates gets all ones.  After an all-gather of the
+ * keys (16 bytes per query and rank), pfann_match_pick reduces keys_dev[n_ranks][nQ][2] to the winners, out_dev[nQ]
+ * (n_cand = 0).  Both are asynchronous on `stream`. */
+int pfann_match_pack(pfann_db *db, const pfann_match_result *results_dev, int64_t nQ, uint64_t *keys_dev, void *stream);
+int pfann_match_pick(pfann_db *db, const uint64_t *keys_dev, int n_ranks, int64_t nQ, pfann_match_result *out_dev,
+                     void *stream);
+
 /* Bytes of the shard's fingerprint matrix as stored (n*d*4, or n*d*2 with fp16 storage). */
 int64_t pfann_db_bytes(pfann_db *db);
 

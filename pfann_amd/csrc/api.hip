@@ -728,6 +728,17 @@ int pfann_match(pfann_db *db, const float *q, const int64_t *labels, int k, cons
     return launch_match(a, (hipStream_t)stream);
 }
 
+int pfann_match_pack(pfann_db *db, const pfann_match_result *results_dev, int64_t nQ, uint64_t *keys_dev, void *stream) {
+    PF_HIP(hipSetDevice(db->device));
+    return launch_match_pack(results_dev, nQ, reinterpret_cast<unsigned long long *>(keys_dev), (hipStream_t)stream);
+}
+
+int pfann_match_pick(pfann_db *db, const uint64_t *keys_dev, int n_ranks, int64_t nQ, pfann_match_result *out_dev, void *stream) {
+    PF_HIP(hipSetDevice(db->device));
+    if (n_ranks < 1) { set_error("pfann_match_pick: n_ranks < 1"); return -1; }
+    return launch_match_pick(reinterpret_cast<const unsigned long long *>(keys_dev), n_ranks, nQ, out_dev, (hipStream_t)stream);
+}
+
 int seq_score(void *index, const int64_t *song_pos, int n_songs, const float *query, int query_len,
               const int64_t *labels, int top_k, float *song_scores, int frame_shift_mul, float score_alpha) {
     pfann_db *db = (pfann_db *)index;

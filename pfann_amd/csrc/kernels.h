@@ -90,6 +90,8 @@ struct RerankArgs {
     pfann_match_result *results; float *song_scores;
 };
 int launch_match(const RerankArgs &a, hipStream_t s);
+int launch_match_pack(const pfann_match_result *res, int64_t nQ, unsigned long long *keys, hipStream_t s);
+int launch_match_pick(const unsigned long long *keys, int G, int64_t nQ, pfann_match_result *out, hipStream_t s);
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): the attribute is per device
 int ensure_dyn_lds(const void *func, int bytes);
 

@@ -144,6 +144,40 @@ __global__ __launch_bounds__(NT) void match_kernel(RerankArgs a) {
         const int slen = (int)(a.song_pos[cd.song + 1] - start);
         const int sub_len = (qlen - cd.shift + a.fsm - 1) / a.fsm;
         float tot = 0.f;         // mode 0: lane-partial of the whole dot; mode 1: running sco
+        if (a.fsm == 1 && (a.mode == 0 || a.alpha == 0.0f)) {
+            // The rows of one alignment are ONE contiguous block of the db (and of the query): a single long dot
+            // product read with independent 16-byte loads, four chunks in flight per lane, instead of qlen
+            // row-by-row round trips -- the matcher is a random 10 KB gather per candidate and lives on memory-level
+            // parallelism.  Fixed, data-independent summation order: duplicated songs still tie bit-exactly.
+            const int j_lo = cd.off < 0 ? -cd.off : 0;
+            const int j_hi = min(sub_len, slen - cd.off);
+            const int nch = j_hi > j_lo ? (j_hi - j_lo) * (a.d >> 2) : 0;
+            const int64_t ro = (start + cd.off + j_lo - a.label_base) * a.d;
+            const float4 *qb = reinterpret_cast<const float4 *>(a.q + (q0 + j_lo) * a.d);
+            float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+            if (a.db != nullptr) {
+                const float4 *vb = reinterpret_cast<const float4 *>(a.db + ro);
+#pragma unroll 4
+                for (int ch = lane; ch < nch; ch += 64) {
+                    const float4 v = vb[ch], w = qb[ch];
+                    p0 = fmaf(v.x, w.x, p0); p1 = fmaf(v.y, w.y, p1); p2 = fmaf(v.z, w.z, p2); p3 = fmaf(v.w, w.w, p3);
+                }
+            } else {
+                typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                const f16x4 *vb = reinterpret_cast<const f16x4 *>(reinterpret_cast<const _Float16 *>(a.dbh) + ro);
+#pragma unroll 4
+                for (int ch = lane; ch < nch; ch += 64) {
+                    const f16x4 v = vb[ch];
+                    const float4 w = qb[ch];
+                    p0 = fmaf((float)v[0], w.x, p0); p1 = fmaf((float)v[1], w.y, p1);
+                    p2 = fmaf((float)v[2], w.z, p2); p3 = fmaf((float)v[3], w.w, p3);
+                }
+            }
+            tot = wave_sum((p0 + p1) + (p2 + p3));
+            if (a.mode != 0) tot = tot / (float)max(sub_len, 1);
+            if (lane == 0) score[c] = tot;
+            continue;
+        }
         for (int j = 0; j < sub_len; ++j) {
             const int r = cd.off + j;
             if (r < 0 || r >= slen) continue;
@@ -243,6 +277,57 @@ __global__ __launch_bounds__(NT) void match_kernel(RerankArgs a) {
             }
         }
     }
+}
+
+// ---- multi-GPU winner selection ----------------------------------------------------------------------
+// One 128-bit key per (rank, query) whose UNSIGNED lexicographic order (hi, lo) is the reference's preference:
+// higher score first, ties -> the candidate that comes first in its sorted candidate list, i.e. the smallest
+// (shift, song, offset) (database.py:129,140,158-163: strict '>' over np.unique-sorted candidates).
+//   hi = ~orderable(score as fp64)      lo = shift << 58 | song << 28 | (offset + 2^27)      (no candidate: all ones)
+__device__ __forceinline__ unsigned long long ord64(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return u ^ ((u >> 63) ? ~0ull : 0x8000000000000000ull);
+}
+__global__ void match_pack_kernel(const pfann_match_result *__restrict__ res, int64_t nQ, unsigned long long *__restrict__ keys) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nQ) return;
+    const pfann_match_result r = res[j];
+    unsigned long long hi = ~0ull, lo = ~0ull;
+    if (r.song >= 0) { hi = ~ord64(r.score + 0.0); lo = pack_cand(0, r.song, r.offset, r.shift); }   // -0.0 + 0.0 = +0.0: equal scores, equal bits
+    keys[2 * j] = hi;
+    keys[2 * j + 1] = lo;
+}
+__global__ void match_pick_kernel(const unsigned long long *__restrict__ keys, int G, int64_t nQ, pfann_match_result *__restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nQ) return;
+    unsigned long long bh = ~0ull, bl = ~0ull;
+    for (int g = 0; g < G; ++g) {
+        const unsigned long long h = keys[((int64_t)g * nQ + j) * 2], l = keys[((int64_t)g * nQ + j) * 2 + 1];
+        if (h < bh || (h == bh && l < bl)) { bh = h; bl = l; }
+    }
+    pfann_match_result r;
+    r.n_cand = 0;
+    if (bh == ~0ull && bl == ~0ull) {
+        r.song = -1; r.offset = 0; r.shift = 0; r.score = -INFINITY;
+    } else {
+        const Cand c = unpack_cand(0, bl);
+        r.song = c.song; r.offset = c.off; r.shift = c.shift;
+        const unsigned long long o = ~bh;
+        r.score = __longlong_as_double((long long)(o ^ ((o >> 63) ? 0x8000000000000000ull : ~0ull)));
+    }
+    out[j] = r;
+}
+int launch_match_pack(const pfann_match_result *res, int64_t nQ, unsigned long long *keys, hipStream_t s) {
+    if (nQ <= 0) return 0;
+    PF_LAUNCH(match_pack_kernel, dim3((unsigned)cdiv(nQ, 256)), dim3(256), 0, s, res, nQ, keys);
+    PF_HIP(hipGetLastError());
+    return 0;
+}
+int launch_match_pick(const unsigned long long *keys, int G, int64_t nQ, pfann_match_result *out, hipStream_t s) {
+    if (nQ <= 0) return 0;
+    PF_LAUNCH(match_pick_kernel, dim3((unsigned)cdiv(nQ, 256)), dim3(256), 0, s, keys, G, nQ, out);
+    PF_HIP(hipGetLastError());
+    return 0;
 }
 
 int launch_match(const RerankArgs &a, hipStream_t s) {

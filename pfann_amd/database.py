@@ -96,8 +96,34 @@ class DeviceIndex:
                      "pfann_topk_merge")
         return D, I
 
-    def match(self, q, labels, qstart, qlen, fsm=1, alpha=0.0, mode=0, only_owned=False, want_song_scores=False):
-        """Sequence matcher for nQ queries.  Returns (results structured array, song_scores or None)."""
+    RESULT_DTYPE = np.dtype([("song", "<i4"), ("offset", "<i4"), ("shift", "<i4"), ("n_cand", "<i4"), ("score", "<f8")])
+
+    def results_to_host(self, res_dev):
+        """device results (uint8 [nQ, 24]) -> structured numpy array: the ONE device-to-host copy of a step."""
+        out = np.frombuffer(res_dev.cpu().numpy().tobytes(), dtype=self.RESULT_DTYPE)
+        if (out["song"] == -2).any():
+            raise _l.PfannError("matcher refused a query (candidate buffer sizing error)")
+        return out
+
+    def pack_winner_keys(self, res_dev):
+        """-> int64 [nQ, 2] device tensor of 128-bit keys (bit patterns of two uint64), see pfann_match_pack."""
+        nQ = res_dev.shape[0]
+        keys = torch.empty((nQ, 2), device=self.device, dtype=torch.int64)
+        _l.check(self.lib.pfann_match_pack(self.handle, res_dev.data_ptr(), nQ, keys.data_ptr(), self._stream()), "pfann_match_pack")
+        return keys
+
+    def pick_winner(self, all_keys):
+        """all_keys int64 [G, nQ, 2] (all-gathered) -> structured array of the winners (one D2H)."""
+        all_keys = all_keys.to(self.device).contiguous()
+        G, nQ = all_keys.shape[0], all_keys.shape[1]
+        out = torch.empty((nQ, ctypes.sizeof(_l.MatchResult)), device=self.device, dtype=torch.uint8)
+        _l.check(self.lib.pfann_match_pick(self.handle, all_keys.data_ptr(), G, nQ, out.data_ptr(), self._stream()), "pfann_match_pick")
+        return self.results_to_host(out)
+
+    def match(self, q, labels, qstart, qlen, fsm=1, alpha=0.0, mode=0, only_owned=False, want_song_scores=False,
+              to_host=True):
+        """Sequence matcher for nQ queries.  Returns (results structured array -- or, with to_host=False, the device
+        tensor of results --, song_scores or None)."""
         q = q.to(self.device, torch.float32).contiguous()
         labels = labels.to(self.device, torch.int64).contiguous()
         qs = torch.as_tensor(np.asarray(qstart, dtype=np.int64)).to(self.device)
@@ -115,12 +141,9 @@ class DeviceIndex:
                                           1 if only_owned else 0, res.data_ptr(),
                                           ss.data_ptr() if ss is not None else None, self._stream()),
                      "pfann_match")
-        dt = np.dtype([("song", "<i4"), ("offset", "<i4"), ("shift", "<i4"), ("n_cand", "<i4"),
-                       ("score", "<f8")])
-        out = np.frombuffer(res.cpu().numpy().tobytes(), dtype=dt)
-        if (out["song"] == -2).any():
-            raise _l.PfannError("matcher refused a query (candidate buffer sizing error)")
-        return out, ss
+        if not to_host:
+            return res, ss
+        return self.results_to_host(res), ss
 
 
 def _fine_to_time(fine, fsm, hop_size):

@@ -117,37 +117,12 @@ class ShardedIndex:
         return gD.contiguous(), gI.contiguous()
 
     def query_batch(self, q, qstart, qlen):
-        """-> structured array (song, offset, shift, score) per query, identical on all ranks."""
+        """-> structured array (song, offset, shift, score) per query, identical on all ranks.
+        Everything between the search and the final result stays on the device: the owner-side results are packed
+        into one 128-bit orderable key per query (pfann_match_pack), all-gathered (16 bytes per query and rank) and
+        reduced by pfann_match_pick; the winners come back in the step's single device-to-host copy."""
         D, I = self.search_global(q)
-        res, _ = self.b.match(q, I, qstart, qlen, self.fsm, self.alpha, 0, True, False)
-        nQ = len(qlen)
-        dev = q.device
-        pack_h = np.stack([res["score"], res["song"].astype(np.float64), res["offset"].astype(np.float64),
-                           res["shift"].astype(np.float64)], axis=1)
-        pack = torch.as_tensor(pack_h).to(dev)                       # one small H2D copy
-        allp = all_gather_rows(pack, self.group).cpu().numpy()     # [G, nQ, 4]
-        return pick_best(allp)
-
-
-def pick_best(allp):
-    """allp [G, nQ, 4] = per-rank (score, song, offset, shift), song < 0 = no candidate on that rank.
-    -> structured array of the winner per query: highest score, ties -> the reference's candidate
-    order (shift, song, offset) ascending (database.py:129,140,158-163)."""
-    G, nQ, _ = allp.shape
-    sc, song, off, sh = (allp[..., i].T for i in range(4))       # each [nQ, G]
-    valid = song >= 0
-    key_sc = np.where(valid, -sc, np.inf)
-    big = np.float64(1 << 40)
-    # lexicographic argmin over (−score, shift, song, offset) per query, vectorised
-    order = np.lexsort((np.where(valid, off, big).ravel(), np.where(valid, song, big).ravel(),
-                        np.where(valid, sh, big).ravel(), key_sc.ravel(),
-                        np.repeat(np.arange(nQ), G)))
-    first = order.reshape(nQ, G)[:, 0] - np.arange(nQ) * G          # winning rank per query
-    rows = np.arange(nQ)
-    out = np.zeros(nQ, dtype=[("song", "<i4"), ("offset", "<i4"), ("shift", "<i4"), ("score", "<f8")])
-    ok = valid[rows, first]
-    out["song"] = np.where(ok, song[rows, first], -1).astype(np.int32)
-    out["offset"] = np.where(ok, off[rows, first], 0).astype(np.int32)
-    out["shift"] = np.where(ok, sh[rows, first], 0).astype(np.int32)
-    out["score"] = np.where(ok, sc[rows, first], -np.inf)
-    return out
+        res, _ = self.b.match(q, I, qstart, qlen, self.fsm, self.alpha, 0, True, False, to_host=False)
+        keys = self.b.pack_winner_keys(res)                          # int64 [nQ, 2]
+        allk = all_gather_rows(keys, self.group)                     # [G, nQ, 2]
+        return self.b.pick_winner(allk)

@@ -61,6 +61,8 @@ SYMBOLS = {
                                  c_void_p]),
     "pfann_match": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int,
                             c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "pfann_match_pack": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "pfann_match_pick": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     "pfann_prof_enable": (None, [c_int]),
     "pfann_prof_reset": (None, []),
     "pfann_prof_marker": (None, [c_void_p]),

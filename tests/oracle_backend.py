@@ -40,7 +40,38 @@ class OracleIndex:
             I[r, :len(o)] = L[r][o]
         return torch.from_numpy(D), torch.from_numpy(I)
 
-    def match(self, q, labels, qstart, qlen, fsm=1, alpha=0.0, mode=0, only_owned=False, want_song_scores=False):
+    # ---- winner keys: numpy statement of pfann_match_pack / pfann_match_pick (include/pfann_amd.h) --------------
+    @staticmethod
+    def _ord64(score):
+        u = np.asarray(score, np.float64).view(np.uint64)
+        return np.where(u >> np.uint64(63), ~u, u ^ np.uint64(1 << 63))
+
+    def pack_winner_keys(self, res):
+        hi = ~self._ord64(res["score"] + 0.0)                       # -0.0 -> +0.0
+        lo = (res["shift"].astype(np.uint64) << np.uint64(58)) | (res["song"].astype(np.int64).astype(np.uint64) << np.uint64(28)) | \
+            (res["offset"].astype(np.int64) + (1 << 27)).astype(np.uint64)
+        none = res["song"] < 0
+        hi = np.where(none, ~np.uint64(0), hi)
+        lo = np.where(none, ~np.uint64(0), lo)
+        return torch.from_numpy(np.stack([hi, lo], 1).view(np.int64).copy())
+
+    def pick_winner(self, all_keys):
+        k = all_keys.cpu().numpy().view(np.uint64)                  # [G, nQ, 2]
+        G, nQ = k.shape[0], k.shape[1]
+        out = np.zeros(nQ, dtype=[("song", "<i4"), ("offset", "<i4"), ("shift", "<i4"), ("n_cand", "<i4"), ("score", "<f8")])
+        for j in range(nQ):
+            g = min(range(G), key=lambda r: (int(k[r, j, 0]), int(k[r, j, 1])))
+            hi, lo = int(k[g, j, 0]), int(k[g, j, 1])
+            if hi == (1 << 64) - 1 and lo == (1 << 64) - 1:
+                out[j] = (-1, 0, 0, 0, -np.inf)
+                continue
+            o = ~np.uint64(hi)
+            bits = o ^ np.uint64(1 << 63) if int(o) >> 63 else ~o
+            out[j] = ((lo >> 28) & 0x3FFFFFFF, (lo & 0xFFFFFFF) - (1 << 27), lo >> 58, 0, np.array([bits], np.uint64).view(np.float64)[0])
+        return out
+
+    def match(self, q, labels, qstart, qlen, fsm=1, alpha=0.0, mode=0, only_owned=False, want_song_scores=False,
+              to_host=True):
         """Python-path oracle restricted to owned songs: labels of other shards' songs are
         dropped before candidate generation, local rows are addressed through label_base."""
         q, labels = q.numpy(), labels.numpy()

@@ -697,3 +697,41 @@ def test_search_chunks_large_query_batches(torch_cuda):
     rows = [0, 1, 16383, 16384, 16385, nq - 1]
     Dr, Ir = osr.flat_ip_topk(q[rows], db, 5)
     assert np.array_equal(I[rows], Ir)
+
+
+def test_winner_keys_pack_and_pick_vs_numpy_statement(torch_cuda):
+    """pfann_match_pack / pfann_match_pick (device-side multi-GPU winner selection) against the numpy statement of the
+    same 128-bit key in tests/oracle_backend.py: bit-identical keys, identical winners incl. ties on the score
+    (-> smallest (shift, song, offset)), negative scores, negative offsets and ranks without a candidate."""
+    from oracle_backend import OracleIndex
+    from pfann_amd.database import DeviceIndex
+    idx = DeviceIndex(16, 0)
+    ob = OracleIndex(16)
+    rng = np.random.default_rng(5)
+    G, nQ = 5, 300
+    res = np.zeros((G, nQ), dtype=DeviceIndex.RESULT_DTYPE)
+    res["song"] = rng.integers(-1, 200000, (G, nQ))
+    res["offset"] = rng.integers(-40, 5000, (G, nQ))
+    res["shift"] = rng.integers(0, 4, (G, nQ))
+    res["score"] = rng.standard_normal((G, nQ)) * 0.3
+    res["score"][:, :60] = np.round(res["score"][:, :60], 1)           # many exact score ties across ranks
+    res["score"][1, 100] = -0.0
+    res["score"][2, 100] = 0.0
+    res["song"][:, 7] = -1                                               # nobody has a candidate
+    keys = []
+    for g in range(G):
+        dev = torch_cuda.as_tensor(np.frombuffer(res[g].tobytes(), np.uint8).reshape(nQ, 24).copy()).cuda()
+        kg = idx.pack_winner_keys(dev).cpu()
+        assert np.array_equal(kg.numpy(), ob.pack_winner_keys(res[g]).numpy()), "key bits differ on rank %d" % g
+        keys.append(kg)
+    allk = torch_cuda.stack(keys)
+    got, want = idx.pick_winner(allk.cuda()), ob.pick_winner(allk)
+    for f in ("song", "offset", "shift"):
+        assert np.array_equal(got[f], want[f]), f
+    assert np.array_equal(got["score"], want["score"]) and got["song"][7] == -1 and got["score"][7] == -np.inf
+    # and against the definition: highest score, ties -> smallest (shift, song, offset)
+    for j in range(nQ):
+        c = [(-(res["score"][g, j] + 0.0), res["shift"][g, j], res["song"][g, j], res["offset"][g, j]) for g in range(G) if res["song"][g, j] >= 0]
+        if c:
+            b = min(c)
+            assert (got["shift"][j], got["song"][j], got["offset"][j]) == b[1:], j
