@@ -213,6 +213,24 @@ def test_encoder_large_mean_activations(torch_cuda, fused):
     assert np.abs(eng.encode(xt, norm=True).cpu().numpy() - ref).max() < 1e-4
 
 
+def test_encoder_large_batch_128_tiles_vs_oracle(torch_cuda):
+    """A batch large enough for the 128x128 GEMM tiles (the golden tests run 3 segments, i.e. the 64x64 tiles):
+    embeddings against the CPU oracle for a batch that is not a multiple of anything convenient."""
+    from oracle import encoder as oe
+    from pfann_amd.engine import Engine
+    params = cfg("default")
+    _, _, _, F, T = synth.model_dims(params)
+    sd = synth.make_state_dict(params, seed=123)
+    B = 37
+    x = (synth.normal(78, "t/persist", B * F * T).reshape(B, F, T) * 3.0 - 6.0).astype(np.float32)
+    ref = oe.encode(x, sd, params, norm=True)
+    eng = Engine(params, 0, max_batch=64)
+    eng.load_state_dict(sd)
+    e1 = eng.encode(torch_cuda.as_tensor(x).cuda(), norm=True).cpu().numpy()
+    print("128-tile kernels vs oracle %.3e" % np.abs(e1 - ref).max())
+    assert np.abs(e1 - ref).max() < 1e-4
+
+
 def test_encoder_split_precision_matches_fp32(torch_cuda):
     """Opt-in encoder arithmetic (pfann_set_encoder_precision = 1): conv products as three fp16 MFMA
     terms of two-term operand splits, fp32 accumulation.  Must stay fp32-grade: embeddings within 2e-5
