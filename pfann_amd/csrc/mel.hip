@@ -8,6 +8,8 @@
 // radix-2 FFT in LDS (SoA re/im, host-computed twiddles staged in LDS), the power spectrum
 // goes through the 0.7 %-dense mel bank as a CSR gather-MAC (never a dense GEMM), and the
 // [n_mels][n_frames] tile is assembled in LDS so the store to HBM is one coalesced stream.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace pfann {
@@ -22,7 +24,8 @@ struct MelArgs {
     const float *window; const float2 *twiddle;
     const int *fb_ptr, *fb_idx; const float *fb_val;
     int fb_nnz;
-    int group_out;           // 1: stream each group of 4 frames out through a small LDS tile (3 workgroups / CU)
+    int group_out;           // 0: whole [n_mels][n_frames] tile in LDS; else frames per output group (4, 8 or 16): the
+                             // group leaves through a small LDS tile as group_out*4-byte row pieces (3 workgroups / CU)
 };
 
 __device__ __forceinline__ unsigned bitrev(unsigned x, int bits) { return __brev(x) >> (32 - bits); }
@@ -63,8 +66,9 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs a) {
     const int WSZ = 2 * M > 1152 ? 2 * M : 1152;
     float *work = tw_im + M;              // [4][WSZ]  per-wave FFT buffer (re[M], im[M]; radix-8 path: 576 float2)
     float *pw = work + 4 * WSZ;           // [4][M+4]  power spectrum per wave
-    float *tile = pw + 4 * (M + 4);       // [n_mels][n_frames+1], or [n_mels][5] when group_out
-    float *red = tile + a.n_mels * (a.group_out ? 5 : a.n_frames + 1);  // [8]
+    float *tile = pw + 4 * (M + 4);       // [n_mels][n_frames+1], or [n_mels][group_out+1]
+    const int tp = a.group_out ? a.group_out + 1 : a.n_frames + 1;       // tile row pitch
+    float *red = tile + a.n_mels * tp;    // [8]
     int *s_ptr = reinterpret_cast<int *>(red + 8);    // mel bank CSR, resident in LDS: [n_mels+1], [nnz], [nnz]
     int *s_idx = s_ptr + a.n_mels + 1;
     float *s_val = reinterpret_cast<float *>(s_idx + a.fb_nnz);
@@ -278,18 +282,22 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs a) {
                 acc += a.log_eps;
                 if (a.log_mode == 1) acc = logf(acc);
                 else if (a.log_mode == 2) acc = log10f(acc);
-                if (a.group_out) tile[m * 5 + wave] = acc;
-                else tile[m * (a.n_frames + 1) + t] = acc;
+                if (a.group_out) tile[m * tp + (t % a.group_out)] = acc;
+                else tile[m * tp + t] = acc;
             }
         }
         wave_sync();
-        if (a.group_out) {
-            // frames 4g .. 4g+3 of every mel row: 16 contiguous bytes of the [n_mels][n_frames] output
+        if (a.group_out && ((4 * g + 4) % a.group_out == 0)) {
+            // a finished group of frames: group_out*4 contiguous bytes of every mel row of the [n_mels][n_frames]
+            // output (16-byte pieces made HBM write traffic 4.1x the tensor: partial 64-byte requests)
             __syncthreads();
-            float *o4 = a.out + (int64_t)blockIdx.x * a.n_mels * a.n_frames + 4 * g;
-            for (int m = tid; m < a.n_mels; m += 256)
-                *reinterpret_cast<float4 *>(o4 + (int64_t)m * a.n_frames) =
-                    make_float4(tile[m * 5], tile[m * 5 + 1], tile[m * 5 + 2], tile[m * 5 + 3]);
+            const int q4 = a.group_out >> 2;                          // float4 pieces per row
+            float *og = a.out + (int64_t)blockIdx.x * a.n_mels * a.n_frames + (4 * g + 4 - a.group_out);
+            for (int i = tid; i < a.n_mels * q4; i += 256) {
+                const int m = i / q4, c = i - m * q4;
+                const float *tr = tile + m * tp + 4 * c;
+                *reinterpret_cast<float4 *>(og + (int64_t)m * a.n_frames + 4 * c) = make_float4(tr[0], tr[1], tr[2], tr[3]);
+            }
             __syncthreads();
         }
     }
@@ -328,18 +336,22 @@ int launch_melspec(const MelPlan &mp, const float *segs, int64_t B, int64_t seg_
     a.spec_norm_max = mp.spec_norm_max; a.remove_mean = remove_mean; a.log_eps = mp.log_eps;
     a.window = mp.window; a.twiddle = mp.twiddle;
     a.fb_ptr = mp.fb_ptr; a.fb_idx = mp.fb_idx; a.fb_val = mp.fb_val; a.fb_nnz = mp.fb_nnz;
-    a.group_out = (!mp.spec_norm_max && mp.n_frames % 4 == 0) ? 1 : 0;
     const int M = mp.n_fft / 2;
     const int WSZ = 2 * M > 1152 ? 2 * M : 1152;
-    const size_t lds = sizeof(float) * (size_t)(2 * M + 4 * WSZ + 4 * (M + 4) + mp.n_mels * (a.group_out ? 5 : mp.n_frames + 1) + 8 +
-                                               mp.n_mels + 1 + 2 * (size_t)mp.fb_nnz);
-    if (lds > 160 * 1024) { set_error("melspec: LDS need %zu B > 160 KiB", lds); return -1; }
-    static bool attr_set = false;
-    if (!attr_set) {
-        PF_HIP(hipFuncSetAttribute((const void *)melspec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   160 * 1024));
-        attr_set = true;
+    auto lds_for = [&](int gf) {
+        return sizeof(float) * (size_t)(2 * M + 4 * WSZ + 4 * (M + 4) + mp.n_mels * (gf ? gf + 1 : mp.n_frames + 1) + 8 +
+                                        mp.n_mels + 1 + 2 * (size_t)mp.fb_nnz);
+    };
+    // widest output group (16, 8 or 4 frames = 64 / 32 / 16-byte row pieces) that still leaves three workgroups per CU
+    a.group_out = 0;
+    if (!mp.spec_norm_max) {
+        for (int gf : {16, 8, 4})
+            if (mp.n_frames % gf == 0 && (a.group_out == 0 ? (3 * lds_for(gf) <= 160 * 1024 || gf == 4) : false)) a.group_out = gf;
     }
+    if (getenv("PFANN_MEL_GROUP")) a.group_out = atoi(getenv("PFANN_MEL_GROUP"));
+    const size_t lds = lds_for(a.group_out);
+    if (lds > 160 * 1024) { set_error("melspec: LDS need %zu B > 160 KiB", lds); return -1; }
+    if (ensure_dyn_lds((const void *)melspec_kernel, 160 * 1024)) return -1;
     ProfScope ps("melspec", s);
     PF_LAUNCH(melspec_kernel, dim3((unsigned)B), dim3(256), lds, s, a);
     PF_HIP(hipGetLastError());
