@@ -21,7 +21,7 @@ from .musicdata import MusicDataset
 from .utils import StageTimer, init_logger, read_config
 
 
-def embed_files(engine, dataset, hop, batch_windows=2048, timer=None, norm=True):
+def embed_files(engine, dataset, hop, batch_windows=4096, timer=None, norm=True):
     """Yields (index, n_seg, embeddings cuda tensor [n_seg, d]) in list order; a file that
     fails to load yields n_seg = 0 (the reference's 0-segment-song convention,
     builder.py:82-86)."""
@@ -90,7 +90,7 @@ def main(argv=None):
     init_logger("builder")                                                 # builder.py:27-28
 
     print("loading model...")
-    engine = Engine(params, 0, max_batch=int(os.environ.get("PFANN_MAX_BATCH", "1024")))
+    engine = Engine(params, 0, max_batch=int(os.environ.get("PFANN_MAX_BATCH", "4096")))
     model_pt = os.path.join(params["model_dir"], "model.pt")
     engine.load_state_dict(torch.load(model_pt, map_location="cpu"))
     print("model loaded")

@@ -25,7 +25,7 @@ def main(argv=None):
     configs = os.path.join(dir_for_db, "configs.json")
     params = read_config(configs)
     print("loading model...")
-    engine = Engine(params, 0, max_batch=int(os.environ.get("PFANN_MAX_BATCH", "1024")))
+    engine = Engine(params, 0, max_batch=int(os.environ.get("PFANN_MAX_BATCH", "4096")))
     engine.load_state_dict(torch.load(os.path.join(dir_for_db, "model.pt"), map_location="cpu"))
     print("model loaded")
     dataset = MusicDataset(file_list_for_query, params)
