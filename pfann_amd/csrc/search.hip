@@ -14,6 +14,7 @@
 //     LDS is exact;
 //   * a list overflow on the final level (pathological ties / duplicates) raises tau from
 //     the captured survivors and rescans; it never degrades to an approximate answer.
+#include <stdlib.h>
 #include <algorithm>
 #include <utility>
 #include <vector>
@@ -393,8 +394,12 @@ __global__ __launch_bounds__(256, 2) void scan_small_kernel(ScanParams p) {
 
 // k-th largest of the G group maxima of every query row (MSB radix select, 4 x 8 bits, LDS histogram) ->
 // thr[m]; also zeroes the row's survivor counters for the pass that follows.
+// eps != nullptr (fp16 pre-filter): the maxima are approximate scores; thr_adj[m] = tau - margin * eps[m] (floored at
+// -1000 eps: finite, below every possible score), margin = 2 with exact re-scoring downstream, 0 when the s16 scores are final.
 __global__ __launch_bounds__(256) void group_max_select_kernel(const float *__restrict__ gmax, int G, int k,
-                                                               float *__restrict__ thr, int *__restrict__ cnt, int ncnt) {
+                                                               float *__restrict__ thr, int *__restrict__ cnt, int ncnt,
+                                                               const float *__restrict__ eps, float *__restrict__ thr_adj,
+                                                               float margin) {
     constexpr int GMAX = 4096;
     __shared__ unsigned sv[GMAX];
     __shared__ int hist[256];
@@ -404,7 +409,10 @@ __global__ __launch_bounds__(256) void group_max_select_kernel(const float *__re
     for (int i = tid; i < ncnt; i += 256) cnt[m * ncnt + i] = 0;
     for (int i = tid; i < G; i += 256) sv[i] = ~f2ord(gmax[m * G + i]);          // ascending = descending score
     __syncthreads();
-    if (G < k) { if (tid == 0) thr[m] = -INFINITY; return; }
+    if (G < k) {
+        if (tid == 0) { thr[m] = -INFINITY; if (eps != nullptr) thr_adj[m] = -1000.f * eps[m]; }
+        return;
+    }
     unsigned prefix = 0;
     int kk = k;
     for (int pass = 0; pass < 4; ++pass) {
@@ -437,7 +445,19 @@ __global__ __launch_bounds__(256) void group_max_select_kernel(const float *__re
         prefix |= (unsigned)s_bin << shift;
         kk = s_kk;
     }
-    if (tid == 0) thr[m] = ord2f(~prefix);
+    if (tid == 0) {
+        const float t = ord2f(~prefix);
+        thr[m] = t;
+        if (eps != nullptr) thr_adj[m] = fmaxf(t - margin * eps[m], -1000.f * eps[m]);
+    }
+}
+
+int launch_group_max_select(SearchWorkspace &ws, int64_t nq, int G, int k, int ncnt, bool with_eps, float margin, hipStream_t s) {
+    ProfScope ps("topk_group_select", s);
+    PF_LAUNCH(group_max_select_kernel, dim3((unsigned)nq), dim3(256), 0, s, reinterpret_cast<const float *>(ws.cl), G, k, ws.thr,
+              ws.cnt, ncnt, with_eps ? ws.eps : nullptr, ws.thr_adj, margin);
+    PF_HIP(hipGetLastError());
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------
@@ -717,11 +737,7 @@ static int search_small(const void *rows, int64_t n, int d, const void *qrows, i
         ProfScope ps("scan_topk_sample", s, p.nrows * bytes_per_row);
         PF_SMALL(1, GRID);
     }
-    {
-        ProfScope ps("topk_group_select", s);
-        PF_LAUNCH(group_max_select_kernel, dim3((unsigned)nq), dim3(256), 0, s, p.gmax, W, k, ws.thr, ws.cnt, 32);
-        PF_HIP(hipGetLastError());
-    }
+    if (launch_group_max_select(ws, nq, W, k, 32, false, 0.f, s)) return -1;
     p.row_stride = 1; p.nrows = n; p.nsub = 32; p.thr = ws.thr; p.gmax = nullptr;
     {
         ProfScope ps("scan_topk", s, n * bytes_per_row);
@@ -777,6 +793,19 @@ int search_topk(const float *db, const void *dbh, float xnorm_max, int64_t n, in
         // ---- fp16 MFMA scan (search_f16.hip).  fp32 storage: pre-filter with a rigorous margin + exact fp32
         // re-scoring (same exact result); fp16-only storage: eps = 0, the s16 scores are the result
         const int rescore = half_only ? 0 : 1;
+        {
+            // one group-maximum pass over every 4th row instead of the dense + 1/16 survivor levels
+            int G = 0;
+            const int rc = (k <= 128 && getenv("PFANN_NO_GMAX") == nullptr) ? launch_scan_f16_gmax(dbh, n, d, 4, ws.qh, nq, k, ws, &G, s) : 1;
+            if (rc < 0) return -1;
+            if (rc == 0) {
+                if (launch_group_max_select(ws, nq, G, k, 0, true, rescore ? 2.f : 0.f, s)) return -1;
+                int nsub = 1;
+                if (launch_scan_f16(dbh, n, d, 1, ws.qh, nq, ws.thr_adj, ws, true, &nsub, s)) return -1;
+                if (launch_select_rescore(ws, nq, k, 1, D, I, label_base, q, db, d, nsub, rescore, s)) return -1;
+                return launch_topk_fallback(ws, q, db, dbh, n, d, nq, k, D, I, label_base, s);
+            }
+        }
         const float *ta = nullptr;
         for (int lev = levels; lev >= 1; --lev) {
             int nsub = 1;

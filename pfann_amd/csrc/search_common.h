@@ -56,6 +56,8 @@ __device__ inline void bitonic_sort_u64(unsigned long long *s, int P, int tid, i
 // ---- fp16 pre-filter path (search_f16.hip) ------------------------------------------------
 int launch_rows_to_half(const float *x, int64_t n, int d, void *xh, float *norm_max_dev, hipStream_t s);
 int launch_q_prep(const float *q, int64_t nq, int d, float xnorm_max, void *qh, float *eps, int *row_ovf, hipStream_t s);
+int launch_scan_f16_gmax(const void *dbh, int64_t n, int d, int64_t stride, const void *qh, int64_t nq, int k,
+                         SearchWorkspace &ws, int *n_groups_out, hipStream_t s);
 int launch_scan_f16(const void *dbh, int64_t n, int d, int64_t stride, const void *qh, int64_t nq,
                     const float *thr_adj, SearchWorkspace &ws, bool allow_sublists, int *nsub_out, hipStream_t s);
 // rescore = 1: survivors within 2 eps of the k-th best approximate score are re-scored in exact fp32 from db32;

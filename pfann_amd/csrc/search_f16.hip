@@ -263,8 +263,15 @@ __global__ __launch_bounds__(256, 2) void scan_f16_kernel(ScanParams p) {
 //     15 million device-scope atomics of a db-stationary split cost 5 ms per pass on MI355X
 //     (measured) and are gone.  The select kernels gather the S sub-lists of a row.
 // ------------------------------------------------------------------------------------
-template <int KS>
+// GMAX = true (sampled pass, no thresholds): no survivor lists at all -- every wave keeps the running maximum of its
+// 64 query rows over GCH consecutive db tiles of its slice and writes one value per (query row, group); the k-th
+// best of a row's group maxima is the score of a real row, hence (minus the rounding margin) a lower bound of its
+// k-th best overall.  One such pass over every 4th row + a radix select of the group maxima replace the dense and
+// 1/16 levels with their two survivor selects, and hand the full pass a threshold of rank ~4k instead of ~16k: a
+// 32x32 block then holds a survivor with probability 0.34 instead of 0.8 (the survivor path was half of the pass).
+template <int KS, bool GMAX = false>
 __global__ __launch_bounds__(256, 2) void scan_f16_qres_kernel(ScanParams p) {
+    constexpr int GCH = 5;                        // db tiles per group (GMAX)
     constexpr int BM = 128, WM = 64, WN = 64, TM = 2, TN = 2;
     constexpr int ROWB = KS * 32;                 // bytes of one fp16 row
     constexpr int CPR = ROWB / 16;                // 16-byte chunks per row
@@ -296,14 +303,19 @@ __global__ __launch_bounds__(256, 2) void scan_f16_qres_kernel(ScanParams p) {
         for (int kk = 0; kk < KS; ++kk)
             afr[i][kk] = __builtin_bit_cast(f16x8, buf_load4(srd_q, (unsigned)(wm * WM + i * 32 + l31) * ROWB + kk * 32 + lhalf * 16));
     // C operand: -(tau - eps) of C rows wm*64 + i*32 + 8g + 4*lhalf + e (register 4g + e); rows past nq: -inf
-    f32x16 cinit[TM];
+    f32x16 cinit[TM], gmx[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int64_t m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-            cinit[i][r] = m < p.nq ? -p.thr[m] : -INFINITY;
+            cinit[i][r] = GMAX ? 0.f : (m < p.nq ? -p.thr[m] : -INFINITY);
+            gmx[i][r] = -INFINITY;
         }
+    const int n_grp = GMAX ? (int)((((t_hi - t_lo + S - 1) / S) + GCH - 1) / GCH) : 0;   // groups of this workgroup's slice
+    const int g_per = GMAX ? (int)((((t_hi + S - 1) / S) + GCH - 1) / GCH) : 0;          // groups per slice (upper bound)
+    int n_in_grp = 0, grp = 0;
+    (void)n_grp;
 
     // ---- db-tile staging straight into LDS (global_load_lds_dwordx4: no staging registers, no
     // ds_write pass).  The LDS image is lane-linear (wave-uniform base + lane*16), so rows cannot be
@@ -367,6 +379,32 @@ __global__ __launch_bounds__(256, 2) void scan_f16_qres_kernel(ScanParams p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[i][kk], b8[j], kk == 0 ? cinit[i] : acc[i][j], 0, 0, 0);
         }
+        if (GMAX) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const bool nok = t * 128 + wn * WN + j * 32 + l31 < p.nrows;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) gmx[i][r] = fmaxf(gmx[i][r], nok ? acc[i][j][r] : -INFINITY);
+            }
+            if (++n_in_grp == GCH || t + S >= t_hi) {             // close the group: maximum over the 32 lanes of a half
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = gmx[i][r];
+#pragma unroll
+                        for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+                        const int64_t m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                        if (l31 == 0 && m < p.nq)
+                            p.gmax[m * ((int64_t)S * g_per * 2) + ((int64_t)seg * g_per + grp) * 2 + wn] = v;
+                        gmx[i][r] = -INFINITY;
+                    }
+                n_in_grp = 0;
+                ++grp;
+            }
+        } else
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int64_t n = t * 128 + wn * WN + j * 32 + l31;
@@ -401,7 +439,48 @@ __global__ __launch_bounds__(256, 2) void scan_f16_qres_kernel(ScanParams p) {
         }
         __syncthreads();                 // (waits for the tile in flight: vmcnt(0) precedes the barrier)
     }
+    if (GMAX) {       // groups this slice did not reach (shorter slices): never the k-th best
+        for (int gq = grp; gq < g_per; ++gq)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                    if (l31 == 0 && m < p.nq) p.gmax[m * ((int64_t)S * g_per * 2) + ((int64_t)seg * g_per + gq) * 2 + wn] = -INFINITY;
+                }
+        return;
+    }
     if (tid < BM && m0 + tid < p.nq) p.cnt[(m0 + tid) * S + seg] = s_cnt[tid];
+}
+
+// Sampled group-maximum pass (every `stride`-th row): fills gmax[nq][*n_groups_out] for group_max_select.
+// Returns 1 (not applicable: use the survivor ladder) when the shapes do not give >= 4 k groups per row.
+int launch_scan_f16_gmax(const void *dbh, int64_t n, int d, int64_t stride, const void *qh, int64_t nq, int k,
+                         SearchWorkspace &ws, int *n_groups_out, hipStream_t s) {
+    ScanParams p;
+    p.q = reinterpret_cast<const float *>(qh);
+    p.db = reinterpret_cast<const float *>(dbh);
+    p.nq = nq; p.d = d; p.row_stride = stride;
+    p.nrows = (n + stride - 1) / stride;
+    p.thr = nullptr; p.cnt = ws.cnt; p.keys = nullptr;
+    p.n_tiles_m = cdiv(nq, 128);
+    const int64_t db_tiles = cdiv(p.nrows, 128);
+    if (!(d == 128 || d == 64) || nq < 1024 || db_tiles < 16) return 1;
+    int S = (int)(2048 / p.n_tiles_m);
+    S = S < 1 ? 1 : (S > 32 ? 32 : S);
+    if (S > db_tiles) S = (int)db_tiles;
+    const int g_per = (int)(((db_tiles + S - 1) / S + 4) / 5);
+    const int G = S * g_per * 2;
+    if (G < 4 * k || G > 4096) return 1;
+    p.nsub = S;
+    p.gmax = reinterpret_cast<float *>(ws.cl);
+    ProfScope ps("scan_topk_f16_sample", s, 2.0 * (double)nq * p.nrows * d);
+    const dim3 grid((unsigned)(p.n_tiles_m * S));
+    if (d == 128) PF_LAUNCH((scan_f16_qres_kernel<8, true>), grid, dim3(256), 0, s, p);
+    else PF_LAUNCH((scan_f16_qres_kernel<4, true>), grid, dim3(256), 0, s, p);
+    PF_HIP(hipGetLastError());
+    *n_groups_out = G;
+    return 0;
 }
 
 __global__ void fill_int2_kernel(int *p, int v, int64_t n) {
