@@ -227,3 +227,60 @@ def test_accuracy_tool_prints_what_the_reference_prints(tmp_path, case):
                        capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stderr
     assert r.stdout == want
+
+
+def test_stage_log_lines_parse_like_the_reference_stat_tool(tmp_path, monkeypatch):
+    """utils.init_logger + StageTimer write one '<stage> <seconds>s' record per measurement in the reference's log
+    format (simpleutils.py:72-85); the aggregation of the reference's tools/stat.py:17 (regex task + ' (\\d+\\.\\d+)s'
+    per known stage name) must recover the per-stage totals, with search and rerank separate."""
+    import logging
+    from pfann_amd import utils
+    monkeypatch.chdir(tmp_path)
+    path = utils.init_logger("matcher")
+    try:
+        t = utils.StageTimer()
+        for name, dt in [("load", 0.25), ("stereo to mono", 0.125), ("compute embedding", 1.5), ("search", 0.75),
+                         ("rerank", 0.5), ("search", 0.25), ("output answer", 0.0625)]:
+            t.add(name, dt)
+        utils.get_logger().info("total query time %.6fs", 3.5)
+    finally:
+        for h in list(utils.get_logger().handlers):
+            h.close()
+            utils.get_logger().removeHandler(h)
+    totals = {}
+    for line in open(path, encoding="utf8"):
+        body = line[line.rfind("] ") + 2:] if "] " in line else line
+        for task in ["load", "resample", "stereo to mono", "compute embedding", "search", "rerank", "output answer",
+                     "total query time"]:
+            m = re.search(task + r" (\d+\.\d+)s", body)
+            if m:
+                totals[task] = totals.get(task, 0.0) + float(m.group(1))
+    assert totals == {"load": 0.25, "stereo to mono": 0.125, "compute embedding": 1.5, "search": 1.0, "rerank": 0.5,
+                      "output answer": 0.0625, "total query time": 3.5}
+    assert t.t["search"] == 1.0
+
+
+def test_torch_synth_generators_are_pure_functions_of_ids():
+    """Large-scale test/bench inputs (pfann_amd.synth.make_songs_torch / make_queries_torch): int16, peak-normalised,
+    a song depends on its id only (any batch composition), queries are crops at the reported offset plus noise at the
+    requested SNR; the calibrated state_dict differs from the seeded one in g.linear2.bias only."""
+    import torch
+    a = synth.make_songs_torch([5, 9, 11], seconds=3.0)
+    b = synth.make_songs_torch([11, 5], seconds=3.0)
+    assert a.dtype == torch.int16 and a.shape == (3, 24000)
+    assert torch.equal(a[0], b[1]) and torch.equal(a[2], b[0]) and not torch.equal(a[0], a[1])
+    assert int(a.abs().max()) == 32000
+    q, off = synth.make_queries_torch(a, [0, 1, 2], seconds=1.0, snr_db=30.0)
+    assert q.shape == (3, 8000) and (off >= 0).all() and (off <= 2.0).all()
+    for j in range(3):                                   # at 30 dB the crop is recognisable at the reported offset
+        o = int(round(float(off[j]) * 8000))
+        x = a[j, o:o + 8000].float()
+        c = torch.dot(x, q[j].float()) / (x.norm() * q[j].float().norm())
+        assert c > 0.99
+    q0, _ = synth.make_queries_torch(a, [0, 1, 2], seconds=1.0, snr_db=0.0)
+    n0 = (q0[0].float() / q0[0].float().norm() - q[0].float() / q[0].float().norm()).norm()
+    assert 0.5 < n0 < 1.0                                # SNR 0: noise as strong as the signal
+    params = json.load(open(os.path.join(REPO, "configs", "default.json")))
+    s0, s1 = synth.make_state_dict(params, 123), synth.make_state_dict_calibrated(params, 123)
+    diff = [k for k in s0 if not np.array_equal(s0[k], s1[k])]
+    assert diff == ["g.linear2.bias"]
