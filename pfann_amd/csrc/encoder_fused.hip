@@ -21,6 +21,7 @@
 #include "kernels.h"
 #include <set>
 #include <string>
+#include <type_traits>
 
 namespace pfann {
 
@@ -198,13 +199,14 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
     };
 
     struct Stage {                       // one K-tile of prefetched operands, in registers
-        f32x4 ra[AR], rw[AR], rbb[AR], rb[BR];   // FIRST: ra[i][0..2] = the three log-mel taps
+        f32x4 ra[2][AR], rw[AR], rbb[AR], rb[BR];   // FIRST: ra[0][i][0..2] = the three log-mel taps; EA: two sets,
+                                                  // tile t's activations in ra[t & 1] (two K-tiles of prefetch)
                                                   // SPLIT: rb[j] = (hi k0..3 as 2 dwords, lo k0..3 as 2 dwords)
         int cc;                                   // channel of element 0 (first-conv weights come from LDS)
     };
-    auto load_A = [&](Stage &S) {        // EA only
+    auto load_A = [&](Stage &S, int par) {        // EA only; par is a compile-time constant at every call site
 #pragma unroll
-        for (int i = 0; i < AR; ++i) S.ra[i] = buf_load4(srd_a, va[i][0], cA * 4);
+        for (int i = 0; i < AR; ++i) S.ra[par][i] = buf_load4(srd_a, va[i][0], cA * 4);
         cA += BK;
         if (cA >= p.Ci) {                // uniform branch: next filter tap
             cA = 0;
@@ -229,10 +231,10 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
                 // are fetched on the first K-tile of each filter tap only and stay in S.ra for the others
                 if (!UNI || c == 0 || kap == p.k_begin) {
 #pragma unroll
-                    for (int t1 = 0; t1 < NA; ++t1) S.ra[i][t1] = buf_load1(srd_a, va[i][t1]);
+                    for (int t1 = 0; t1 < NA; ++t1) S.ra[0][i][t1] = buf_load1(srd_a, va[i][t1]);
                 }
             } else if (!EA) {
-                S.ra[i] = buf_load4(srd_a, va[i][0], so_c);
+                S.ra[0][i] = buf_load4(srd_a, va[i][0], so_c);
             }
             S.rw[i] = buf_load4(srd_w, vr[i], so_c);
             S.rbb[i] = buf_load4(srd_lb, vr[i], so_c);
@@ -265,7 +267,7 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
     // input (conv padding, m >= M, k >= k_end) need no select: their offsets were out of range, so
     // W = B = 0 arrive from the buffer unit and (z - mean) * rstd * 0 + 0 = +-0, which every
     // activation maps to 0.
-    auto store_tile = [&](const Stage &S, float *Ad, float *Bd) {
+    auto store_tile = [&](const Stage &S, float *Ad, float *Bd, int par) {
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             const f32x2 mu2 = {amu[i], amu[i]}, rs2 = {ars[i], ars[i]};
@@ -277,12 +279,12 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
             }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                f32x2 z = {S.ra[i][2 * h], S.ra[i][2 * h + 1]};
+                f32x2 z = {S.ra[par][i][2 * h], S.ra[par][i][2 * h + 1]};
                 if (FIRST) {   // same FMA order as conv_first_stats_kernel: bias, then taps 0, 1, 2
                     z = f32x2{b1v[2 * h], b1v[2 * h + 1]};
 #pragma unroll
                     for (int t1 = 0; t1 < 3; ++t1)
-                        z = __builtin_elementwise_fma(f32x2{S.ra[i][t1], S.ra[i][t1]},
+                        z = __builtin_elementwise_fma(f32x2{S.ra[0][i][t1], S.ra[0][i][t1]},
                                                       f32x2{w1v[t1][2 * h], w1v[t1][2 * h + 1]}, z);
                     if (!RELU_BN && !p.after_bn) { z[0] = act_fn(z[0], p.act); z[1] = act_fn(z[1], p.act); }   // PRE of sub-layer 0
                 }
@@ -337,11 +339,55 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
     const int nk = (p.k_end - p.k_begin + BK - 1) / BK;
     const int l31 = lane & 31, lhalf = lane >> 5;
     Stage S;
-    if (EA) { set_offsets_A(tapA); load_A(S); }
+    if (EA) { set_offsets_A(tapA); load_A(S, 0); }
     load_tile(S);
-    store_tile(S, As, Bs);
-    if (EA && nk > 1) load_A(S);
+    store_tile(S, As, Bs, 0);
+    if (EA && nk > 1) load_A(S, 1);
+    if (EA && nk > 2) load_A(S, 0);
     __syncthreads();
+    // EA: the K loop is unrolled by two so that the register set holding tile kt+1's activations (kt+1 & 1) is a
+    // compile-time choice; the activations of tile kt+3 are requested as soon as tile kt+1's have gone to LDS
+    auto ea_ktile = [&](int kt, auto parc) {
+        constexpr int PB = decltype(parc)::value;
+        const float *Ac = As + PB * (BM * LDK), *Bc = Bs + PB * (BN * LDK);
+        float *An = As + (PB ^ 1) * (BM * LDK), *Bn = Bs + (PB ^ 1) * (BN * LDK);
+        const bool more = kt + 1 < nk;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            f32x4 a4[TM], b4[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a4[i] = *reinterpret_cast<const f32x4 *>(&Ac[(wm * WM + i * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b4[j] = *reinterpret_cast<const f32x4 *>(&Bc[(wn * WN + j * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
+            if (kk == 0) {
+                if (more) load_tile(S);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (kk == BK / 8 - 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) store_tile(S, An, Bn, PB ^ 1);
+                if (kt + 3 < nk) load_A(S, PB ^ 1);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[j][s], a4[i][s], acc[i][j], 0, 0, 0);   // C^T: rows = n
+        }
+        __syncthreads();
+    };
+    if constexpr (EA) {
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            ea_ktile(kt, std::integral_constant<int, 0>{});
+            ea_ktile(kt + 1, std::integral_constant<int, 1>{});
+        }
+        if (kt < nk) ea_ktile(kt, std::integral_constant<int, 0>{});
+    } else
     for (int kt = 0; kt < nk; ++kt) {
         // MFMAs on LDS buffer kt&1 while tile kt+1 goes global -> registers -> buffer (kt+1)&1
         const float *Ac = As + (kt & 1) * (BM * LDK), *Bc = Bs + (kt & 1) * (BN * LDK);
@@ -371,7 +417,7 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
                 }
                 if (ks == BK / 16 - 1) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (more) store_tile(S, An, Bn);
+                    if (more) store_tile(S, An, Bn, 0);
                 }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -404,8 +450,7 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
                 }
                 if (kk == BK / 8 - 1) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (more) store_tile(S, An, Bn);
-                    if (EA && kt + 2 < nk) load_A(S);
+                    if (more) store_tile(S, An, Bn, 0);
                 }
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
@@ -433,6 +478,18 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
     // the sums) and an out-of-range store offset; rows m >= M lie beyond srd_y and form whole statistics
     // groups (M is a multiple of G) that are never written out.
     const unsigned rowbytes = (unsigned)p.N * 4u;
+    // ALL bias chunks first, then nothing but math and stores.  gfx950 counts loads and stores in ONE in-order counter
+    // (vmcnt): with a bias load issued after every store, each "wait for the bias" also waited for the previous store
+    // to be acknowledged by memory -- eight serialised store round trips per wave made the epilogue 25 k cycles
+    // (in-kernel timestamps), as long as four K-tiles.
+    f32x4 bias4[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = n0 + wn * WN + j * 32 + 8 * g + 4 * lhalf;
+            bias4[j][g] = buf_load4(srd_bias, n < p.N ? (unsigned)n * 4u : BUF_OOB);
+        }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         float a1 = 0.f, a2 = 0.f;        // this lane's row m = wm*WM + i*32 + l31
@@ -443,7 +500,7 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
             for (int g = 0; g < 4; ++g) {
                 const int n = n0 + wn * WN + j * 32 + 8 * g + 4 * lhalf;
                 const unsigned nb = n < p.N ? (unsigned)n * 4u : BUF_OOB;
-                const f32x4 b4v = buf_load4(srd_bias, nb);
+                const f32x4 b4v = bias4[j][g];
                 f32x4 z4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
