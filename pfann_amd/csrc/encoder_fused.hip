@@ -586,7 +586,7 @@ static int gemm_tile(const SubLayer &L, int64_t B) {
 
 int fused_out_slots(const SubLayer &L, int64_t B) {
     const int rps = L.Fo * L.To;
-    if (L.ci == 1) return rps / 64 > 0 ? rps / 64 : 1;       // conv_first_stats: 64 rows per block
+    if (L.ci == 1 || L.depthwise) return rps / 64 > 0 ? rps / 64 : 1;       // conv_first_stats / conv_dw_ln: 64 rows per block
     const int bt = gemm_tile(L, B);
     return (rps >= bt ? rps / bt : 1) * cdiv(L.co, bt);
 }
@@ -595,8 +595,8 @@ bool fused_supported(const SubLayer *sub, int n) {
     for (int i = 0; i < n; ++i) {
         const SubLayer &L = sub[i];
         const int rps = L.Fo * L.To;
-        if (L.depthwise) return false;
         if (rps & (rps - 1)) return false;                  // power of two: tiles never straddle samples unevenly
+        if (L.depthwise) { if (L.co % 4 || L.axis != 1) return false; continue; }     // conv_dw_ln_kernel
         if (L.ci == 1) { if (i != 0 || rps % 64 || L.co % 4) return false; }
         else if (L.ci % 4 || L.co % 4) return false;
     }
@@ -811,6 +811,86 @@ int launch_conv_first_gram_stats(const SubLayer &L, const float *x, float *part,
     ProfScope ps("conv_first_gram_stats", s, 4.0 * (double)B * L.F * L.T);
     PF_LAUNCH(conv_first_gram_stats_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, s, x, part, M, L.To, L.T,
               L.stride, L.pad_lo, rps, fused_out_slots(L, B), g);
+    PF_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// Depthwise 3x1 conv along F (conv2 of non-"fuller" models: configs/seg.json, n640d64.json) in the fused scheme:
+// LayerNorm(+activation) of its INPUT applied on load -- v = POST((z - mean) * rstd * W + B) -- and the partial
+// LayerNorm statistics of its OUTPUT produced by the same pass, so a depthwise model's activations are written once
+// (raw) and read once, as in the full-conv models (the separate LayerNorm kernel made three more passes over every
+// tensor: 46 % of the n640d64 encoder).  HBM-bound elementwise work: one workgroup = up to 64 output rows of ONE sample
+// x all channels, float4 along C; statistics reduced in a fixed order.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_dw_ln_kernel(const float *__restrict__ x, const float *__restrict__ in_stats,
+                                                         const float *__restrict__ lw, const float *__restrict__ lb,
+                                                         const float *__restrict__ w, const float *__restrict__ bias,
+                                                         float *__restrict__ y, float *__restrict__ part, int C, int To,
+                                                         int F, int T, int stride, int pad_lo, int rps, int P, int act,
+                                                         int after_bn) {
+    __shared__ float red[8];
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x / P;
+    const int slot = (int)(blockIdx.x - b * P);
+    const int rows = rps < 64 ? rps : 64;
+    const int r0 = slot * rows;
+    const int c4n = C >> 2;
+    const float mean = in_stats[2 * b], rstd = in_stats[2 * b + 1];
+    const float *xs = x + b * (int64_t)F * T * C;
+    float *ys = y + (b * rps + r0) * (int64_t)C;
+    float s1 = 0.f, s2 = 0.f;
+    for (int e = tid; e < rows * c4n; e += 256) {
+        const int rl = e / c4n, c = (e - rl * c4n) * 4;
+        const int r = r0 + rl;
+        const int fo = r / To, to = r - fo * To;
+        f32x4 o = *reinterpret_cast<const f32x4 *>(bias + c);
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            const int f = fo * stride - pad_lo + tap;
+            if ((unsigned)f < (unsigned)F) {
+                const int64_t idx = ((int64_t)f * T + to) * C + c;
+                const f32x4 z = *reinterpret_cast<const f32x4 *>(xs + idx);
+                const f32x4 wv = *reinterpret_cast<const f32x4 *>(lw + idx), bv = *reinterpret_cast<const f32x4 *>(lb + idx);
+                const f32x4 kv = *reinterpret_cast<const f32x4 *>(w + tap * C + c);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float t = fmaf((z[q] - mean) * rstd, wv[q], bv[q]);
+                    if (after_bn) t = act_fn(t, act);
+                    o[q] = fmaf(t, kv[q], o[q]);
+                }
+            }
+        }
+        if (!after_bn) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = act_fn(o[q], act);
+        }
+        *reinterpret_cast<f32x4 *>(ys + (int64_t)rl * C + c) = o;
+        s1 += (o[0] + o[1]) + (o[2] + o[3]);
+        s2 += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if ((tid & 63) == 0) { red[tid >> 6] = s1; red[4 + (tid >> 6)] = s2; }
+    __syncthreads();
+    if (tid == 0) {
+        float *o = part + (b * P + slot) * 2;
+        o[0] = (red[0] + red[1]) + (red[2] + red[3]);
+        o[1] = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+}
+
+int launch_conv_dw_ln(const SubLayer &L, const SubLayer &Lin, const float *x, const float *in_part, int in_P, float *in_stats,
+                      float *y, float *out_part, int64_t B, int act, int after_bn, hipStream_t s) {
+    const int rps = L.Fo * L.To;
+    const int64_t in_elems = (int64_t)L.F * L.T * L.ci;
+    {
+        ProfScope ps("ln_finalize", s);
+        PF_LAUNCH(ln_finalize_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, s, in_part, in_P, 1.0 / (double)in_elems, in_stats, (int)B);
+    }
+    const int P = fused_out_slots(L, B);
+    ProfScope ps("conv_dw_ln", s, 4.0 * (double)B * ((double)in_elems + (double)rps * L.co));
+    PF_LAUNCH(conv_dw_ln_kernel, dim3((unsigned)(B * P)), dim3(256), 0, s, x, in_stats, Lin.ln_w, Lin.ln_b, L.w, L.bias, y, out_part,
+              L.co, L.To, L.F, L.T, L.stride, L.pad_lo, rps, P, act, after_bn);
     PF_HIP(hipGetLastError());
     return 0;
 }

@@ -278,7 +278,7 @@ def test_config5_d64_fp16_storage():
     t0 = time.time()
     params, sd, eng = _engine("n640d64", 4096)
     d, k, n_songs, nq = 64, params["indexer"]["top_k"], 10000, 2000
-    assert eng.set_fused_layernorm(True) is False                    # depthwise model: separate LayerNorm kernels
+    assert eng.set_fused_layernorm(True) is True                     # depthwise model on the fused path (conv_dw_ln_kernel)
     db, pos = build_db(eng, n_songs, d, 4096)
     q_pcm, q_song, q_off, emb = make_queries(eng, n_songs, nq, 0.0)
     i32 = DeviceIndex(d, 0)
