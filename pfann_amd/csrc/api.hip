@@ -389,7 +389,7 @@ static int encode_chunk_fused(pfann_ctx *c, const float *mel, int64_t B, float *
     // Sub-layer 0 (C_in = 1 conv): normally only its LayerNorm statistics are computed here and the
     // conv itself is folded into sub-layer 1's A-loader; the 2 MiB/segment tensor is materialised
     // only when verification taps are requested.
-    const bool fold_first = !c->keep && c->sub[1].axis == 1 && !c->sub[1].depthwise && c->sub[0].co <= 256 &&
+    const bool fold_first = !c->keep && c->sub[1].axis == 1 && c->sub[0].co <= 256 &&
                             getenv("PFANN_NO_FOLD_FIRST") == nullptr;
     if (fold_first && g.relu_after_bn && (int)c->w1_host.size() == 3 * c->sub[0].co && (int)c->b1_host.size() == c->sub[0].co) {
         if (!c->gram_ready) build_gram(c);
@@ -402,8 +402,8 @@ static int encode_chunk_fused(pfann_ctx *c, const float *mel, int64_t B, float *
     for (int i = 1; i < 16; ++i) {
         const bool first = fold_first && i == 1;
         if (c->sub[i].depthwise) {
-            if (launch_conv_dw_ln(c->sub[i], c->sub[i - 1], buf[(i - 1) & 1], part[(i - 1) & 1], P, c->stats + slot0 * 2, buf[i & 1],
-                                  part[i & 1], B, g.activation, g.relu_after_bn, s)) return -1;
+            if (launch_conv_dw_ln(c->sub[i], c->sub[i - 1], first ? mel : buf[(i - 1) & 1], part[(i - 1) & 1], P, c->stats + slot0 * 2,
+                                  buf[i & 1], part[i & 1], B, g.activation, g.relu_after_bn, first ? &c->sub[0] : nullptr, s)) return -1;
         } else if (launch_conv_gemm_ln(c->sub[i], c->sub[i - 1], first ? mel : buf[(i - 1) & 1], part[(i - 1) & 1], P, c->stats + slot0 * 2, buf[i & 1],
                                 part[i & 1], B, g.activation, g.relu_after_bn, first ? &c->sub[0] : nullptr, c->precision, s)) return -1;
         P = fused_out_slots(c->sub[i], B);

@@ -823,12 +823,16 @@ int launch_conv_first_gram_stats(const SubLayer &L, const float *x, float *part,
 // tensor: 46 % of the n640d64 encoder).  HBM-bound elementwise work: one workgroup = up to 64 output rows of ONE sample
 // x all channels, float4 along C; statistics reduced in a fixed order.
 // ------------------------------------------------------------------------------------
+// FIRST: the input is the C_in = 1 first conv computed on the fly from the log-mel (x = mel [B][F][T0]): its
+// 1 MiB/segment output (n640d64) is never written or read back, as in the full-conv models' folded first layer.
+template <bool FIRST>
 __global__ __launch_bounds__(256) void conv_dw_ln_kernel(const float *__restrict__ x, const float *__restrict__ in_stats,
                                                          const float *__restrict__ lw, const float *__restrict__ lb,
                                                          const float *__restrict__ w, const float *__restrict__ bias,
                                                          float *__restrict__ y, float *__restrict__ part, int C, int To,
                                                          int F, int T, int stride, int pad_lo, int rps, int P, int act,
-                                                         int after_bn) {
+                                                         int after_bn, const float *__restrict__ w1,
+                                                         const float *__restrict__ b1, int T0, int st1, int pad1) {
     __shared__ float red[8];
     const int tid = threadIdx.x;
     const int64_t b = blockIdx.x / P;
@@ -837,7 +841,7 @@ __global__ __launch_bounds__(256) void conv_dw_ln_kernel(const float *__restrict
     const int r0 = slot * rows;
     const int c4n = C >> 2;
     const float mean = in_stats[2 * b], rstd = in_stats[2 * b + 1];
-    const float *xs = x + b * (int64_t)F * T * C;
+    const float *xs = x + b * (int64_t)F * (FIRST ? T0 : T * C);
     float *ys = y + (b * rps + r0) * (int64_t)C;
     float s1 = 0.f, s2 = 0.f;
     for (int e = tid; e < rows * c4n; e += 256) {
@@ -850,7 +854,26 @@ __global__ __launch_bounds__(256) void conv_dw_ln_kernel(const float *__restrict
             const int f = fo * stride - pad_lo + tap;
             if ((unsigned)f < (unsigned)F) {
                 const int64_t idx = ((int64_t)f * T + to) * C + c;
-                const f32x4 z = *reinterpret_cast<const f32x4 *>(xs + idx);
+                f32x4 z;
+                if (FIRST) {           // z = b1 + sum_t1 w1[t1] * mel[f][to*s1 - pad1 + t1]  (bias, then taps 0, 1, 2)
+                    z = *reinterpret_cast<const f32x4 *>(b1 + c);
+#pragma unroll
+                    for (int t1 = 0; t1 < 3; ++t1) {
+                        const int tq = to * st1 - pad1 + t1;
+                        if ((unsigned)tq < (unsigned)T0) {
+                            const float mv = xs[(int64_t)f * T0 + tq];
+                            const f32x4 k1 = *reinterpret_cast<const f32x4 *>(w1 + t1 * C + c);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) z[q] = fmaf(mv, k1[q], z[q]);
+                        }
+                    }
+                    if (!after_bn) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) z[q] = act_fn(z[q], act);
+                    }
+                } else {
+                    z = *reinterpret_cast<const f32x4 *>(xs + idx);
+                }
                 const f32x4 wv = *reinterpret_cast<const f32x4 *>(lw + idx), bv = *reinterpret_cast<const f32x4 *>(lb + idx);
                 const f32x4 kv = *reinterpret_cast<const f32x4 *>(w + tap * C + c);
 #pragma unroll
@@ -880,7 +903,7 @@ __global__ __launch_bounds__(256) void conv_dw_ln_kernel(const float *__restrict
 }
 
 int launch_conv_dw_ln(const SubLayer &L, const SubLayer &Lin, const float *x, const float *in_part, int in_P, float *in_stats,
-                      float *y, float *out_part, int64_t B, int act, int after_bn, hipStream_t s) {
+                      float *y, float *out_part, int64_t B, int act, int after_bn, const SubLayer *Lfirst, hipStream_t s) {
     const int rps = L.Fo * L.To;
     const int64_t in_elems = (int64_t)L.F * L.T * L.ci;
     {
@@ -889,8 +912,13 @@ int launch_conv_dw_ln(const SubLayer &L, const SubLayer &Lin, const float *x, co
     }
     const int P = fused_out_slots(L, B);
     ProfScope ps("conv_dw_ln", s, 4.0 * (double)B * ((double)in_elems + (double)rps * L.co));
-    PF_LAUNCH(conv_dw_ln_kernel, dim3((unsigned)(B * P)), dim3(256), 0, s, x, in_stats, Lin.ln_w, Lin.ln_b, L.w, L.bias, y, out_part,
-              L.co, L.To, L.F, L.T, L.stride, L.pad_lo, rps, P, act, after_bn);
+    if (Lfirst != nullptr)
+        PF_LAUNCH(conv_dw_ln_kernel<true>, dim3((unsigned)(B * P)), dim3(256), 0, s, x, in_stats, Lin.ln_w, Lin.ln_b, L.w, L.bias, y,
+                  out_part, L.co, L.To, L.F, L.T, L.stride, L.pad_lo, rps, P, act, after_bn, Lfirst->w, Lfirst->bias, Lfirst->T,
+                  Lfirst->stride, Lfirst->pad_lo);
+    else
+        PF_LAUNCH(conv_dw_ln_kernel<false>, dim3((unsigned)(B * P)), dim3(256), 0, s, x, in_stats, Lin.ln_w, Lin.ln_b, L.w, L.bias, y,
+                  out_part, L.co, L.To, L.F, L.T, L.stride, L.pad_lo, rps, P, act, after_bn, nullptr, nullptr, 0, 1, 0);
     PF_HIP(hipGetLastError());
     return 0;
 }

@@ -43,7 +43,7 @@ int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, 
                         float *in_stats, float *y, float *out_part, int64_t B, int act, int after_bn,
                         const SubLayer *Lfirst, int precision, hipStream_t s);
 int launch_conv_dw_ln(const SubLayer &L, const SubLayer &Lin, const float *x, const float *in_part, int in_P, float *in_stats,
-                      float *y, float *out_part, int64_t B, int act, int after_bn, hipStream_t s);
+                      float *y, float *out_part, int64_t B, int act, int after_bn, const SubLayer *Lfirst, hipStream_t s);
 int launch_ln_apply(const SubLayer &L, const float *z, const float *part, int P, float *out, int64_t B, int act,
                     int after_bn, hipStream_t s);
 int launch_myg_ln(const SubLayer &Llast, const float *z, const float *part, int P, int act, int after_bn,
