@@ -113,6 +113,29 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return start + idx;
 }
 
+// n / d for 0 <= n < 2^31 and a launch-constant divisor d >= 1, as one multiply-high and a shift (a 32-bit scalar
+// division is ~40 dependent instructions; in a GEMM prologue that shares its SIMD with another workgroup's MFMA stream
+// every dependent instruction costs 10+ cycles).  k = ceil(log2 d), mul = floor(2^(31+k) / d) + 1 < 2^32 for d >= 2:
+// n * mul / 2^(31+k) = n/d + n*e/2^(31+k) with 0 < e <= 1, and n*e/2^(31+k) < 2^-k <= 1/d, so the floor is exact.
+struct FastDiv {
+    unsigned mul;      // 0: d == 1
+    int shift;         // k - 1
+    int d;
+};
+inline FastDiv make_fastdiv(int d) {
+    FastDiv f;
+    f.d = d; f.mul = 0; f.shift = 0;
+    if (d <= 1) return f;
+    int k = 0;
+    while ((1ll << k) < d) ++k;
+    f.mul = (unsigned)(((1ull << (31 + k)) / (unsigned long long)d) + 1ull);
+    f.shift = k - 1;
+    return f;
+}
+__device__ __forceinline__ int fastdiv(int n, const FastDiv &f) {
+    return f.mul == 0 ? n : (int)(__umulhi((unsigned)n, f.mul) >> f.shift);
+}
+
 // ---- encoder plan shared between api and kernels ---------------------------------------
 struct SubLayer {          // one conv (+LN+act) sub-layer, channels-last activations
     int ci, co;            // input / output channels

@@ -41,6 +41,7 @@ struct FusedGemmParams {
     int axis, stride, pad_lo, in_len;
     int64_t tap_stride;
     int n_tiles_n;
+    FastDiv dv_group, dv_tile, dv_n;   // divisors 64 * (rows_per_sample / BM) * n_tiles_n, 64 * n_tiles_n, n_tiles_n
     int k_begin, k_end;
     // input normalisation
     const float *in_stats;       // [n_samples][2] = (mean, rstd) of the input, from ln_finalize_kernel
@@ -76,10 +77,18 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int RPT = NT / TPR;                      // tile rows covered per loader pass
     constexpr int AR = BM / RPT, BR = BN / RPT;
-    __shared__ __attribute__((aligned(16))) float As[2 * BM * LDK];
-    __shared__ __attribute__((aligned(16))) float Bs[2 * BN * LDK];
+    __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDK + 2 * BN * LDK];     // one array: the epilogue reuses it whole
+    float *const As = smem, *const Bs = smem + 2 * BM * LDK;
     __shared__ __attribute__((aligned(16))) float s_w1[FIRST ? 4 * 256 : 4];   // FIRST: w1[3][Ci], b1[Ci]; Ci <= 256
 
+    // Every launch constant the prologue touches, requested in ONE batch of scalar loads: left to itself the compiler
+    // loads them where first used, and each of those five `s_waitcnt lgkmcnt(0)` cost a scalar-cache round trip of
+    // 1-2 k cycles on a chip busy streaming operands (in-kernel timestamps: 11 k cycles before the first operand load).
+    asm volatile("" :: "s"(p.x), "s"(p.w), "s"(p.in_stats), "s"(p.ln_w), "s"(p.ln_b), "s"(p.in_elems), "s"(p.tap_stride),
+                 "s"(p.M), "s"(p.N), "s"(p.K), "s"(p.Ci), "s"(p.rows_per_sample), "s"(p.To), "s"(p.F), "s"(p.T));
+    asm volatile("" :: "s"(p.rps_shift), "s"(p.To_shift), "s"(p.axis), "s"(p.stride), "s"(p.pad_lo), "s"(p.in_len),
+                 "s"(p.n_tiles_n), "s"(p.k_begin), "s"(p.k_end), "s"(p.n_samples), "s"(p.dv_group.mul), "s"(p.dv_group.shift),
+                 "s"(p.dv_tile.mul), "s"(p.dv_tile.shift), "s"(p.dv_n.mul), "s"(p.dv_n.shift));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int L = xcd_remap(blockIdx.x, gridDim.x);
@@ -91,17 +100,17 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
         constexpr int GS = 64;
         const int tps = rps / BM;
         const int per_group = GS * tps * p.n_tiles_n;
-        const int g = L / per_group;
+        const int g = fastdiv(L, p.dv_group);
         const int left = p.n_samples - g * GS;
         const int gs = left < GS ? left : GS;
         const int r = L - g * per_group;
-        const int ti = r / (gs * p.n_tiles_n);
+        const int ti = gs == GS ? fastdiv(r, p.dv_tile) : r / (gs * p.n_tiles_n);     // the last group may be short
         const int r2 = r - ti * (gs * p.n_tiles_n);
-        const int bi = r2 / p.n_tiles_n;
+        const int bi = fastdiv(r2, p.dv_n);
         nt = r2 - bi * p.n_tiles_n;
         mt = (g * GS + bi) * tps + ti;
     } else {
-        mt = L / p.n_tiles_n;
+        mt = fastdiv(L, p.dv_n);
         nt = L - mt * p.n_tiles_n;
     }
     const int m0 = mt * BM;
@@ -125,29 +134,33 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
     const __amdgpu_buffer_rsrc_t srd_bl = make_srd(p.w_lo, SPLIT ? (unsigned long long)p.N * p.K * 2ull : 0ull);
     int aoff[AR], arel[AR], ap0[AR], atq[AR];
     float amu[AR], ars[AR];
+    // Branch-free on purpose: with the row set-up under `if (m < M)` the statistics loads sat inside a divergent
+    // region whose join needs the loaded value at once -- two serialised memory round trips (`global_load; s_waitcnt
+    // vmcnt(0)` twice in the ISA) before the first operand load was even issued, 12 k cycles of prologue per tile
+    // (in-kernel timestamps).  Now: two bounds-checked loads (rows m >= M read 0) that are first needed by the
+    // LayerNorm transform of K-tile 0.
+    const __amdgpu_buffer_rsrc_t srd_st = make_srd(p.in_stats, (unsigned long long)p.n_samples * 8ull);
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
         const int m = m0 + rowq + RPT * i;
-        if (m < p.M) {
-            const int b = m >> p.rps_shift;
-            const int r = m & (rps - 1);
-            const int fo = r >> p.To_shift, to = r & (p.To - 1);
-            int rel;
-            if (p.axis == 0) { ap0[i] = to * p.stride - p.pad_lo; rel = (fo * p.T + ap0[i]) * p.Ci; }
-            else { ap0[i] = fo * p.stride - p.pad_lo; rel = (ap0[i] * p.T + to) * p.Ci; }
-            const int sl = b - b_first;
-            arel[i] = rel;
-            aoff[i] = sl * (int)p.in_elems + rel;
-            if (FIRST) {   // mel element of tap2 = 0, tap1 = 0:  ((b*F + f_in) * T0 + to*s1 - pad1)
-                atq[i] = to * p.s1 - p.pad1;
-                aoff[i] = (sl * p.F + ap0[i]) * p.T0 + atq[i];
-            }
-            amu[i] = p.in_stats[2 * b];
-            ars[i] = p.in_stats[2 * b + 1];
-        } else {
-            ap0[i] = -(1 << 20);
-            aoff[i] = 0; arel[i] = 0; amu[i] = 0.f; ars[i] = 0.f; atq[i] = 0;
+        const bool mok = m < p.M;
+        const int b = m >> p.rps_shift;
+        amu[i] = buf_load1(srd_st, mok ? (unsigned)b * 8u : BUF_OOB);
+        ars[i] = buf_load1(srd_st, mok ? (unsigned)b * 8u + 4u : BUF_OOB);
+        const int r = m & (rps - 1);
+        const int fo = r >> p.To_shift, to = r & (p.To - 1);
+        int rel, a0;
+        if (p.axis == 0) { a0 = to * p.stride - p.pad_lo; rel = (fo * p.T + a0) * p.Ci; }
+        else { a0 = fo * p.stride - p.pad_lo; rel = (a0 * p.T + to) * p.Ci; }
+        const int sl = b - b_first;
+        arel[i] = rel;
+        aoff[i] = sl * (int)p.in_elems + rel;
+        atq[i] = 0;
+        if (FIRST) {   // mel element of tap2 = 0, tap1 = 0:  ((b*F + f_in) * T0 + to*s1 - pad1)
+            atq[i] = to * p.s1 - p.pad1;
+            aoff[i] = (sl * p.F + a0) * p.T0 + atq[i];
         }
+        ap0[i] = mok ? a0 : -(1 << 20);          // rows past M: every tap out of range -> all offsets out of range
     }
     // Operand addressing.  UNI (Ci % BK == 0): every thread of the block is in the same filter tap
     // for a whole K-tile, so the K position lives in a scalar register (the buffer instruction's
@@ -471,8 +484,16 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
     // store as for a dwordx4 one; scalar stores made the epilogue 6 % of the kernel).
     const __amdgpu_buffer_rsrc_t srd_y = make_srd(p.y + (int64_t)m0 * p.N, (unsigned long long)(p.M - m0) * p.N * 4ull);
     const __amdgpu_buffer_rsrc_t srd_bias = make_srd(p.bias, (unsigned long long)p.N * 4ull);
-    float *red1 = As;                 // [BM][WAVES_N] row (or sub-tile) sums; As/Bs are free now
-    float *red2 = As + BM * WAVES_N;
+    // The output tile goes through LDS so that it reaches memory as whole rows: straight from the accumulators a store
+    // instruction covers 32 rows x 32 B (a quarter cache line per row, four waves completing each 512 B row at different
+    // times); from LDS a half-wave writes one row's 512 contiguous bytes.  Measured on a stripped clone of this kernel
+    // (tools/ubench/gemm_tile.hip): +2.7 % at K = 384, +1.5 % at K = 768.  LDC = BN + 4: lanes 0..7 of a b128 write land
+    // on all 32 banks.
+    constexpr int LDC = BN + 4;
+    constexpr bool STAGE_C = BM * LDC + 2 * BM * WAVES_N + 8 <= 2 * BM * LDK + 2 * BN * LDK;
+    float *Cs = smem;                                   // [BM][LDC]
+    float *red1 = smem + (STAGE_C ? BM * LDC : 0);      // [BM][WAVES_N] row (or sub-tile) sums; As/Bs are free now
+    float *red2 = red1 + BM * WAVES_N;
     const int G = rps >= BM ? BM : rps;          // rows per statistics group inside the tile
     // No validity selects: columns n >= N (N % 4 == 0) have zero weights and bias (z = 0 adds nothing to
     // the sums) and an out-of-range store offset; rows m >= M lie beyond srd_y and form whole statistics
@@ -510,7 +531,8 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
                     a2 = fmaf(z, z, a2);
                     z4[e] = z;
                 }
-                buf_store4(srd_y, nb + ro, z4);
+                if (STAGE_C) *reinterpret_cast<f32x4 *>(&Cs[(wm * WM + i * 32 + l31) * LDC + wn * WN + j * 32 + 8 * g + 4 * lhalf]) = z4;
+                else buf_store4(srd_y, nb + ro, z4);
             }
         a1 += __shfl_xor(a1, 32, 64);    // the other half of the row's columns
         a2 += __shfl_xor(a2, 32, 64);
@@ -520,6 +542,17 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
         }
     }
     __syncthreads();
+    if (STAGE_C) {
+        constexpr int LPR = BN / 4, RPP = NT / LPR;     // lanes per tile row, rows per pass
+        const int cl = tid % LPR, rr = tid / LPR;
+        const int n = n0 + cl * 4;
+        const unsigned nb = n < p.N ? (unsigned)n * 4u : BUF_OOB;
+#pragma unroll
+        for (int it = 0; it < BM / RPP; ++it) {
+            const int row = it * RPP + rr;
+            buf_store4(srd_y, nb + (unsigned)row * rowbytes, *reinterpret_cast<const f32x4 *>(&Cs[row * LDC + cl * 4]));
+        }
+    }
     // rows -> statistics groups of G rows (one per sample touched), in a fixed order: thread r owns row r
     float t1 = 0.f, t2 = 0.f;
     if (tid < BM) {
@@ -528,7 +561,7 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
         for (int o = (G < 64 ? G : 64) >> 1; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o, 64); t2 += __shfl_xor(t2, o, 64); }
     }
     if (G > 64) {                        // BM = G = 128: one group spanning two waves
-        float *x2 = As + 2 * BM * WAVES_N;
+        float *x2 = red2 + BM * WAVES_N;
         if (tid < BM && lane == 0) { x2[2 * wave] = t1; x2[2 * wave + 1] = t2; }
         __syncthreads();
         t1 = x2[0] + x2[2];
@@ -659,6 +692,8 @@ int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, 
     } while (0)
     if (gemm_tile(L, B) == 128) {
         p.n_tiles_n = cdiv(p.N, 128);
+        p.dv_n = make_fastdiv(p.n_tiles_n); p.dv_tile = make_fastdiv(64 * p.n_tiles_n);
+        p.dv_group = make_fastdiv(64 * (p.rows_per_sample >= 128 ? p.rows_per_sample / 128 : 1) * p.n_tiles_n);
         const int64_t blocks = (int64_t)cdiv(p.M, 128) * p.n_tiles_n;
         ProfScope ps(layer_tag("conv_gemm_ln_128"), s, flops);
         // 8 waves (512 threads), each a 64x32 tile: half the prefetch registers per thread and four
@@ -672,6 +707,8 @@ int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, 
         PF_GEMM_LN(128, 128, 64, 32, 512);
     } else {
         p.n_tiles_n = cdiv(p.N, 64);
+        p.dv_n = make_fastdiv(p.n_tiles_n); p.dv_tile = make_fastdiv(64 * p.n_tiles_n);
+        p.dv_group = make_fastdiv(64 * (p.rows_per_sample >= 64 ? p.rows_per_sample / 64 : 1) * p.n_tiles_n);
         const int64_t blocks = (int64_t)cdiv(p.M, 64) * p.n_tiles_n;
         ProfScope ps(layer_tag("conv_gemm_ln_64"), s, flops);
         if (uni) {
