@@ -252,10 +252,10 @@ __global__ __launch_bounds__(256, 2) void scan_f16_kernel(ScanParams p) {
 // ------------------------------------------------------------------------------------
 // Query-stationary fp16 scan (d = 16*KS <= 128, thresholds present).  A workgroup owns ONE 128-row
 // query tile and one of S interleaved slices of the db tiles:
-//   * the query tile lives in REGISTERS as MFMA A-fragments for the whole launch (64 VGPRs at
-//     d = 128), and so does -(tau - eps) of its rows, which is the C operand of every first MFMA:
-//     the chain yields s16 - (tau - eps) and "survivor" is a sign test on the max of a lane's 16
-//     results (a handful of v_max instead of 16 compares);
+//   * the query tile lives in REGISTERS as MFMA fragments for the whole launch (64 VGPRs at
+//     d = 128) and is the SECOND MFMA operand, so a lane's 16 results are 16 db rows against ONE
+//     query row: threshold, survivor test (max of the 16 vs tau - eps), list reservation and the
+//     sampled pass's running maximum are all lane-local (see "query fragments" in the kernel);
 //   * only the 32 KB db tile goes through LDS per step (double buffered, one barrier): half the
 //     LDS traffic and staging instructions per MFMA of the generic kernel above, which matters
 //     because with d this small the loop is bound by LDS and issue slots, not by the fp16 MFMA rate;
@@ -294,7 +294,12 @@ __global__ __launch_bounds__(256, 2) void scan_f16_qres_kernel(ScanParams p) {
     const __amdgpu_buffer_rsrc_t srd_k = make_srd(p.keys + m0 * CAP + (int64_t)seg * subcap, (unsigned long long)BM * CAP * 8ull);
     const char *qb = reinterpret_cast<const char *>(p.q), *dbb = reinterpret_cast<const char *>(p.db);
 
-    // ---- A fragments: lane (l31, lhalf) holds k = 16*kk + 8*lhalf .. +7 of query row m0 + wm*64 + i*32 + l31
+    // ---- query fragments: lane (l31, lhalf) holds k = 16*kk + 8*lhalf .. +7 of query row m0 + wm*64 + i*32 + l31.
+    // They are the MFMA's SECOND operand (the db rows the first), so the result tile comes out transposed: a lane owns
+    // ONE query row and its 16 registers are 16 db rows (8g + 4*lhalf + e for register 4g + e).  Everything per query
+    // row is then lane-local: the threshold is one register instead of a 16-register C operand, "any survivor" is a
+    // compare of the lane maximum, a lane's survivors take ONE list reservation (count, then consecutive slots) instead
+    // of one LDS atomic each, and the running group maximum of the sampled pass is one register with no cross-lane step.
     const __amdgpu_buffer_rsrc_t srd_q = make_srd(qb + m0 * ROWB, (unsigned long long)(p.nq - m0) * ROWB);
     f16x8 afr[TM][KS];
 #pragma unroll
@@ -302,16 +307,16 @@ __global__ __launch_bounds__(256, 2) void scan_f16_qres_kernel(ScanParams p) {
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk)
             afr[i][kk] = __builtin_bit_cast(f16x8, buf_load4(srd_q, (unsigned)(wm * WM + i * 32 + l31) * ROWB + kk * 32 + lhalf * 16));
-    // C operand: -(tau - eps) of C rows wm*64 + i*32 + 8g + 4*lhalf + e (register 4g + e); rows past nq: -inf
-    f32x16 cinit[TM], gmx[TM];
+    float th[TM], gm[TM];          // tau - eps of this lane's query rows (rows past nq: +inf, never a survivor)
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
+        const int64_t m = m0 + wm * WM + i * 32 + l31;
+        th[i] = GMAX ? 0.f : (m < p.nq ? p.thr[m] : INFINITY);
+        gm[i] = -INFINITY;
+    }
+    f32x16 zero16;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-            cinit[i][r] = GMAX ? 0.f : (m < p.nq ? -p.thr[m] : -INFINITY);
-            gmx[i][r] = -INFINITY;
-        }
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
     const int n_grp = GMAX ? (int)((((t_hi - t_lo + S - 1) / S) + GCH - 1) / GCH) : 0;   // groups of this workgroup's slice
     const int g_per = GMAX ? (int)((((t_hi + S - 1) / S) + GCH - 1) / GCH) : 0;          // groups per slice (upper bound)
     int n_in_grp = 0, grp = 0;
@@ -377,64 +382,60 @@ __global__ __launch_bounds__(256, 2) void scan_f16_qres_kernel(ScanParams p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[i][kk], b8[j], kk == 0 ? cinit[i] : acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b8[j], afr[i][kk], kk == 0 ? zero16 : acc[i][j], 0, 0, 0);
         }
-        if (GMAX) {
+        const int nvalid = (int)(p.nrows - t * 128 < 128 ? p.nrows - t * 128 : 128);
+        if (nvalid < 128) {              // last tile (uniform): db rows past the end never count
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const bool nok = t * 128 + wn * WN + j * 32 + l31 < p.nrows;
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int r = 0; r < 16; ++r)
+                    if (wn * WN + j * 32 + 8 * (r >> 2) + 4 * lhalf + (r & 3) >= nvalid) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) gmx[i][r] = fmaxf(gmx[i][r], nok ? acc[i][j][r] : -INFINITY);
-            }
-            if (++n_in_grp == GCH || t + S >= t_hi) {             // close the group: maximum over the 32 lanes of a half
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float v = gmx[i][r];
-#pragma unroll
-                        for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-                        const int64_t m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-                        if (l31 == 0 && m < p.nq)
-                            p.gmax[m * ((int64_t)S * g_per * 2) + ((int64_t)seg * g_per + grp) * 2 + wn] = v;
-                        gmx[i][r] = -INFINITY;
+                        for (int i = 0; i < TM; ++i) acc[i][j][r] = -INFINITY;
                     }
-                n_in_grp = 0;
-                ++grp;
-            }
-        } else
+        }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int64_t n = t * 128 + wn * WN + j * 32 + l31;
-            const bool nok = n < p.nrows;
-            const unsigned rowid = (unsigned)(n * p.row_stride);
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 float mx = fmaxf(acc[i][j][0], acc[i][j][1]);
 #pragma unroll
                 for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(mx, acc[i][j][r]), acc[i][j][r + 1]);
-                if (__any(nok && mx >= 0.f)) {
-                    // all LDS counter updates first (one latency), then the stores
-                    int pos[16];
+                if (GMAX) {
+                    gm[i] = fmaxf(gm[i], mx);
+                } else if (__any(mx >= th[i])) {
+                    const int ml = wm * WM + i * 32 + l31;
+                    int c = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c += acc[i][j][r] >= th[i] ? 1 : 0;
+                    int pos = 0x7FFFFFFF;
+                    if (c > 0) pos = atomicAdd(&s_cnt[ml], c);
+                    const unsigned row0 = (unsigned)((t * 128 + wn * WN + j * 32 + 4 * lhalf) * p.row_stride);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        pos[r] = 0x7FFFFFFF;
-                        if (nok && acc[i][j][r] >= 0.f)
-                            pos[r] = atomicAdd(&s_cnt[wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf], 1);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        if (pos[r] < subcap) {
-                            const int ml = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-                            const unsigned long long key = pack_key(acc[i][j][r] - cinit[i][r], rowid);
-                            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, key), srd_k,
-                                                                  (ml * CAP + pos[r]) * 8, 0, 0);
+                        if (acc[i][j][r] >= th[i]) {
+                            if (pos < subcap) {
+                                const unsigned long long key = pack_key(acc[i][j][r], row0 + (unsigned)((8 * (r >> 2) + (r & 3)) * p.row_stride));
+                                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, key), srd_k, (ml * CAP + pos) * 8, 0, 0);
+                            }
+                            ++pos;
                         }
                     }
                 }
+            }
+        if (GMAX) {
+            if (++n_in_grp == GCH || t + S >= t_hi) {             // close the group: the two lane halves hold different db rows
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float v = fmaxf(gm[i], __shfl_xor(gm[i], 32, 64));
+                    const int64_t m = m0 + wm * WM + i * 32 + l31;
+                    if (lhalf == 0 && m < p.nq) p.gmax[m * ((int64_t)S * g_per * 2) + ((int64_t)seg * g_per + grp) * 2 + wn] = v;
+                    gm[i] = -INFINITY;
+                }
+                n_in_grp = 0;
+                ++grp;
             }
         }
         __syncthreads();                 // (waits for the tile in flight: vmcnt(0) precedes the barrier)
@@ -442,12 +443,10 @@ __global__ __launch_bounds__(256, 2) void scan_f16_qres_kernel(ScanParams p) {
     if (GMAX) {       // groups this slice did not reach (shorter slices): never the k-th best
         for (int gq = grp; gq < g_per; ++gq)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-                    if (l31 == 0 && m < p.nq) p.gmax[m * ((int64_t)S * g_per * 2) + ((int64_t)seg * g_per + gq) * 2 + wn] = -INFINITY;
-                }
+            for (int i = 0; i < TM; ++i) {
+                const int64_t m = m0 + wm * WM + i * 32 + l31;
+                if (lhalf == 0 && m < p.nq) p.gmax[m * ((int64_t)S * g_per * 2) + ((int64_t)seg * g_per + gq) * 2 + wn] = -INFINITY;
+            }
         return;
     }
     if (tid < BM && m0 + tid < p.nq) p.cnt[(m0 + tid) * S + seg] = s_cnt[tid];
