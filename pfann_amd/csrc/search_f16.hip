@@ -399,28 +399,47 @@ __global__ __launch_bounds__(256, 2) void scan_f16_qres_kernel(ScanParams p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                float mx = fmaxf(acc[i][j][0], acc[i][j][1]);
+                // maxima of the four register quads (4 consecutive db rows each), then of the lane
+                float mg[4];
 #pragma unroll
-                for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(mx, acc[i][j][r]), acc[i][j][r + 1]);
+                for (int g = 0; g < 4; ++g)
+                    mg[g] = fmaxf(fmaxf(acc[i][j][4 * g], acc[i][j][4 * g + 1]), fmaxf(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]));
+                const float mx = fmaxf(fmaxf(mg[0], mg[1]), fmaxf(mg[2], mg[3]));
                 if (GMAX) {
                     gm[i] = fmaxf(gm[i], mx);
                 } else if (__any(mx >= th[i])) {
+                    // Survivors are rare (a 32x32 block holds one with probability ~0.3, almost never two in a lane), so
+                    // the path is built from wave-uniform tests per register quad and stores whose offset is out of range
+                    // for non-survivors (the buffer unit drops them): no per-register exec-mask regions -- the
+                    // straightforward `if (survivor) { atomic; store }` per register compiled to 440 instructions per
+                    // block and was a third of the pass.
                     const int ml = wm * WM + i * 32 + l31;
+                    bool anyg[4];
                     int c = 0;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) c += acc[i][j][r] >= th[i] ? 1 : 0;
-                    int pos = 0x7FFFFFFF;
-                    if (c > 0) pos = atomicAdd(&s_cnt[ml], c);
+                    for (int g = 0; g < 4; ++g) {
+                        anyg[g] = __any(mg[g] >= th[i]);
+                        if (anyg[g]) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) c += acc[i][j][4 * g + e] >= th[i] ? 1 : 0;
+                        }
+                    }
+                    int pos = 0;
+                    if (c > 0) pos = atomicAdd(&s_cnt[ml], c);       // one reservation for all of the lane's survivors
                     const unsigned row0 = (unsigned)((t * 128 + wn * WN + j * 32 + 4 * lhalf) * p.row_stride);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        if (acc[i][j][r] >= th[i]) {
-                            if (pos < subcap) {
-                                const unsigned long long key = pack_key(acc[i][j][r], row0 + (unsigned)((8 * (r >> 2) + (r & 3)) * p.row_stride));
+                    for (int g = 0; g < 4; ++g) {
+                        if (anyg[g]) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float v = acc[i][j][4 * g + e];
+                                const bool sv = v >= th[i];
+                                const unsigned long long key = pack_key(v, row0 + (unsigned)((8 * g + e) * p.row_stride));
                                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, key), srd_k, (ml * CAP + pos) * 8, 0, 0);
+                                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, key), srd_k,
+                                                                      (sv && pos < subcap) ? (unsigned)(ml * CAP + pos) * 8u : BUF_OOB, 0, 0);
+                                pos += sv ? 1 : 0;
                             }
-                            ++pos;
                         }
                     }
                 }
