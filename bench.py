@@ -48,7 +48,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--queries", type=int, default=512, help="10 s queries per step (whole job)")
+    ap.add_argument("--queries", type=int, default=512,
+                    help="10 s queries per step and GPU (--scaling weak, the default) or per step for the whole job (strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = every rank brings its own --queries queries per step (the db stays the one "
+                         "1M-segment db, song-sharded), strong = --queries split over the ranks")
     ap.add_argument("--db-songs", type=int, default=16950, help="16950 x 59 = 1,000,050 segments")
     ap.add_argument("--filler-db", action="store_true",
                     help="round-1 style database (48 real songs + seeded unit-norm filler rows): scan-only studies")
@@ -163,7 +167,7 @@ def main():
         sharded = ShardedIndex(index, song_pos, k, 1, 0.0)
 
     # ----------------------------------------------------------------- queries (untimed)
-    Q = args.queries
+    Q = args.queries * ((emu if emu > 1 else world) if args.scaling == "weak" else 1)      # queries per step, whole job
     if args.filler_db:
         all_real = np.unique(np.linspace(0, n_songs - 1, 48).astype(np.int64))
         q_song = [int(all_real[j % len(all_real)]) for j in range(Q)]
@@ -493,7 +497,7 @@ def main():
                       % (args.snr, "1M" if n_rows == 1000050 else str(n_rows)),
             "value": round(value, 1), "unit": "segments/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
             "dtype_note": "all results exact fp32 (fp32 MFMA encoder; batched scan pre-filtered on fp16 MFMA with a rigorous "
                           "margin, then re-scored in fp32)",
             "data": "synthetic",
@@ -504,7 +508,8 @@ def main():
                                    "; %d x 10 s queries/step at SNR %g dB (%d segments), configs/default.json encoder "
                                    "(d=128,h=1024,u=32,fuller; seeded weights with calibrated output bias), top_k=100" %
                                    (Q, args.snr, n_seg),
-                       "db_rows": n_rows, "queries_per_step": Q, "segments_per_step": n_seg,
+                       "db_rows": n_rows, "queries_per_step": Q, "queries_per_step_per_gpu": Q // world,
+                       "segments_per_step": n_seg,
                        "parallelism": "song-sharded db x%d" % world, "max_batch": args.max_batch},
             "top1_hit_rate": round(hits / Q, 4), "top1_near_0.5s": round(near / Q, 4),
             "top1_exact_0.25s": round(exact / Q, 4),

@@ -794,9 +794,11 @@ int search_topk(const float *db, const void *dbh, float xnorm_max, int64_t n, in
         // re-scoring (same exact result); fp16-only storage: eps = 0, the s16 scores are the result
         const int rescore = half_only ? 0 : 1;
         {
-            // one group-maximum pass over every 4th row instead of the dense + 1/16 survivor levels
-            int G = 0;
-            const int rc = (k <= 128 && getenv("PFANN_NO_GMAX") == nullptr) ? launch_scan_f16_gmax(dbh, n, d, 4, ws.qh, nq, k, ws, &G, s) : 1;
+            // one group-maximum pass over every 4th row instead of the dense + 1/16 survivor levels; shards too small
+            // to give 4 k groups at that stride (the 1/4 and 1/8 shards of a multi-GPU job) are sampled more densely
+            int G = 0, rc = 1;
+            if (k <= 128 && getenv("PFANN_NO_GMAX") == nullptr)
+                for (int64_t gs = 4; gs >= 1 && rc == 1; gs >>= 1) rc = launch_scan_f16_gmax(dbh, n, d, gs, ws.qh, nq, k, ws, &G, s);
             if (rc < 0) return -1;
             if (rc == 0) {
                 if (launch_group_max_select(ws, nq, G, k, 0, true, rescore ? 2.f : 0.f, s)) return -1;

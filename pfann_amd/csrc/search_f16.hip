@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void scan_f16_kernel(ScanParams p) {
 // 32x32 block then holds a survivor with probability 0.34 instead of 0.8 (the survivor path was half of the pass).
 template <int KS, bool GMAX = false>
 __global__ __launch_bounds__(256, 2) void scan_f16_qres_kernel(ScanParams p) {
-    constexpr int GCH = 5;                        // db tiles per group (GMAX)
+    const int GCH = GMAX ? p.gch : 1;             // db tiles per group (GMAX)
     constexpr int BM = 128, WM = 64, WN = 64, TM = 2, TN = 2;
     constexpr int ROWB = KS * 32;                 // bytes of one fp16 row
     constexpr int CPR = ROWB / 16;                // 16-byte chunks per row
@@ -487,9 +487,16 @@ int launch_scan_f16_gmax(const void *dbh, int64_t n, int d, int64_t stride, cons
     int S = (int)(2048 / p.n_tiles_m);
     S = S < 1 ? 1 : (S > 32 ? 32 : S);
     if (S > db_tiles) S = (int)db_tiles;
-    const int g_per = (int)(((db_tiles + S - 1) / S + 4) / 5);
-    const int G = S * g_per * 2;
-    if (G < 4 * k || G > 4096) return 1;
+    // tiles per group: the coarsest grouping that still leaves >= 4 k group maxima per query row (the k-th best of G
+    // maxima is a useful threshold only while most of the top k fall into different groups) and <= 4096 of them
+    int gch = 0, g_per = 0, G = 0;
+    for (int c : {5, 3, 2, 1}) {
+        g_per = (int)(((db_tiles + S - 1) / S + c - 1) / c);
+        G = S * g_per * 2;
+        if (G >= 4 * k && G <= 4096) { gch = c; break; }
+    }
+    if (gch == 0) return 1;
+    p.gch = gch;
     p.nsub = S;
     p.gmax = reinterpret_cast<float *>(ws.cl);
     ProfScope ps("scan_topk_f16_sample", s, 2.0 * (double)nq * p.nrows * d);

@@ -37,25 +37,28 @@ def test_bench_json_contract_small():
     assert out["seq_score_seam"]["same_best_song"] is True
 
 
-def test_two_rank_sharded_path_matches_single_gpu(tmp_path):
+@pytest.mark.parametrize("scaling", ["strong", "weak"])
+def test_two_rank_sharded_path_matches_single_gpu(tmp_path, scaling):
     """N>1 on the real kernels: 2 ranks sharing this box's GPU (gloo-staged collectives, debugging
-    aid) must reach exactly the single-GPU decisions."""
+    aid) must reach exactly the single-GPU decisions.  strong: the 24 queries split over the ranks; weak (bench.py's
+    default): every rank brings 12 of its own -- the same 24 queries either way."""
     import numpy as np
-    common = ["--steps", "1", "--warmup", "0", "--queries", "24", "--db-songs", "600",
-              "--no-cpu-baseline", "--no-prof", "--max-batch", "512"]
+    common = ["--steps", "1", "--warmup", "0", "--db-songs", "600", "--no-cpu-baseline", "--no-prof", "--max-batch", "512"]
     one = str(tmp_path / "one.npy")
     two = str(tmp_path / "two.npy")
-    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + common + ["--dump-decisions", one],
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + common + ["--queries", "24", "--dump-decisions", one],
                        capture_output=True, text=True, timeout=900, cwd=REPO)
     assert r.returncode == 0, r.stderr[-3000:]
     env = dict(os.environ, PFANN_DIST_BACKEND="gloo", PFANN_FORCE_DEVICE="0", MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29733", os.path.join(REPO, "bench.py"),
-                        "--gpus", "2"] + common + ["--dump-decisions", two],
+                        "--master-addr", "127.0.0.1", "--master-port", "29733" if scaling == "strong" else "29735",
+                        os.path.join(REPO, "bench.py"), "--gpus", "2", "--scaling", scaling,
+                        "--queries", "24" if scaling == "strong" else "12"] + common + ["--dump-decisions", two],
                        capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     a, b = np.load(one), np.load(two)
     assert np.array_equal(a[:, :2], b[:, :2])
     assert np.abs(a[:, 2] - b[:, 2]).max() < 1e-6
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
-    assert out["n_gpus"] == 2 and out["scaling"] == "strong"
+    assert out["n_gpus"] == 2 and out["scaling"] == scaling
+    assert out["config"]["queries_per_step"] == 24 and out["config"]["queries_per_step_per_gpu"] == 12
