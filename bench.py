@@ -173,19 +173,25 @@ def main():
         q_song = [int(all_real[j % len(all_real)]) for j in range(Q)]
     else:
         q_song = [int((j * 7919 + 13) % n_songs) for j in range(Q)]        # spread over the whole db
-    q_pcm_t, q_off_t = [], []
-    for c0 in range(0, Q, CH):
-        ids = q_song[c0:c0 + CH]
-        qp, qo = synth.make_queries_torch(synth.make_songs_torch(ids, 30.0, device=dev), list(range(c0, c0 + len(ids))),
-                                          10.0, args.snr)
-        q_pcm_t.append(qp)
-        q_off_t.append(qo)
-    q_pcm_all = torch.cat(q_pcm_t)                                          # [Q, 80000] int16 on the device
-    q_off = torch.cat(q_off_t).cpu().numpy()
-    q_len = q_pcm_all.shape[1]
+    # every rank synthesises only its own slice of the step's queries; the crop offsets (for the hit-rate) are gathered
     my_q = split_even(Q, emu if emu > 1 else world)[rank]
     q_counts = [(hi - lo) * QUERY_SEGS for lo, hi in split_even(Q, world)]
-    pcm_dev = q_pcm_all[my_q[0]:my_q[1]].reshape(-1).contiguous()          # resident in HBM
+    q_pcm_t, q_off_t = [], []
+    for c0 in range(my_q[0], my_q[1], CH):
+        c1 = min(c0 + CH, my_q[1])
+        ids = q_song[c0:c1]
+        qp, qo = synth.make_queries_torch(synth.make_songs_torch(ids, 30.0, device=dev), list(range(c0, c1)), 10.0, args.snr)
+        q_pcm_t.append(qp)
+        q_off_t.append(qo)
+    q_pcm_mine = torch.cat(q_pcm_t)                                         # [my queries, 80000] int16 on the device
+    q_off_mine = torch.cat(q_off_t)
+    if world > 1:
+        q_off = all_gather_ragged(q_off_mine.reshape(-1, 1), [hi - lo for lo, hi in split_even(Q, world)]).reshape(-1).cpu().numpy()
+    else:
+        q_off = np.full(Q, 1e9)                                             # emulation: only rank 0's slice is known
+        q_off[my_q[0]:my_q[1]] = q_off_mine.cpu().numpy()
+    q_len = q_pcm_mine.shape[1]
+    pcm_dev = q_pcm_mine.reshape(-1).contiguous()                           # resident in HBM
     pcm_host = pcm_dev.cpu().pin_memory()                                   # the same bytes as a host hand-over
     starts = (np.arange(my_q[1] - my_q[0], dtype=np.int64)[:, None] * q_len +
               np.arange(QUERY_SEGS, dtype=np.int64)[None, :] * 4000).reshape(-1)
@@ -444,7 +450,7 @@ def main():
         from oracle import native, search as osr, segmenter as osg
         nq_cpu = min(args.cpu_queries, Q)
         db_host = shard.cpu().numpy()
-        q_pcm = q_pcm_all[:nq_cpu].cpu().numpy()
+        q_pcm = q_pcm_mine[:nq_cpu].cpu().numpy()
         native.lib()
         tc = time.perf_counter()
         agree = 0
