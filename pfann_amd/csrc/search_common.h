@@ -34,7 +34,6 @@ struct ScanParams {
     int n_tiles_m;
     int nsub;                // survivor sub-lists per query row (small-batch kernel: 32), else 1
     float *gmax;             // small-batch kernel, group-maximum mode: [nq][gridDim.x * 4]
-    int gch;                 // batched group-maximum pass: db tiles per group
 };
 
 

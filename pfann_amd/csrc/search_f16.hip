@@ -263,15 +263,13 @@ __global__ __launch_bounds__(256, 2) void scan_f16_kernel(ScanParams p) {
 //     15 million device-scope atomics of a db-stationary split cost 5 ms per pass on MI355X
 //     (measured) and are gone.  The select kernels gather the S sub-lists of a row.
 // ------------------------------------------------------------------------------------
-// GMAX = true (sampled pass, no thresholds): no survivor lists at all -- every wave keeps the running maximum of its
-// 64 query rows over GCH consecutive db tiles of its slice and writes one value per (query row, group); the k-th
-// best of a row's group maxima is the score of a real row, hence (minus the rounding margin) a lower bound of its
-// k-th best overall.  One such pass over every 4th row + a radix select of the group maxima replace the dense and
-// 1/16 levels with their two survivor selects, and hand the full pass a threshold of rank ~4k instead of ~16k: a
-// 32x32 block then holds a survivor with probability 0.34 instead of 0.8 (the survivor path was half of the pass).
+// GMAX = true (sampled pass, no thresholds): no survivor lists at all -- every (lane, register) keeps the running maximum
+// of ITS row position over all db tiles of the slice and the kernel writes 128 group maxima per (query row, slice); the
+// k-th best of a row's 128*S group maxima is the score of a real row, hence (minus the rounding margin) a lower bound of its
+// k-th best overall.  One such pass over every 4th row + a radix select of the group maxima replace the dense and 1/16
+// levels with their two survivor selects.  Groups are interleaved on purpose (see gmx in the kernel).
 template <int KS, bool GMAX = false>
 __global__ __launch_bounds__(256, 2) void scan_f16_qres_kernel(ScanParams p) {
-    const int GCH = GMAX ? p.gch : 1;             // db tiles per group (GMAX)
     constexpr int BM = 128, WM = 64, WN = 64, TM = 2, TN = 2;
     constexpr int ROWB = KS * 32;                 // bytes of one fp16 row
     constexpr int CPR = ROWB / 16;                // 16-byte chunks per row
@@ -307,21 +305,27 @@ __global__ __launch_bounds__(256, 2) void scan_f16_qres_kernel(ScanParams p) {
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk)
             afr[i][kk] = __builtin_bit_cast(f16x8, buf_load4(srd_q, (unsigned)(wm * WM + i * 32 + l31) * ROWB + kk * 32 + lhalf * 16));
-    float th[TM], gm[TM];          // tau - eps of this lane's query rows (rows past nq: +inf, never a survivor)
+    float th[TM];                  // tau - eps of this lane's query rows (rows past nq: +inf, never a survivor)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int64_t m = m0 + wm * WM + i * 32 + l31;
         th[i] = GMAX ? 0.f : (m < p.nq ? p.thr[m] : INFINITY);
-        gm[i] = -INFINITY;
     }
+    // GMAX: one running maximum per (query row, tile-row position): register r of lane half h of sub-tile (wn, j) is its
+    // own group, fed by that row position of every tile of the slice (rows 128*S*stride apart): 128 groups per slice
+    // whose members are spread over the whole shard, so a song's run of similar consecutive rows lands in as many
+    // different groups instead of collapsing into one (contiguous groups gave the full pass a rank-1800 threshold on
+    // the real db -- 83 % of its 32x32 blocks held a survivor).
+    f32x16 gmx[GMAX ? TM : 1][GMAX ? TN : 1];
+#pragma unroll
+    for (int i = 0; i < (GMAX ? TM : 1); ++i)
+#pragma unroll
+        for (int j = 0; j < (GMAX ? TN : 1); ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gmx[i][j][r] = -INFINITY;
     f32x16 zero16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
-    const int n_grp = GMAX ? (int)((((t_hi - t_lo + S - 1) / S) + GCH - 1) / GCH) : 0;   // groups of this workgroup's slice
-    const int g_per = GMAX ? (int)((((t_hi + S - 1) / S) + GCH - 1) / GCH) : 0;          // groups per slice (upper bound)
-    int n_in_grp = 0, grp = 0;
-    (void)n_grp;
-
     // ---- db-tile staging straight into LDS (global_load_lds_dwordx4: no staging registers, no
     // ds_write pass).  The LDS image is lane-linear (wave-uniform base + lane*16), so rows cannot be
     // padded; instead 16-byte chunk c of row r is FETCHED by the lane whose slot is c ^ key(r) and
@@ -406,7 +410,8 @@ __global__ __launch_bounds__(256, 2) void scan_f16_qres_kernel(ScanParams p) {
                     mg[g] = fmaxf(fmaxf(acc[i][j][4 * g], acc[i][j][4 * g + 1]), fmaxf(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]));
                 const float mx = fmaxf(fmaxf(mg[0], mg[1]), fmaxf(mg[2], mg[3]));
                 if (GMAX) {
-                    gm[i] = fmaxf(gm[i], mx);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) gmx[i][j][r] = fmaxf(gmx[i][j][r], acc[i][j][r]);
                 } else if (__any(mx >= th[i])) {
                     // Survivors are rare (a 32x32 block holds one with probability ~0.3, almost never two in a lane), so
                     // the path is built from wave-uniform tests per register quad and stores whose offset is out of range
@@ -444,28 +449,32 @@ __global__ __launch_bounds__(256, 2) void scan_f16_qres_kernel(ScanParams p) {
                     }
                 }
             }
-        if (GMAX) {
-            if (++n_in_grp == GCH || t + S >= t_hi) {             // close the group: the two lane halves hold different db rows
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const float v = fmaxf(gm[i], __shfl_xor(gm[i], 32, 64));
-                    const int64_t m = m0 + wm * WM + i * 32 + l31;
-                    if (lhalf == 0 && m < p.nq) p.gmax[m * ((int64_t)S * g_per * 2) + ((int64_t)seg * g_per + grp) * 2 + wn] = v;
-                    gm[i] = -INFINITY;
-                }
-                n_in_grp = 0;
-                ++grp;
-            }
-        }
         __syncthreads();                 // (waits for the tile in flight: vmcnt(0) precedes the barrier)
     }
-    if (GMAX) {       // groups this slice did not reach (shorter slices): never the k-th best
-        for (int gq = grp; gq < g_per; ++gq)
+    if (GMAX) {
+        // group maxima -> LDS [128 query rows][128 slots] (XOR-swizzled by the row: lanes write 32 different rows at the
+        // same slot) -> one coalesced 512 B row per query row: gmax[m][seg * 128 + slot]
+        float *Gs = &Bs[0][0];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int64_t m = m0 + wm * WM + i * 32 + l31;
-                if (lhalf == 0 && m < p.nq) p.gmax[m * ((int64_t)S * g_per * 2) + ((int64_t)seg * g_per + gq) * 2 + wn] = -INFINITY;
-            }
+        for (int i = 0; i < TM; ++i) {
+            const int ml = wm * WM + i * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int slot = ((wn * TN + j) * 16 + r) * 2 + lhalf;
+                    Gs[ml * 128 + (slot ^ (ml & 31))] = gmx[i][j][r];
+                }
+        }
+        __syncthreads();
+        const int64_t G = (int64_t)S * 128;
+        for (int it = 0; it < 16; ++it) {
+            const int idx4 = it * 256 + tid, row = idx4 >> 5, c4 = idx4 & 31;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = Gs[row * 128 + ((4 * c4 + e) ^ (row & 31))];
+            if (m0 + row < p.nq) *reinterpret_cast<f32x4 *>(&p.gmax[(m0 + row) * G + seg * 128 + 4 * c4]) = v;
+        }
         return;
     }
     if (tid < BM && m0 + tid < p.nq) p.cnt[(m0 + tid) * S + seg] = s_cnt[tid];
@@ -487,16 +496,8 @@ int launch_scan_f16_gmax(const void *dbh, int64_t n, int d, int64_t stride, cons
     int S = (int)(2048 / p.n_tiles_m);
     S = S < 1 ? 1 : (S > 32 ? 32 : S);
     if (S > db_tiles) S = (int)db_tiles;
-    // tiles per group: the coarsest grouping that still leaves >= 4 k group maxima per query row (the k-th best of G
-    // maxima is a useful threshold only while most of the top k fall into different groups) and <= 4096 of them
-    int gch = 0, g_per = 0, G = 0;
-    for (int c : {5, 3, 2, 1}) {
-        g_per = (int)(((db_tiles + S - 1) / S + c - 1) / c);
-        G = S * g_per * 2;
-        if (G >= 4 * k && G <= 4096) { gch = c; break; }
-    }
-    if (gch == 0) return 1;
-    p.gch = gch;
+    const int G = S * 128;                   // one group per (slice, row position in the 128-row tile)
+    if (G < 4 * k || db_tiles < 4 * (int64_t)S) return 1;      // >= 4 rows per group
     p.nsub = S;
     p.gmax = reinterpret_cast<float *>(ws.cl);
     ProfScope ps("scan_topk_f16_sample", s, 2.0 * (double)nq * p.nrows * d);
