@@ -373,20 +373,27 @@ __global__ __launch_bounds__(256, 2) void scan_f16_qres_kernel(ScanParams p) {
         if (t + S < t_hi) load_tile(t + S, b ^ 1);
         __builtin_amdgcn_sched_barrier(0);
         f32x16 acc[TM][TN];
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            f16x8 b8[TN];
+        // db fragments one K step ahead of the MFMAs that use them: with four 32-cycle MFMAs per step a wave that reads
+        // its fragments only after issuing the previous step's MFMAs waits out the whole LDS latency every step
+        f16x8 b8[2][TN];
+        auto frag = [&](int kk, int set) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int r = wn * WN + j * 32 + l31;
-                b8[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(
-                                                      &Bs[b][r * (ROWB / 4) + (((kk * 2 + lhalf) ^ key(r)) * 4)]));
+                b8[set][j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(
+                                                           &Bs[b][r * (ROWB / 4) + (((kk * 2 + lhalf) ^ key(r)) * 4)]));
             }
+        };
+        frag(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            if (kk + 1 < KS) frag(kk + 1, (kk + 1) & 1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b8[j], afr[i][kk], kk == 0 ? zero16 : acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b8[kk & 1][j], afr[i][kk], kk == 0 ? zero16 : acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         const int nvalid = (int)(p.nrows - t * 128 < 128 ? p.nrows - t * 128 : 128);
         if (nvalid < 128) {              // last tile (uniform): db rows past the end never count
