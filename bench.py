@@ -386,7 +386,10 @@ def main():
         cnt = ctypes.c_int64(0)
         ms = lib.pfann_prof_elapsed_ms(b"scan_topk", ctypes.byref(cnt))
         us = 1e3 * ms / max(cnt.value, 1)
-        gbs = (r_hi - r_lo) * d * 4 / (us * 1e-6) / 1e9
+        # default: the pass streams the shard's fp16 copy as a pre-filter (exact fp32 re-scoring in the select);
+        # PFANN_SMALL_F32=1: the fp32 rows themselves
+        elt = 4 if os.environ.get("PFANN_SMALL_F32") else 2
+        gbs = (r_hi - r_lo) * d * elt / (us * 1e-6) / 1e9
         call_kernels = {}
         buf1 = ctypes.create_string_buffer(4096)
         lib.pfann_prof_tags(buf1, 4096)
@@ -405,10 +408,11 @@ def main():
             index.search(q19, k)
         torch.cuda.synchronize()
         call_us = 1e6 * (time.perf_counter() - t1) / 200
-        single = {"kernel": "pfann::scan_small_kernel<128,4,0> (one 19-row query vs the whole shard, full pass)",
+        single = {"kernel": "pfann::scan_small_kernel<128,%d,0> (one 19-row query vs the whole shard, full pass%s)"
+                            % (elt, " over the fp16 copy; exact fp32 re-scoring of the survivors follows" if elt == 2 else ""),
                   "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM, "unit": "GB/s",
                   "frac": round(gbs / PEAK_HBM, 4), "pass_us": round(us, 1),
-                  "algorithmic_bytes": (r_hi - r_lo) * d * 4, "search_call_us": round(call_us, 1),
+                  "algorithmic_bytes": (r_hi - r_lo) * d * elt, "search_call_us": round(call_us, 1),
                   "search_call_kernels_us": call_kernels}
         # the whole path for ONE 10 s query (PCM in HBM -> decision on the host), one db pass per query
         n1 = QUERY_SEGS

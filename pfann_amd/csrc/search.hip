@@ -706,8 +706,11 @@ __global__ void fill_empty_kernel(float *D, int64_t *I, int64_t total) {
 //                         row (~R*k survivors) -> 256-thread radix select + rank sort.
 // Four short launches around the one pass that reads the shard; no host synchronisation.
 template <int ELT>
+// db32 != nullptr with ELT == 2: `rows` is the fp16 copy of an fp32 shard -- the scan is a pre-filter with the rigorous
+// margin of q_prep_kernel (half the bytes of the fp32 pass), the select re-scores in exact fp32 like the batched path.
 static int search_small(const void *rows, int64_t n, int d, const void *qrows, int64_t nq, int k, float *D, int64_t *I,
-                        int64_t label_base, const float *q32, SearchWorkspace &ws, hipStream_t s) {
+                        int64_t label_base, const float *q32, const float *db32, SearchWorkspace &ws, hipStream_t s) {
+    const bool prefilter = ELT == 2 && db32 != nullptr;
     ScanParams p;
     p.q = reinterpret_cast<const float *>(qrows); p.db = reinterpret_cast<const float *>(rows);
     p.nq = nq; p.d = d; p.cnt = ws.cnt; p.keys = reinterpret_cast<unsigned long long *>(ws.cl);
@@ -737,14 +740,14 @@ static int search_small(const void *rows, int64_t n, int d, const void *qrows, i
         ProfScope ps("scan_topk_sample", s, p.nrows * bytes_per_row);
         PF_SMALL(1, GRID);
     }
-    if (launch_group_max_select(ws, nq, W, k, 32, false, 0.f, s)) return -1;
-    p.row_stride = 1; p.nrows = n; p.nsub = 32; p.thr = ws.thr; p.gmax = nullptr;
+    if (launch_group_max_select(ws, nq, W, k, 32, prefilter, prefilter ? 2.f : 0.f, s)) return -1;
+    p.row_stride = 1; p.nrows = n; p.nsub = 32; p.thr = prefilter ? ws.thr_adj : ws.thr; p.gmax = nullptr;
     {
         ProfScope ps("scan_topk", s, n * bytes_per_row);
         PF_SMALL(0, GRID);
     }
 #undef PF_SMALL
-    return launch_select_rescore(ws, nq, k, 1, D, I, label_base, q32, nullptr, d, 32, 0, s);
+    return launch_select_rescore(ws, nq, k, 1, D, I, label_base, q32, db32, d, 32, prefilter ? 1 : 0, s);
 }
 
 int search_topk(const float *db, const void *dbh, float xnorm_max, int64_t n, int d, int64_t label_base,
@@ -761,7 +764,12 @@ int search_topk(const float *db, const void *dbh, float xnorm_max, int64_t n, in
     if (db == nullptr && dbh == nullptr) { set_error("search_topk: no rows"); return -1; }
     if (ensure_ws(ws, nq)) return -1;
     const bool half_only = db == nullptr;               // fp16-only storage: s16 scores are final
-    const bool need_qh = half_only || (dbh != nullptr && nq > 64);
+    // <= 32 query rows against an fp32 shard that also keeps its fp16 copy: stream the fp16 rows (half the bytes) as a
+    // pre-filter and re-score exactly; PFANN_SMALL_F32=1 keeps the fp32 streaming pass (A/B timing)
+    static const bool small_f32 = getenv("PFANN_SMALL_F32") != nullptr;
+    const bool small = nq <= 32 && (d == 128 || d == 64);
+    const bool small_pre = small && !half_only && dbh != nullptr && n > CAP && !small_f32;
+    const bool need_qh = half_only || (dbh != nullptr && nq > 64) || small_pre;
     if (need_qh) {
         if (ws.qh_elems < nq * d) {
             if (ws.qh) { PF_HIP(hipStreamSynchronize(s)); (void)hipFree(ws.qh); }
@@ -771,10 +779,11 @@ int search_topk(const float *db, const void *dbh, float xnorm_max, int64_t n, in
         }
         if (launch_q_prep(q, nq, d, xnorm_max, ws.qh, ws.eps, ws.row_ovf, s)) return -1;
     }
-    if (nq <= 32 && (d == 128 || d == 64)) {
+    if (small) {
         int rc;
-        if (half_only) rc = search_small<2>(dbh, n, d, ws.qh, nq, k, D, I, label_base, q, ws, s);
-        else rc = search_small<4>(db, n, d, q, nq, k, D, I, label_base, q, ws, s);
+        if (half_only) rc = search_small<2>(dbh, n, d, ws.qh, nq, k, D, I, label_base, q, nullptr, ws, s);
+        else if (small_pre) rc = search_small<2>(dbh, n, d, ws.qh, nq, k, D, I, label_base, q, db, ws, s);
+        else rc = search_small<4>(db, n, d, q, nq, k, D, I, label_base, q, nullptr, ws, s);
         if (rc) return rc;
         return launch_topk_fallback(ws, q, db, dbh, n, d, nq, k, D, I, label_base, s);
     }
