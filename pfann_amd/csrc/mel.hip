@@ -24,6 +24,7 @@ struct MelArgs {
     const float *window; const float2 *twiddle;
     const int *fb_ptr, *fb_idx; const float *fb_val;
     int fb_nnz;
+    int parts;               // workgroups per segment (small batches: each takes n_frames / parts frames = whole output groups)
     int group_out;           // 0: whole [n_mels][n_frames] tile in LDS; else frames per output group (4, 8 or 16): the
                              // group leaves through a small LDS tile as group_out*4-byte row pieces (3 workgroups / CU)
 };
@@ -74,7 +75,8 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs a) {
     float *s_val = reinterpret_cast<float *>(s_idx + a.fb_nnz);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float *x = a.segs + (a.starts ? a.starts[blockIdx.x] : (int64_t)blockIdx.x * a.seg_stride);
+    const int seg = a.parts > 1 ? (int)blockIdx.x / a.parts : (int)blockIdx.x, part = a.parts > 1 ? (int)blockIdx.x % a.parts : 0;
+    const float *x = a.segs + (a.starts ? a.starts[seg] : (int64_t)seg * a.seg_stride);
 
     for (int j = tid; j < M; j += 256) { const float2 t = a.twiddle[j]; tw_re[j] = t.x; tw_im[j] = t.y; }
     for (int j = tid; j <= a.n_mels; j += 256) s_ptr[j] = a.fb_ptr[j];
@@ -149,7 +151,8 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs a) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) win[n1][e] = radix8 ? a.window[2 * (64 * n1 + lane) + e] : 0.f;
     const int n_groups = (a.n_frames + 3) >> 2;
-    for (int g = 0; g < n_groups; ++g) {
+    const int g_lo = part * (n_groups / a.parts), g_hi = a.parts > 1 ? g_lo + n_groups / a.parts : n_groups;
+    for (int g = g_lo; g < g_hi; ++g) {
         const int t = g * 4 + wave;
         const bool live = t < a.n_frames;
         if (radix8) {
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs a) {
             // output (16-byte pieces made HBM write traffic 4.1x the tensor: partial 64-byte requests)
             __syncthreads();
             const int q4 = a.group_out >> 2;                          // float4 pieces per row
-            float *og = a.out + (int64_t)blockIdx.x * a.n_mels * a.n_frames + (4 * g + 4 - a.group_out);
+            float *og = a.out + (int64_t)seg * a.n_mels * a.n_frames + (4 * g + 4 - a.group_out);
             for (int i = tid; i < a.n_mels * q4; i += 256) {
                 const int m = i / q4, c = i - m * q4;
                 const float *tr = tile + m * tp + 4 * c;
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelArgs a) {
         __syncthreads();
         sub = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     }
-    float *o = a.out + (int64_t)blockIdx.x * a.n_mels * a.n_frames;
+    float *o = a.out + (int64_t)seg * a.n_mels * a.n_frames;
     if (256 % a.n_frames == 0) {          // thread -> fixed frame, mel rows advance by 256 / n_frames: no divisions
         const int tf = tid % a.n_frames, mstep = 256 / a.n_frames;
         int m = tid / a.n_frames;
@@ -349,11 +352,17 @@ int launch_melspec(const MelPlan &mp, const float *segs, int64_t B, int64_t seg_
             if (mp.n_frames % gf == 0 && (a.group_out == 0 ? (3 * lds_for(gf) <= 160 * 1024 || gf == 4) : false)) a.group_out = gf;
     }
     if (getenv("PFANN_MEL_GROUP")) a.group_out = atoi(getenv("PFANN_MEL_GROUP"));
+    // small batches (one query = 19 segments): a workgroup per output group instead of per segment, so that the launch
+    // covers more than a handful of CUs; same arithmetic in the same order (every workgroup recomputes the segment statistics)
+    a.parts = 1;
+    if (a.group_out && B <= 192 && mp.n_frames % a.group_out == 0 && (mp.n_frames / a.group_out) * a.group_out == mp.n_frames &&
+        a.group_out % 4 == 0 && mp.n_frames % 4 == 0)
+        a.parts = mp.n_frames / a.group_out;
     const size_t lds = lds_for(a.group_out);
     if (lds > 160 * 1024) { set_error("melspec: LDS need %zu B > 160 KiB", lds); return -1; }
     if (ensure_dyn_lds((const void *)melspec_kernel, 160 * 1024)) return -1;
     ProfScope ps("melspec", s);
-    PF_LAUNCH(melspec_kernel, dim3((unsigned)B), dim3(256), lds, s, a);
+    PF_LAUNCH(melspec_kernel, dim3((unsigned)(B * a.parts)), dim3(256), lds, s, a);
     PF_HIP(hipGetLastError());
     return 0;
 }
