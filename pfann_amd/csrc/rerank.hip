@@ -108,7 +108,42 @@ __global__ __launch_bounds__(NT) void match_kernel(RerankArgs a) {
         __syncthreads();
         // ---- sort ascending (== lexicographic candidate order of the reference)
         bitonic_sort_keys<NT>(sk, P, tid);
-        // ---- dedup (np.unique / std::unique): blank repeats, re-sort, count survivors
+        // ---- dedup (np.unique / std::unique).  Lists of <= 8 keys per thread: order-preserving compaction (each thread
+        // takes a run of consecutive keys into registers, a block-wide exclusive scan of the unique counts gives the
+        // destinations) instead of blanking the repeats and sorting a second time; longer lists keep the second sort.
+        if (P <= 8 * NT) {
+            __shared__ int s_wtot[NT / 64];
+            const int ept = P >= NT ? P / NT : 1;
+            unsigned long long kreg[8];
+            int cnt_u = 0;
+            unsigned umask = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int i = tid * ept + e;
+                kreg[e] = SENT;
+                if (e < ept && i < P) {
+                    kreg[e] = sk[i];
+                    const bool u = kreg[e] != SENT && (i == 0 || kreg[e] != sk[i - 1]);
+                    if (u) { umask |= 1u << e; ++cnt_u; }
+                }
+            }
+            int incl = cnt_u;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += v;
+            }
+            if (lane == 63) s_wtot[wave] = incl;
+            __syncthreads();                      // every key is in registers: the list may be overwritten
+            int base = 0, total = 0;
+            for (int w = 0; w < NT / 64; ++w) { const int v = s_wtot[w]; if (w < wave) base += v; total += v; }
+            int pos = base + incl - cnt_u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (umask & (1u << e)) sk[pos++] = kreg[e];
+            if (tid == 0) s_nc = total;
+            __syncthreads();
+        } else {
         int *dupf = reinterpret_cast<int *>(score);
         for (int i = tid; i < P; i += NT) dupf[i] = (i > 0 && sk[i] == sk[i - 1]) ? 1 : 0;
         __syncthreads();
@@ -119,6 +154,7 @@ __global__ __launch_bounds__(NT) void match_kernel(RerankArgs a) {
         for (int i = tid; i < P; i += NT)
             if (sk[i] != SENT && (i + 1 == P || sk[i + 1] == SENT)) s_nc = i + 1;
         __syncthreads();
+        }
         nc = s_nc;
         if (a.phase == 1) {          // phased launch: the sorted unique keys go to / stay in gkeys
             if (in_lds) {
