@@ -358,6 +358,124 @@ __global__ __launch_bounds__(512, 4) void kpers(const float *__restrict__ x, con
     if (ts != nullptr && tid == 0) { ts[blockIdx.x * 4] = c_loop; ts[blockIdx.x * 4 + 1] = c_epi; ts[blockIdx.x * 4 + 2] = c_first; ts[blockIdx.x * 4 + 3] = n_t; }
 }
 
+// Three 4-wave workgroups per CU: 64x128 tiles (four 64x32 wave tiles), LDS rows unpadded and XOR-swizzled by the row
+// (chunk c of row r lives at chunk c ^ (r & 7)): 2 x (64 + 128) x 128 B = 48 KB per workgroup, 144 KB per CU.  Three
+// barrier domains instead of two at the same MFMAs per barrier; the weight tile is re-read per 64 rows instead of 128.
+// EPI 1: direct stores; 2: the 64x128 output tile through LDS, whole 512 B rows.
+template <int EPI>
+__global__ __launch_bounds__(256, 3) void k3(const float *__restrict__ x, const float *__restrict__ lw, const float *__restrict__ lb,
+                                             const float *__restrict__ w, const float *__restrict__ stats, float *__restrict__ y,
+                                             float *__restrict__ part, int nk, int rps_out) {
+    constexpr int BM = 64, BN = 128, C = 128;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem, *Bs = smem + 2 * BM * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int l31 = lane & 31, lhalf = lane >> 5, col4 = tid & 7, rowq = tid >> 3;     // rowq 0..31
+    const int m0 = blockIdx.x * BM;
+    const int b = m0 / rps_out, r0 = m0 % rps_out;
+    const int rps_in = 2 * rps_out;
+    const float mu = stats[2 * b], rs = stats[2 * b + 1];
+    const __amdgpu_buffer_rsrc_t sx = srd(x + (int64_t)b * rps_in * C, (uint64_t)rps_in * C * 4);
+    const __amdgpu_buffer_rsrc_t slw = srd(lw, (uint64_t)rps_in * C * 4), slb = srd(lb, (uint64_t)rps_in * C * 4);
+    const __amdgpu_buffer_rsrc_t sw = srd(w, (uint64_t)BN * nk * 32 * 4);
+    unsigned va[2], vb[4];
+    int arow[2];
+    for (int i = 0; i < 2; ++i) arow[i] = 2 * (r0 + rowq + 32 * i) - 1;
+    for (int j = 0; j < 4; ++j) vb[j] = (unsigned)(rowq + 32 * j) * (unsigned)(nk * 32) * 4u + col4 * 16u;
+    auto offs = [&](int tap) {
+        for (int i = 0; i < 2; ++i) va[i] = (unsigned)(arow[i] + tap) < (unsigned)rps_in ? (unsigned)((arow[i] + tap) * C + col4 * 4) * 4u : 0x80000000u;
+    };
+    int tapA = 0, cA = 0, tap = 0, c = 0;
+    unsigned vaA[2], vaL[2];
+    offs(0); vaA[0] = va[0]; vaA[1] = va[1]; vaL[0] = va[0]; vaL[1] = va[1];
+    f32x4 ra[2][2], rw[2], rbb[2], rb[4];
+    auto load_A = [&](int par) {
+        for (int i = 0; i < 2; ++i) ra[par][i] = ld4(sx, vaA[i], cA * 4);
+        cA += 32;
+        if (cA >= C) { cA = 0; ++tapA; offs(tapA); vaA[0] = va[0]; vaA[1] = va[1]; }
+    };
+    auto load_tile = [&]() {
+        for (int i = 0; i < 2; ++i) { rw[i] = ld4(slw, vaL[i], c * 4); rbb[i] = ld4(slb, vaL[i], c * 4); }
+        for (int j = 0; j < 4; ++j) rb[j] = ld4(sw, vb[j], (tap * C + c) * 4);
+        c += 32;
+        if (c >= C) { c = 0; ++tap; offs(tap); vaL[0] = va[0]; vaL[1] = va[1]; }
+    };
+    const int sw4 = (col4 ^ (rowq & 7)) * 4;            // (rowq + 32 i) & 7 == rowq & 7
+    auto store_tile = [&](float *Ad, float *Bd, int par) {
+        for (int i = 0; i < 2; ++i) {
+            f32x4 v;
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf((ra[par][i][e] - mu) * rs, rw[i][e], rbb[i][e]), 0.f);
+            *reinterpret_cast<f32x4 *>(&Ad[(rowq + 32 * i) * 32 + sw4]) = v;
+        }
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4 *>(&Bd[(rowq + 32 * j) * 32 + sw4]) = rb[j];
+    };
+    f32x16 acc[2];
+    for (int i = 0; i < 2; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    load_A(0);
+    load_tile();
+    store_tile(As, Bs, 0);
+    if (nk > 1) load_A(1);
+    if (nk > 2) load_A(0);
+    __syncthreads();
+    auto ktile = [&](int kt, int PB) {
+        const float *Ac = As + PB * (BM * 32), *Bc = Bs + PB * (BN * 32);
+        float *An = As + (PB ^ 1) * (BM * 32), *Bn = Bs + (PB ^ 1) * (BN * 32);
+        const bool more = kt + 1 < nk;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int ch = ((kk * 2 + lhalf) ^ (l31 & 7)) * 4;
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(&Ac[l31 * 32 + ch]);
+            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(&Ac[(32 + l31) * 32 + ch]);
+            const f32x4 b0 = *reinterpret_cast<const f32x4 *>(&Bc[(wn * 32 + l31) * 32 + ch]);
+            if (kk == 0) { if (more) load_tile(); __builtin_amdgcn_sched_barrier(0); }
+            if (kk == 3) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) store_tile(An, Bn, PB ^ 1);
+                if (kt + 3 < nk) load_A(PB ^ 1);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[s], a0[s], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[s], a1[s], acc[1], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    };
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) { ktile(kt, 0); ktile(kt + 1, 1); }
+    if (kt < nk) ktile(kt, 0);
+    const __amdgpu_buffer_rsrc_t sy = srd(y + (int64_t)m0 * BN, (uint64_t)BM * BN * 4);
+    float a1s[2] = {0.f, 0.f}, a2s[2] = {0.f, 0.f};
+    constexpr int LDC = 132;
+    float *Cs = smem;
+    for (int i = 0; i < 2; ++i) {
+        const unsigned ro = (unsigned)(i * 32 + l31) * (BN * 4u);
+        for (int g = 0; g < 4; ++g) {
+            f32x4 z4;
+            for (int e = 0; e < 4; ++e) { const float z = acc[i][4 * g + e] + 0.5f; a1s[i] += z; a2s[i] = fmaf(z, z, a2s[i]); z4[e] = z; }
+            if (EPI == 1) st4(sy, ro + (unsigned)(wn * 32 + 8 * g + 4 * lhalf) * 4u, z4);
+            else *reinterpret_cast<f32x4 *>(&Cs[(i * 32 + l31) * LDC + wn * 32 + 8 * g + 4 * lhalf]) = z4;
+        }
+    }
+    float *red = smem + 64 * LDC;
+    for (int i = 0; i < 2; ++i) {
+        const float a1 = a1s[i] + __shfl_xor(a1s[i], 32, 64), a2 = a2s[i] + __shfl_xor(a2s[i], 32, 64);
+        if (lhalf == 0) { red[(i * 32 + l31) * 4 + wn] = a1; red[256 + (i * 32 + l31) * 4 + wn] = a2; }
+    }
+    __syncthreads();
+    if (EPI == 2)
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 8 + wn * 2 + lhalf;
+            st4(sy, (unsigned)row * (BN * 4u) + l31 * 16u, *reinterpret_cast<const f32x4 *>(&Cs[row * LDC + l31 * 4]));
+        }
+    if (tid < 64) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int q = 0; q < 4; ++q) { t1 += red[tid * 4 + q]; t2 += red[256 + tid * 4 + q]; }
+        for (int o = 32; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o, 64); t2 += __shfl_xor(t2, o, 64); }
+        if (lane == 0) { part[blockIdx.x * 2] = t1; part[blockIdx.x * 2 + 1] = t2; }
+    }
+}
+
 __global__ void fill(float *p, size_t n, float scale, float bias) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         unsigned h = (unsigned)i * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
@@ -404,6 +522,17 @@ int main(int argc, char **argv) {
     TT("PF: full loop + LDS-staged row stores + stats", 2, 15, true, true);
     T("no operands + direct stores", 1, 0, false);
     T("no operands + LDS-staged row stores", 2, 0, false);
+    for (int epi = 1; epi <= 2; ++epi) {
+        const size_t lds3 = 48 * 1024;
+        auto kq = epi == 1 ? k3<1> : k3<2>;
+        (void)hipFuncSetAttribute((const void *)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+        hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        const int nt3 = (int)(M / 64);
+        hipLaunchKernelGGL(kq, dim3(nt3), dim3(256), lds3, 0, x, lw, lb, w, stats, y, part, nk, rps_out); (void)hipDeviceSynchronize();
+        (void)hipEventRecord(e0); for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kq, dim3(nt3), dim3(256), lds3, 0, x, lw, lb, w, stats, y, part, nk, rps_out);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+        printf("3 x 4-wave workgroups/CU, 64x128 tiles, %-22s %8.3f ms  %6.1f TFLOP/s  %.3f  %s\n", epi == 1 ? "direct stores + stats" : "row stores + stats", ms, flop / ms / 1e9, flop / ms / 1e9 / 157.3, hipGetErrorString(hipGetLastError()));
+    }
     unsigned long long *pts; (void)hipMalloc(&pts, 512 * 32);
     for (int delay = 0; delay <= 30000; delay += 30000) {
         auto kq = kpers<true>;
