@@ -264,8 +264,8 @@ __global__ __launch_bounds__(256, 2) void scan_f16_kernel(ScanParams p) {
 //     (measured) and are gone.  The select kernels gather the S sub-lists of a row.
 // ------------------------------------------------------------------------------------
 // GMAX = true (sampled pass, no thresholds): no survivor lists at all -- every (lane, register) keeps the running maximum
-// of ITS row position over all db tiles of the slice and the kernel writes 128 group maxima per (query row, slice); the
-// k-th best of a row's 128*S group maxima is the score of a real row, hence (minus the rounding margin) a lower bound of its
+// of ITS row position over all db tiles of the slice and the kernel writes 64 group maxima per (query row, slice); the
+// k-th best of a row's 64*S group maxima is the score of a real row, hence (minus the rounding margin) a lower bound of its
 // k-th best overall.  One such pass over every 4th row + a radix select of the group maxima replace the dense and 1/16
 // levels with their two survivor selects.  Groups are interleaved on purpose (see gmx in the kernel).
 template <int KS, bool GMAX = false>
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void scan_f16_qres_kernel(ScanParams p) {
         th[i] = GMAX ? 0.f : (m < p.nq ? p.thr[m] : INFINITY);
     }
     // GMAX: one running maximum per (query row, tile-row position): register r of lane half h of sub-tile (wn, j) is its
-    // own group, fed by that row position of every tile of the slice (rows 128*S*stride apart): 128 groups per slice
+    // own group, fed by that row position of every tile of the slice (rows 128*S*stride apart; the two lane halves are merged at the end): 64 groups per slice
     // whose members are spread over the whole shard, so a song's run of similar consecutive rows lands in as many
     // different groups instead of collapsing into one (contiguous groups gave the full pass a rank-1800 threshold on
     // the real db -- 83 % of its 32x32 blocks held a survivor).
@@ -459,8 +459,9 @@ __global__ __launch_bounds__(256, 2) void scan_f16_qres_kernel(ScanParams p) {
         __syncthreads();                 // (waits for the tile in flight: vmcnt(0) precedes the barrier)
     }
     if (GMAX) {
-        // group maxima -> LDS [128 query rows][128 slots] (XOR-swizzled by the row: lanes write 32 different rows at the
-        // same slot) -> one coalesced 512 B row per query row: gmax[m][seg * 128 + slot]
+        // group maxima -> LDS [128 query rows][64 slots] (the two lane halves of a register are merged: 64 groups per
+        // slice; XOR-swizzled by the row: lanes write 32 different rows at the same slot) -> one coalesced 256 B row per
+        // query row: gmax[m][seg * 64 + slot]
         float *Gs = &Bs[0][0];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -469,18 +470,19 @@ __global__ __launch_bounds__(256, 2) void scan_f16_qres_kernel(ScanParams p) {
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int slot = ((wn * TN + j) * 16 + r) * 2 + lhalf;
-                    Gs[ml * 128 + (slot ^ (ml & 31))] = gmx[i][j][r];
+                    const float v = fmaxf(gmx[i][j][r], __shfl_xor(gmx[i][j][r], 32, 64));
+                    const int slot = (wn * TN + j) * 16 + r;
+                    if (lhalf == 0) Gs[ml * 64 + (slot ^ (ml & 31))] = v;
                 }
         }
         __syncthreads();
-        const int64_t G = (int64_t)S * 128;
-        for (int it = 0; it < 16; ++it) {
-            const int idx4 = it * 256 + tid, row = idx4 >> 5, c4 = idx4 & 31;
+        const int64_t G = (int64_t)S * 64;
+        for (int it = 0; it < 8; ++it) {
+            const int idx4 = it * 256 + tid, row = idx4 >> 4, c4 = idx4 & 15;
             f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = Gs[row * 128 + ((4 * c4 + e) ^ (row & 31))];
-            if (m0 + row < p.nq) *reinterpret_cast<f32x4 *>(&p.gmax[(m0 + row) * G + seg * 128 + 4 * c4]) = v;
+            for (int e = 0; e < 4; ++e) v[e] = Gs[row * 64 + ((4 * c4 + e) ^ (row & 31))];
+            if (m0 + row < p.nq) *reinterpret_cast<f32x4 *>(&p.gmax[(m0 + row) * G + seg * 64 + 4 * c4]) = v;
         }
         return;
     }
@@ -503,7 +505,7 @@ int launch_scan_f16_gmax(const void *dbh, int64_t n, int d, int64_t stride, cons
     int S = (int)(2048 / p.n_tiles_m);
     S = S < 1 ? 1 : (S > 32 ? 32 : S);
     if (S > db_tiles) S = (int)db_tiles;
-    const int G = S * 128;                   // one group per (slice, row position in the 128-row tile)
+    const int G = S * 64;                    // one group per (slice, row position in the 128-row tile up to the lane half)
     if (G < 4 * k || db_tiles < 4 * (int64_t)S) return 1;      // >= 4 rows per group
     p.nsub = S;
     p.gmax = reinterpret_cast<float *>(ws.cl);
