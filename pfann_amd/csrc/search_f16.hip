@@ -311,11 +311,11 @@ __global__ __launch_bounds__(256, 2) void scan_f16_qres_kernel(ScanParams p) {
         const int64_t m = m0 + wm * WM + i * 32 + l31;
         th[i] = GMAX ? 0.f : (m < p.nq ? p.thr[m] : INFINITY);
     }
-    // GMAX: one running maximum per (query row, tile-row position): register r of lane half h of sub-tile (wn, j) is its
-    // own group, fed by that row position of every tile of the slice (rows 128*S*stride apart; the two lane halves are merged at the end): 64 groups per slice
-    // whose members are spread over the whole shard, so a song's run of similar consecutive rows lands in as many
-    // different groups instead of collapsing into one (contiguous groups gave the full pass a rank-1800 threshold on
-    // the real db -- 83 % of its 32x32 blocks held a survivor).
+    // GMAX: one running maximum per (query row, tile-row position): register r of sub-tile (wn, j) is its own group, fed
+    // by that row position of every tile of the slice (rows 128*S*stride apart; the two lane halves are merged at the
+    // end): 64 groups per slice whose members are spread over the whole shard, so a song's run of similar consecutive
+    // rows lands in as many different groups instead of collapsing into one or two contiguous ones (which would push
+    // the k-th best group maximum, i.e. the threshold, far down on a db of real music).
     f32x16 gmx[GMAX ? TM : 1][GMAX ? TN : 1];
 #pragma unroll
     for (int i = 0; i < (GMAX ? TM : 1); ++i)
