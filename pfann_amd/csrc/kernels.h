@@ -67,13 +67,26 @@ struct SearchWorkspace {
     float *eps = nullptr;      // [cap_q] per-row bound of |s16 - s|
     void *qh = nullptr;        // [cap_q][d] fp16 query rows
     int64_t qh_elems = 0;
+    // two-phase search of a song-sharded job (search_topk phase 1 -> all-reduce MAX of the bounds -> phase 2): what
+    // phase 1 left behind, valid for exactly this (q, nq, k)
+    const float *bound_q = nullptr;
+    int64_t bound_nq = 0;
+    int bound_k = 0, bound_G = 0;
+    bool bound_valid = false;
 };
 // db != nullptr: fp32 rows, exact results; dbh != nullptr additionally: fp16 copy of the rows for the pre-filter path
 // (batches > 64 rows), xnorm_max = largest row norm of db.
 // db == nullptr (fp16-only storage, pfann_db_set_storage): scores are s16 = sum fl16(q_i) * fl16(x_i) accumulated in
 // fp32, no fp32 re-scoring.  Fully asynchronous on `s`: no host synchronisation inside.
+// phase 0: the whole search.  Song-sharded jobs split it around one collective (pfann_search_bound / _bounded):
+//   phase 1: query preparation + sampled group-maximum pass + group select only; lb[m] = a lower bound of the TRUE k-th
+//            best score of query row m over this shard (-inf where this path has no sampled threshold);
+//   phase 2: lb[m] = lower bound of the k-th best over ALL shards (max over the ranks' phase-1 values): the full pass
+//            emits only rows that can be in the global top-k, so D / I may hold fewer than k entries (padded) -- the
+//            merge of the shards' lists is still the exact global top-k.
 int search_topk(const float *db, const void *dbh, float xnorm_max, int64_t n, int d, int64_t label_base,
-                const float *q, int64_t nq, int k, float *D, int64_t *I, SearchWorkspace &ws, hipStream_t s);
+                const float *q, int64_t nq, int k, float *D, int64_t *I, SearchWorkspace &ws, hipStream_t s,
+                int phase = 0, float *lb = nullptr);
 int topk_merge(const float *S, const int64_t *L, int64_t nq, int m, int k, float *D, int64_t *I,
                hipStream_t s);
 

@@ -750,12 +750,34 @@ static int search_small(const void *rows, int64_t n, int d, const void *qrows, i
     return launch_select_rescore(ws, nq, k, 1, D, I, label_base, q32, db32, d, 32, prefilter ? 1 : 0, s);
 }
 
+// phase 1 -> lb[m] = tau_m - eps_m (the k-th best group maximum is the s16 score of a real row, whose true score is
+// within eps of it); no sampled threshold on this path: -inf
+__global__ void bound_out_kernel(const float *__restrict__ thr, const float *__restrict__ eps, float margin, float *lb, int64_t nq) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < nq) lb[m] = thr == nullptr ? -INFINITY : thr[m] - margin * eps[m];
+}
+// phase 2: rows of this shard whose true score reaches the global bound have s16 >= lb - eps
+__global__ void bound_in_kernel(float *__restrict__ thr_adj, const float *__restrict__ eps, float margin, const float *__restrict__ lb,
+                                int64_t nq) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < nq) thr_adj[m] = fmaxf(thr_adj[m], lb[m] - margin * eps[m]);
+}
+
 int search_topk(const float *db, const void *dbh, float xnorm_max, int64_t n, int d, int64_t label_base,
-                const float *q, int64_t nq, int k, float *D, int64_t *I, SearchWorkspace &ws, hipStream_t s) {
+                const float *q, int64_t nq, int k, float *D, int64_t *I, SearchWorkspace &ws, hipStream_t s,
+                int phase, float *lb) {
     if (nq <= 0) return 0;
+    const bool resume = phase == 2 && ws.bound_valid && ws.bound_q == q && ws.bound_nq == nq && ws.bound_k == k;
+    if (phase != 2 || !resume) ws.bound_valid = false;
+    auto no_bound = [&]() -> int {               // phase 1 on a path without a sampled threshold
+        PF_LAUNCH(bound_out_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, s, (const float *)nullptr, (const float *)nullptr, 0.f, lb, nq);
+        PF_HIP(hipGetLastError());
+        return 0;
+    };
     if (k < 1 || k > 1024) { set_error("search_topk: k=%d outside 1..1024", k); return -1; }
     if (d % 4 != 0) { set_error("search_topk: d=%d must be a multiple of 4", d); return -1; }
     if (n >= (1ll << 32)) { set_error("search_topk: shard rows %lld >= 2^32", (long long)n); return -1; }
+    if (n == 0 && phase == 1) return no_bound();
     if (n == 0) {
         PF_LAUNCH(fill_empty_kernel, dim3((unsigned)cdiv(nq * k, 256)), dim3(256), 0, s, D, I, nq * k);
         PF_HIP(hipGetLastError());
@@ -777,9 +799,10 @@ int search_topk(const float *db, const void *dbh, float xnorm_max, int64_t n, in
             PF_HIP(hipMalloc(&ws.qh, (size_t)nq * d * 2));
             ws.qh_elems = nq * d;
         }
-        if (launch_q_prep(q, nq, d, xnorm_max, ws.qh, ws.eps, ws.row_ovf, s)) return -1;
+        if (!resume && launch_q_prep(q, nq, d, xnorm_max, ws.qh, ws.eps, ws.row_ovf, s)) return -1;
     }
     if (small) {
+        if (phase == 1) return no_bound();
         int rc;
         if (half_only) rc = search_small<2>(dbh, n, d, ws.qh, nq, k, D, I, label_base, q, nullptr, ws, s);
         else if (small_pre) rc = search_small<2>(dbh, n, d, ws.qh, nq, k, D, I, label_base, q, db, ws, s);
@@ -806,16 +829,30 @@ int search_topk(const float *db, const void *dbh, float xnorm_max, int64_t n, in
             // one group-maximum pass over every 4th row instead of the dense + 1/16 survivor levels; shards too small
             // to give 4 k groups at that stride (the 1/4 and 1/8 shards of a multi-GPU job) are sampled more densely
             int G = 0, rc = 1;
-            if (k <= 128 && getenv("PFANN_NO_GMAX") == nullptr)
+            const float margin = rescore ? 1.f : 0.f;
+            if (resume) { G = ws.bound_G; rc = 0; }
+            else if (k <= 128 && getenv("PFANN_NO_GMAX") == nullptr)
                 for (int64_t gs = 4; gs >= 1 && rc == 1; gs >>= 1) rc = launch_scan_f16_gmax(dbh, n, d, gs, ws.qh, nq, k, ws, &G, s);
             if (rc < 0) return -1;
             if (rc == 0) {
-                if (launch_group_max_select(ws, nq, G, k, 0, true, rescore ? 2.f : 0.f, s)) return -1;
+                if (!resume && launch_group_max_select(ws, nq, G, k, 0, true, rescore ? 2.f : 0.f, s)) return -1;
+                if (phase == 1) {
+                    PF_LAUNCH(bound_out_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, s, ws.thr, ws.eps, margin, lb, nq);
+                    PF_HIP(hipGetLastError());
+                    ws.bound_valid = true; ws.bound_q = q; ws.bound_nq = nq; ws.bound_k = k; ws.bound_G = G;
+                    return 0;
+                }
+                if (resume && lb != nullptr) {
+                    PF_LAUNCH(bound_in_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, s, ws.thr_adj, ws.eps, margin, lb, nq);
+                    PF_HIP(hipGetLastError());
+                    ws.bound_valid = false;
+                }
                 int nsub = 1;
                 if (launch_scan_f16(dbh, n, d, 1, ws.qh, nq, ws.thr_adj, ws, true, &nsub, s)) return -1;
                 if (launch_select_rescore(ws, nq, k, 1, D, I, label_base, q, db, d, nsub, rescore, s)) return -1;
                 return launch_topk_fallback(ws, q, db, dbh, n, d, nq, k, D, I, label_base, s);
             }
+            if (phase == 1) return no_bound();
         }
         const float *ta = nullptr;
         for (int lev = levels; lev >= 1; --lev) {
@@ -830,6 +867,7 @@ int search_topk(const float *db, const void *dbh, float xnorm_max, int64_t n, in
         if (launch_select_rescore(ws, nq, k, 1, D, I, label_base, q, db, d, nsub, rescore, s)) return -1;
         return launch_topk_fallback(ws, q, db, dbh, n, d, nq, k, D, I, label_base, s);
     }
+    if (phase == 1) return no_bound();
     const float *thr = nullptr;
     for (int lev = levels; lev >= 1; --lev) {
         if (launch_scan(db, n, d, stride, q, nq, thr, ws, s)) return -1;

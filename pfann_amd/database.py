@@ -86,6 +86,31 @@ class DeviceIndex:
                                                 self._stream()), "pfann_search_topk")
         return D, I
 
+    BOUND_CHUNK = 16384        # query rows per pfann_search_bound / pfann_search_topk_bounded call
+
+    def search_bound(self, q, k):
+        """First half of a sharded search (<= BOUND_CHUNK rows): -> lb [nq] f32 on the device, a lower bound of every
+        row's k-th best score over THIS shard (-inf where no sampled threshold exists).  To be MAX-reduced over the ranks
+        and handed to search_bounded with the same q and k."""
+        nq = q.shape[0]
+        lb = torch.empty((nq,), device=self.device, dtype=torch.float32)
+        if nq:
+            _l.check(self.lib.pfann_search_bound(self.handle, q.data_ptr(), nq, k, lb.data_ptr(), self._stream()),
+                     "pfann_search_bound")
+        return lb
+
+    def search_bounded(self, q, k, lb):
+        """Second half: (D, I) of this shard restricted to rows that can be in the global top-k (padded with
+        -FLT_MAX / -1); q must be the very tensor search_bound was given."""
+        nq = q.shape[0]
+        D = torch.empty((nq, k), device=self.device, dtype=torch.float32)
+        I = torch.empty((nq, k), device=self.device, dtype=torch.int64)
+        if nq:
+            _l.check(self.lib.pfann_search_topk_bounded(self.handle, q.data_ptr(), nq, k, lb.contiguous().data_ptr(),
+                                                        D.data_ptr(), I.data_ptr(), self._stream()),
+                     "pfann_search_topk_bounded")
+        return D, I
+
     def merge_topk(self, S, L, k):
         nq, m = S.shape
         D = torch.empty((nq, k), device=self.device, dtype=torch.float32)

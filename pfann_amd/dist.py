@@ -67,6 +67,17 @@ def all_to_all_rows(x, group=None):
     return out
 
 
+def all_reduce_max(x, group=None):
+    """In-place MAX all-reduce of a float tensor."""
+    if x.is_cuda and dist.get_backend(group) == "gloo":       # debugging on one GPU: stage through host
+        h = x.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+        x.copy_(h)
+        return x
+    dist.all_reduce(x, op=dist.ReduceOp.MAX, group=group)
+    return x
+
+
 def all_gather_ragged(x, counts, group=None):
     """Rows split unevenly over ranks (counts[r] rows on rank r) -> concatenated [sum, ...]."""
     world = dist.get_world_size(group)
@@ -98,10 +109,23 @@ class ShardedIndex:
         The merge is itself distributed: rank r merges the per-shard lists of query slice r (all-to-all),
         then the merged slices are all-gathered -- every rank receives 2*Q*k entries instead of G*Q*k
         (an all-gather of everything was 93 MB per rank and step at 8 GPUs) and merges 1/G of the rows."""
-        D, I = self.b.search(q, self.k)
         G, k, Q = self.world, self.k, q.shape[0]
         if G == 1:
-            return D, I
+            return self.b.search(q, k)
+        # Two-phase shard search: every rank bounds each row's k-th best over ITS shard from the sampled pass, the bounds
+        # are MAX-reduced (the k-th best over all shards is at least the best of them; 4 bytes per row), and the full pass
+        # then emits only rows that can be in the GLOBAL top-k.  Without it every shard digs out its own complete top-k:
+        # the survivor density per db row -- what the scan's epilogue and the select pay for -- grows with the number of
+        # shards (8 shards: almost every 32x32 block of the scan holds a survivor).
+        q = q.contiguous()
+        Dl, Il = [], []
+        for c0 in range(0, Q, self.b.BOUND_CHUNK):
+            qc = q[c0:c0 + self.b.BOUND_CHUNK]
+            lb = all_reduce_max(self.b.search_bound(qc, k), self.group)
+            Dc, Ic = self.b.search_bounded(qc, k, lb)
+            Dl.append(Dc)
+            Il.append(Ic)
+        D, I = torch.cat(Dl), torch.cat(Il)
         Qs = (Q + G - 1) // G
         pad = Qs * G - Q
         if pad:

@@ -29,6 +29,25 @@ class OracleIndex:
         I = np.where(I >= 0, I + self.label_base, -1)
         return torch.from_numpy(D), torch.from_numpy(I)
 
+    # ---- two-phase sharded search (pfann_search_bound / pfann_search_topk_bounded): the oracle's bound is the shard's
+    # exact k-th best (the tightest legal one; -inf when the shard has fewer than k rows), its bounded search drops
+    # every entry below the reduced bound
+    BOUND_CHUNK = 7            # small on purpose: the gloo tests walk several chunks
+
+    def search_bound(self, q, k):
+        D, _ = osr.flat_ip_topk(q.numpy(), self.emb, k)
+        lb = np.where(D[:, k - 1] > -np.finfo(np.float32).max, D[:, k - 1], -np.inf).astype(np.float32) if D.shape[1] >= k else \
+            np.full(q.shape[0], -np.inf, np.float32)
+        return torch.from_numpy(lb)
+
+    def search_bounded(self, q, k, lb):
+        D, I = self.search(q, k)
+        D, I = D.numpy().copy(), I.numpy().copy()
+        drop = D < lb.numpy()[:, None]
+        D[drop] = -np.finfo(np.float32).max
+        I[drop] = -1
+        return torch.from_numpy(D), torch.from_numpy(I)
+
     def merge_topk(self, S, L, k):
         S, L = S.numpy(), L.numpy()
         D = np.full((S.shape[0], k), -np.finfo(np.float32).max, np.float32)

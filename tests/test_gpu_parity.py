@@ -753,3 +753,53 @@ def test_winner_keys_pack_and_pick_vs_numpy_statement(torch_cuda):
         if c:
             b = min(c)
             assert (got["shift"][j], got["song"][j], got["offset"][j]) == b[1:], j
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_two_phase_sharded_search_is_the_exact_global_topk(torch_cuda, storage):
+    """pfann_search_bound on every shard -> MAX over the shards -> pfann_search_topk_bounded -> pfann_topk_merge equals
+    the search over the unsplit db (labels and scores), each shard's bound is a true lower bound of its k-th best, and no
+    shard emits a row below the reduced bound."""
+    torch = torch_cuda
+    from pfann_amd.database import DeviceIndex
+    d, n, nq, k = 128, 150000, 2100, 100
+    db = synth.unit_rows(71, "t/2p", n, d)
+    # songs: runs of 40 similar consecutive rows, so that true matches cluster inside one shard
+    for s0 in range(0, n, 40):
+        db[s0:s0 + 40] = db[s0] + 0.6 * db[s0:s0 + 40]
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    q = synth.unit_rows(72, "t/2pq", nq, d)
+    q[::2] = db[(np.arange(len(q[::2])) * 7919) % n] + 0.5 * q[::2]
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    db_t = torch.from_numpy(db.astype(np.float32)).cuda()
+    q_t = torch.from_numpy(q.astype(np.float32)).cuda()
+    cuts = [0, 50000, 90000, n]                       # three uneven shards
+    pos_all = np.array([0, n], np.int64)
+    whole = DeviceIndex(d, 0, storage=storage)
+    whole.load(db_t, pos_all, 0)
+    D0, I0 = whole.search(q_t, k)
+    shards = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        ix = DeviceIndex(d, 0, storage=storage)
+        ix.load(db_t[lo:hi].contiguous(), np.array([lo, hi], np.int64), lo)
+        shards.append(ix)
+    bounds = [ix.search_bound(q_t, k) for ix in shards]          # one pending bound per handle
+    for ix, lb in zip(shards, bounds):
+        Dl, _ = ix.search(q_t, k)                                 # complete local list (also clears the pending state)
+        assert bool((lb <= Dl[:, k - 1] + 1e-6).all()), "a shard's bound exceeds its true k-th best"
+    bounds = [ix.search_bound(q_t, k) for ix in shards]
+    assert bool(torch.isfinite(torch.stack(bounds)).all())        # this shape takes the sampled-threshold path
+    L = torch.stack(bounds).max(0).values
+    parts = [ix.search_bounded(q_t, k, L) for ix in shards]
+    S = torch.cat([p[0] for p in parts], 1)
+    Lb = torch.cat([p[1] for p in parts], 1)
+    Dm, Im = whole.merge_topk(S, Lb, k)
+    assert torch.equal(Im, I0)
+    assert float((Dm - D0).abs().max()) == 0.0
+    for Dp, Ip in parts:                                          # nothing below the reduced bound (minus the margin) is emitted
+        ok = Ip >= 0
+        assert bool((Dp[ok] >= (L[:, None].expand_as(Dp))[ok] - 3e-3).all())
+    # a bounded call without a pending bound is a plain search
+    D1, I1 = shards[0].search_bounded(q_t, k, torch.full((nq,), float("-inf"), device="cuda"))
+    D2, I2 = shards[0].search(q_t, k)
+    assert torch.equal(I1, I2) and torch.equal(D1, D2)
