@@ -705,9 +705,9 @@ __global__ void fill_empty_kernel(float *D, int64_t *I, int64_t total) {
 //                         (radix select of 2048 values) -> full pass emitting scores >= tau into 32 sub-lists per
 //                         row (~R*k survivors) -> 256-thread radix select + rank sort.
 // Four short launches around the one pass that reads the shard; no host synchronisation.
-template <int ELT>
 // db32 != nullptr with ELT == 2: `rows` is the fp16 copy of an fp32 shard -- the scan is a pre-filter with the rigorous
 // margin of q_prep_kernel (half the bytes of the fp32 pass), the select re-scores in exact fp32 like the batched path.
+template <int ELT>
 static int search_small(const void *rows, int64_t n, int d, const void *qrows, int64_t nq, int k, float *D, int64_t *I,
                         int64_t label_base, const float *q32, const float *db32, SearchWorkspace &ws, hipStream_t s) {
     const bool prefilter = ELT == 2 && db32 != nullptr;
