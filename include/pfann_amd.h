@@ -172,16 +172,18 @@ int pfann_search_topk(pfann_db *db, const float *q_dev, int64_t nq, int k, float
 
 /* The same search split around ONE collective, for a database sharded over several GPUs (pfann_amd/dist.py; the
  * reference has no counterpart: database.py:101-104 replicates the index).  nq <= 16384 per call.
- *   pfann_search_bound        : query preparation + the sampled pass only; lb_dev[nq] = a lower bound of the k-th best
- *                               inner product of every query row over THIS shard (-inf where the path taken has no
- *                               sampled threshold: tiny shards, <= 32 query rows, k > 128).
- *   -- the caller reduces lb over the ranks with MAX: the k-th best over all shards is at least that --
+ *   pfann_search_bound        : query preparation + the sampled pass only; lb_dev[nq][m] = for every query row the m
+ *                               best sampled scores of THIS shard (one per group of rows, so m different real rows),
+ *                               each lowered to a bound of its exact inner product; -inf padding (all -inf where the
+ *                               path taken has no sampled threshold: tiny shards, <= 32 query rows, k > 128).
+ *   -- the caller gathers the ranks' values; the k-th largest of their union bounds the k-th best over all shards
+ *      from below (dist.py sends m = 2k/ranks + 8 values per row and rank) --
  *   pfann_search_topk_bounded : finishes the search started by pfann_search_bound for the SAME (q_dev, nq, k) on the
- *                               same handle (nothing else may use the handle's search in between); rows that cannot
- *                               reach the global bound are not emitted, so D / I may hold fewer than k entries
+ *                               same handle (nothing else may use the handle's search in between), lb_dev[nq] = the
+ *                               reduced bound; rows that cannot reach it are not emitted, so D / I may hold fewer than k entries
  *                               (D = -FLT_MAX, I = -1 padding).  pfann_topk_merge of the shards' lists is the exact
  *                               global top-k.  Without a matching pfann_search_bound call it is pfann_search_topk. */
-int pfann_search_bound(pfann_db *db, const float *q_dev, int64_t nq, int k, float *lb_dev, void *stream);
+int pfann_search_bound(pfann_db *db, const float *q_dev, int64_t nq, int k, int m, float *lb_dev, void *stream);
 int pfann_search_topk_bounded(pfann_db *db, const float *q_dev, int64_t nq, int k, const float *lb_dev,
                               float *D_dev, int64_t *I_dev, void *stream);
 

@@ -693,11 +693,12 @@ int pfann_search_topk(pfann_db *db, const float *q, int64_t nq, int k, float *D,
     return 0;
 }
 
-int pfann_search_bound(pfann_db *db, const float *q, int64_t nq, int k, float *lb, void *stream) {
+int pfann_search_bound(pfann_db *db, const float *q, int64_t nq, int k, int m, float *lb, void *stream) {
     PF_HIP(hipSetDevice(db->device));
     if (nq > 16384) { set_error("pfann_search_bound: at most 16384 query rows per call (got %lld)", (long long)nq); return -1; }
+    if (m < 1 || m > 1024) { set_error("pfann_search_bound: m=%d outside 1..1024", m); return -1; }
     return search_topk(db->emb, (db->prefilter || db->emb == nullptr) ? db->emb_h : nullptr, db->xnorm_max, db->n, db->d,
-                       db->label_base, q, nq, k, nullptr, nullptr, db->ws, (hipStream_t)stream, 1, lb);
+                       db->label_base, q, nq, k, nullptr, nullptr, db->ws, (hipStream_t)stream, 1, lb, m);
 }
 
 int pfann_search_topk_bounded(pfann_db *db, const float *q, int64_t nq, int k, const float *lb, float *D, int64_t *I,

@@ -79,14 +79,16 @@ struct SearchWorkspace {
 // db == nullptr (fp16-only storage, pfann_db_set_storage): scores are s16 = sum fl16(q_i) * fl16(x_i) accumulated in
 // fp32, no fp32 re-scoring.  Fully asynchronous on `s`: no host synchronisation inside.
 // phase 0: the whole search.  Song-sharded jobs split it around one collective (pfann_search_bound / _bounded):
-//   phase 1: query preparation + sampled group-maximum pass + group select only; lb[m] = a lower bound of the TRUE k-th
-//            best score of query row m over this shard (-inf where this path has no sampled threshold);
-//   phase 2: lb[m] = lower bound of the k-th best over ALL shards (max over the ranks' phase-1 values): the full pass
+//   phase 1: query preparation + sampled group-maximum pass + group select only; lb[m][0..mtop) = the mtop best sampled
+//            group maxima of query row m, each lowered to a bound of the TRUE score of its row (-inf padding; all -inf
+//            where this path has no sampled threshold).  The k-th largest of the union of all shards' values bounds the
+//            k-th best over all shards from below (>= k different real rows reach it);
+//   phase 2: lb[m] = that lower bound of the k-th best over ALL shards: the full pass
 //            emits only rows that can be in the global top-k, so D / I may hold fewer than k entries (padded) -- the
 //            merge of the shards' lists is still the exact global top-k.
 int search_topk(const float *db, const void *dbh, float xnorm_max, int64_t n, int d, int64_t label_base,
                 const float *q, int64_t nq, int k, float *D, int64_t *I, SearchWorkspace &ws, hipStream_t s,
-                int phase = 0, float *lb = nullptr);
+                int phase = 0, float *lb = nullptr, int mtop = 1);
 int topk_merge(const float *S, const int64_t *L, int64_t nq, int m, int k, float *D, int64_t *I,
                hipStream_t s);
 

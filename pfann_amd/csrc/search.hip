@@ -399,52 +399,73 @@ __global__ __launch_bounds__(256, 2) void scan_small_kernel(ScanParams p) {
 __global__ __launch_bounds__(256) void group_max_select_kernel(const float *__restrict__ gmax, int G, int k,
                                                                float *__restrict__ thr, int *__restrict__ cnt, int ncnt,
                                                                const float *__restrict__ eps, float *__restrict__ thr_adj,
-                                                               float margin) {
+                                                               float margin, float *__restrict__ topm, int mtop, float margin_out) {
     constexpr int GMAX = 4096;
     __shared__ unsigned sv[GMAX];
     __shared__ int hist[256];
-    __shared__ int s_bin, s_kk;
+    __shared__ int s_bin, s_kk, s_n;
     const int64_t m = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < ncnt; i += 256) cnt[m * ncnt + i] = 0;
     for (int i = tid; i < G; i += 256) sv[i] = ~f2ord(gmax[m * G + i]);          // ascending = descending score
     __syncthreads();
+    // key of the kk-th smallest entry of sv (= kk-th best score): MSB radix select, 4 x 8 bits
+    auto kth = [&](int kk) -> unsigned {
+        unsigned prefix = 0;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            hist[tid] = 0;
+            __syncthreads();
+            for (int i = tid; i < G; i += 256) {
+                const unsigned hi = sv[i];
+                if (pass == 0 || (hi >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(hi >> shift) & 255], 1);
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const int c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+                const int sum4 = c0 + c1 + c2 + c3;
+                int incl = sum4;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += v;
+                }
+                const int excl = incl - sum4;
+                if (excl < kk && kk <= incl) {          // exactly one lane
+                    int rem = kk - excl, bin = 4 * lane;
+                    if (rem > c0) { rem -= c0; ++bin; if (rem > c1) { rem -= c1; ++bin; if (rem > c2) { rem -= c2; ++bin; } } }
+                    s_bin = bin;
+                    s_kk = rem;
+                }
+            }
+            __syncthreads();
+            prefix |= (unsigned)s_bin << shift;
+            kk = s_kk;
+        }
+        return prefix;
+    };
+    // topm[m][0..mtop): the mtop best group maxima minus margin_out * eps -- each the score of a DIFFERENT real row of
+    // this shard, lowered to a bound of its true score -- for the cross-shard bound (search_topk phase 1); -inf padded
+    if (topm != nullptr) {
+        const float e = eps != nullptr ? margin_out * eps[m] : 0.f;
+        const int mm = mtop < G ? mtop : G;
+        for (int i = mm + tid; i < mtop; i += 256) topm[m * mtop + i] = -INFINITY;
+        if (mm > 0) {
+            const unsigned tm = kth(mm);
+            if (tid == 0) s_n = 0;
+            __syncthreads();
+            for (int i = tid; i < G; i += 256)
+                if (sv[i] < tm) topm[m * mtop + atomicAdd(&s_n, 1)] = ord2f(~sv[i]) - e;       // strictly better: < mm of them
+            __syncthreads();
+            for (int i = s_n + tid; i < mm; i += 256) topm[m * mtop + i] = ord2f(~tm) - e;     // the mm-th best and its ties
+            __syncthreads();
+        }
+    }
     if (G < k) {
         if (tid == 0) { thr[m] = -INFINITY; if (eps != nullptr) thr_adj[m] = -1000.f * eps[m]; }
         return;
     }
-    unsigned prefix = 0;
-    int kk = k;
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        hist[tid] = 0;
-        __syncthreads();
-        for (int i = tid; i < G; i += 256) {
-            const unsigned hi = sv[i];
-            if (pass == 0 || (hi >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(hi >> shift) & 255], 1);
-        }
-        __syncthreads();
-        if (wave == 0) {
-            const int c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
-            const int sum4 = c0 + c1 + c2 + c3;
-            int incl = sum4;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int v = __shfl_up(incl, o, 64);
-                if (lane >= o) incl += v;
-            }
-            const int excl = incl - sum4;
-            if (excl < kk && kk <= incl) {          // exactly one lane
-                int rem = kk - excl, bin = 4 * lane;
-                if (rem > c0) { rem -= c0; ++bin; if (rem > c1) { rem -= c1; ++bin; if (rem > c2) { rem -= c2; ++bin; } } }
-                s_bin = bin;
-                s_kk = rem;
-            }
-        }
-        __syncthreads();
-        prefix |= (unsigned)s_bin << shift;
-        kk = s_kk;
-    }
+    const unsigned prefix = kth(k);
     if (tid == 0) {
         const float t = ord2f(~prefix);
         thr[m] = t;
@@ -452,10 +473,11 @@ __global__ __launch_bounds__(256) void group_max_select_kernel(const float *__re
     }
 }
 
-int launch_group_max_select(SearchWorkspace &ws, int64_t nq, int G, int k, int ncnt, bool with_eps, float margin, hipStream_t s) {
+int launch_group_max_select(SearchWorkspace &ws, int64_t nq, int G, int k, int ncnt, bool with_eps, float margin, hipStream_t s,
+                            float *topm = nullptr, int mtop = 0, float margin_out = 0.f) {
     ProfScope ps("topk_group_select", s);
     PF_LAUNCH(group_max_select_kernel, dim3((unsigned)nq), dim3(256), 0, s, reinterpret_cast<const float *>(ws.cl), G, k, ws.thr,
-              ws.cnt, ncnt, with_eps ? ws.eps : nullptr, ws.thr_adj, margin);
+              ws.cnt, ncnt, with_eps ? ws.eps : nullptr, ws.thr_adj, margin, topm, mtop, margin_out);
     PF_HIP(hipGetLastError());
     return 0;
 }
@@ -750,11 +772,10 @@ static int search_small(const void *rows, int64_t n, int d, const void *qrows, i
     return launch_select_rescore(ws, nq, k, 1, D, I, label_base, q32, db32, d, 32, prefilter ? 1 : 0, s);
 }
 
-// phase 1 -> lb[m] = tau_m - eps_m (the k-th best group maximum is the s16 score of a real row, whose true score is
-// within eps of it); no sampled threshold on this path: -inf
-__global__ void bound_out_kernel(const float *__restrict__ thr, const float *__restrict__ eps, float margin, float *lb, int64_t nq) {
-    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m < nq) lb[m] = thr == nullptr ? -INFINITY : thr[m] - margin * eps[m];
+// phase 1 on a path without a sampled threshold: no information
+__global__ void bound_none_kernel(float *lb, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) lb[i] = -INFINITY;
 }
 // phase 2: rows of this shard whose true score reaches the global bound have s16 >= lb - eps
 __global__ void bound_in_kernel(float *__restrict__ thr_adj, const float *__restrict__ eps, float margin, const float *__restrict__ lb,
@@ -765,12 +786,12 @@ __global__ void bound_in_kernel(float *__restrict__ thr_adj, const float *__rest
 
 int search_topk(const float *db, const void *dbh, float xnorm_max, int64_t n, int d, int64_t label_base,
                 const float *q, int64_t nq, int k, float *D, int64_t *I, SearchWorkspace &ws, hipStream_t s,
-                int phase, float *lb) {
+                int phase, float *lb, int mtop) {
     if (nq <= 0) return 0;
     const bool resume = phase == 2 && ws.bound_valid && ws.bound_q == q && ws.bound_nq == nq && ws.bound_k == k;
     if (phase != 2 || !resume) ws.bound_valid = false;
     auto no_bound = [&]() -> int {               // phase 1 on a path without a sampled threshold
-        PF_LAUNCH(bound_out_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, s, (const float *)nullptr, (const float *)nullptr, 0.f, lb, nq);
+        PF_LAUNCH(bound_none_kernel, dim3((unsigned)cdiv(nq * mtop, 256)), dim3(256), 0, s, lb, nq * mtop);
         PF_HIP(hipGetLastError());
         return 0;
     };
@@ -835,10 +856,9 @@ int search_topk(const float *db, const void *dbh, float xnorm_max, int64_t n, in
                 for (int64_t gs = 4; gs >= 1 && rc == 1; gs >>= 1) rc = launch_scan_f16_gmax(dbh, n, d, gs, ws.qh, nq, k, ws, &G, s);
             if (rc < 0) return -1;
             if (rc == 0) {
-                if (!resume && launch_group_max_select(ws, nq, G, k, 0, true, rescore ? 2.f : 0.f, s)) return -1;
+                if (!resume && launch_group_max_select(ws, nq, G, k, 0, true, rescore ? 2.f : 0.f, s, phase == 1 ? lb : nullptr,
+                                                       phase == 1 ? mtop : 0, margin)) return -1;
                 if (phase == 1) {
-                    PF_LAUNCH(bound_out_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, s, ws.thr, ws.eps, margin, lb, nq);
-                    PF_HIP(hipGetLastError());
                     ws.bound_valid = true; ws.bound_q = q; ws.bound_nq = nq; ws.bound_k = k; ws.bound_G = G;
                     return 0;
                 }

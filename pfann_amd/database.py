@@ -88,16 +88,29 @@ class DeviceIndex:
 
     BOUND_CHUNK = 16384        # query rows per pfann_search_bound / pfann_search_topk_bounded call
 
-    def search_bound(self, q, k):
-        """First half of a sharded search (<= BOUND_CHUNK rows): -> lb [nq] f32 on the device, a lower bound of every
-        row's k-th best score over THIS shard (-inf where no sampled threshold exists).  To be MAX-reduced over the ranks
-        and handed to search_bounded with the same q and k."""
+    def search_bound(self, q, k, m=1):
+        """First half of a sharded search (<= BOUND_CHUNK rows): -> [nq, m] f32 on the device: per query row the m best
+        sampled scores of THIS shard (m different real rows), each lowered to a bound of its exact score; -inf padded (all
+        -inf where no sampled threshold exists).  reduce_bound over the ranks' tensors gives what search_bounded wants."""
         nq = q.shape[0]
-        lb = torch.empty((nq,), device=self.device, dtype=torch.float32)
+        lb = torch.empty((nq, m), device=self.device, dtype=torch.float32)
         if nq:
-            _l.check(self.lib.pfann_search_bound(self.handle, q.data_ptr(), nq, k, lb.data_ptr(), self._stream()),
+            _l.check(self.lib.pfann_search_bound(self.handle, q.data_ptr(), nq, k, m, lb.data_ptr(), self._stream()),
                      "pfann_search_bound")
         return lb
+
+    def reduce_bound(self, cands, k):
+        """cands [n_ranks, nq, m] (all-gathered search_bound outputs) -> [nq]: the k-th largest of every row's union, a lower
+        bound of the row's k-th best score over all shards (>= k different real rows reach it); -FLT_MAX when the union
+        holds fewer than k finite values."""
+        G, nq, m = cands.shape
+        vals = cands.to(self.device).permute(1, 0, 2).reshape(nq, G * m).contiguous()
+        if G * m < k:
+            return torch.full((nq,), -3.4028234663852886e38, device=self.device, dtype=torch.float32)
+        labels = torch.where(torch.isfinite(vals), torch.arange(G * m, device=self.device, dtype=torch.int64).expand(nq, -1),
+                             torch.full_like(vals, -1, dtype=torch.int64)).contiguous()
+        D, _ = self.merge_topk(vals, labels, k)
+        return D[:, k - 1].contiguous()
 
     def search_bounded(self, q, k, lb):
         """Second half: (D, I) of this shard restricted to rows that can be in the global top-k (padded with

@@ -67,17 +67,6 @@ def all_to_all_rows(x, group=None):
     return out
 
 
-def all_reduce_max(x, group=None):
-    """In-place MAX all-reduce of a float tensor."""
-    if x.is_cuda and dist.get_backend(group) == "gloo":       # debugging on one GPU: stage through host
-        h = x.cpu()
-        dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
-        x.copy_(h)
-        return x
-    dist.all_reduce(x, op=dist.ReduceOp.MAX, group=group)
-    return x
-
-
 def all_gather_ragged(x, counts, group=None):
     """Rows split unevenly over ranks (counts[r] rows on rank r) -> concatenated [sum, ...]."""
     world = dist.get_world_size(group)
@@ -112,16 +101,19 @@ class ShardedIndex:
         G, k, Q = self.world, self.k, q.shape[0]
         if G == 1:
             return self.b.search(q, k)
-        # Two-phase shard search: every rank bounds each row's k-th best over ITS shard from the sampled pass, the bounds
-        # are MAX-reduced (the k-th best over all shards is at least the best of them; 4 bytes per row), and the full pass
+        # Two-phase shard search: every rank extracts from its sampled pass the m best scores of each row (m different
+        # real rows of its shard, lowered to bounds of their exact scores), the values are all-gathered (4 m bytes per row
+        # and rank) and the k-th largest of a row's union bounds its k-th best over ALL shards from below; the full pass
         # then emits only rows that can be in the GLOBAL top-k.  Without it every shard digs out its own complete top-k:
         # the survivor density per db row -- what the scan's epilogue and the select pay for -- grows with the number of
-        # shards (8 shards: almost every 32x32 block of the scan holds a survivor).
+        # shards (8 shards: almost every 32x32 block of the scan holds a survivor).  m = 2k/G + 8 covers a row whose
+        # best matches are spread evenly over the shards twice over; a lopsided row just gets a looser (still valid) bound.
         q = q.contiguous()
+        m = min(k, 2 * k // G + 8)
         Dl, Il = [], []
         for c0 in range(0, Q, self.b.BOUND_CHUNK):
             qc = q[c0:c0 + self.b.BOUND_CHUNK]
-            lb = all_reduce_max(self.b.search_bound(qc, k), self.group)
+            lb = self.b.reduce_bound(all_gather_rows(self.b.search_bound(qc, k, m), self.group), k)
             Dc, Ic = self.b.search_bounded(qc, k, lb)
             Dl.append(Dc)
             Il.append(Ic)

@@ -57,7 +57,7 @@ SYMBOLS = {
     "pfann_db_bytes": (c_int64, [c_void_p]),
     "pfann_db_load": (c_int, [c_void_p, c_void_p, c_int, c_int64, POINTER(c_int64), c_int, c_int64]),
     "pfann_search_topk": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
-    "pfann_search_bound": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "pfann_search_bound": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "pfann_search_topk_bounded": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pfann_topk_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
                                  c_void_p]),

@@ -29,16 +29,22 @@ class OracleIndex:
         I = np.where(I >= 0, I + self.label_base, -1)
         return torch.from_numpy(D), torch.from_numpy(I)
 
-    # ---- two-phase sharded search (pfann_search_bound / pfann_search_topk_bounded): the oracle's bound is the shard's
-    # exact k-th best (the tightest legal one; -inf when the shard has fewer than k rows), its bounded search drops
-    # every entry below the reduced bound
+    # ---- two-phase sharded search (pfann_search_bound / pfann_search_topk_bounded): the oracle's candidates are the
+    # shard's m best exact scores, the reduced bound the k-th largest of the union, and its bounded search drops every
+    # entry below that bound
     BOUND_CHUNK = 7            # small on purpose: the gloo tests walk several chunks
 
-    def search_bound(self, q, k):
-        D, _ = osr.flat_ip_topk(q.numpy(), self.emb, k)
-        lb = np.where(D[:, k - 1] > -np.finfo(np.float32).max, D[:, k - 1], -np.inf).astype(np.float32) if D.shape[1] >= k else \
-            np.full(q.shape[0], -np.inf, np.float32)
-        return torch.from_numpy(lb)
+    def search_bound(self, q, k, m=1):
+        D, _ = osr.flat_ip_topk(q.numpy(), self.emb, m)            # the shard's m best exact scores: the tightest legal values
+        out = np.where(D > -np.finfo(np.float32).max, D, -np.inf).astype(np.float32)
+        return torch.from_numpy(np.ascontiguousarray(out[:, :m]))
+
+    def reduce_bound(self, cands, k):
+        c = cands.numpy()
+        G, nq, m = c.shape
+        v = -np.sort(-c.transpose(1, 0, 2).reshape(nq, G * m), axis=1)
+        lb = v[:, k - 1] if G * m >= k else np.full(nq, -np.inf, np.float32)
+        return torch.from_numpy(np.where(np.isfinite(lb), lb, -np.finfo(np.float32).max).astype(np.float32))
 
     def search_bounded(self, q, k, lb):
         D, I = self.search(q, k)

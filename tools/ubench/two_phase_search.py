@@ -1,6 +1,6 @@
 """What the MAX-reduced bound buys a shard (tuning aid): 1,000,000 unit rows in songs of 40 similar rows, cut into
 N shards held by N handles on this one GPU; time of shard 0's search for 9728 query rows, complete (pfann_search_topk) vs
-two-phase (pfann_search_bound, bounds of all shards MAX-ed, pfann_search_topk_bounded).   python tools/ubench/two_phase_search.py [N]"""
+two-phase (pfann_search_bound, k-th largest of the union of all shards' values, pfann_search_topk_bounded).   python tools/ubench/two_phase_search.py [N]"""
 import os
 import sys
 import time
@@ -40,12 +40,13 @@ def timeit(f, reps=10):
     return 1e3 * (time.perf_counter() - t) / reps
 
 
-L = torch.stack([ix.search_bound(q, k) for ix in shards]).max(0).values
+m = min(k, 2 * k // N + 8)
+L = shards[0].reduce_bound(torch.stack([ix.search_bound(q, k, m) for ix in shards]), k)
 s0 = shards[0]
 
 
 def two_phase():
-    s0.search_bound(q, k)
+    s0.search_bound(q, k, m)
     return s0.search_bounded(q, k, L)
 
 
