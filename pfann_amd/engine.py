@@ -170,9 +170,11 @@ class Engine:
         return out
 
     def pcm16_to_mono(self, pcm):
-        """int16 [n] or [n, ch] (torch / numpy) -> float32 mono [n] on device."""
+        """int16 [n] or [n, ch] (torch / numpy) -> float32 mono [n] on device.  A tensor in PINNED host memory is uploaded
+        asynchronously (the host does not wait for the stream, which may still be busy with the previous batch's encoder):
+        the caller keeps it unchanged until the stream has passed this point."""
         p = pcm if isinstance(pcm, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(pcm))
-        p = p.to(self.device, torch.int16).contiguous()
+        p = p.to(self.device, torch.int16, non_blocking=bool(p.device.type == "cpu" and p.is_pinned())).contiguous()
         n_ch = 1 if p.dim() == 1 else p.shape[1]
         n = p.shape[0]
         out = torch.empty((n,), device=self.device, dtype=torch.float32)
