@@ -15,6 +15,7 @@
  *   pfann_segment_embed     builder.py:88-100 / matcher.py:110-128 emit loops fused with
  *                           datautil/musicdata.py:82-88 (pad, unfold, mean removal)
  *   pfann_pcm16_to_mono     datautil/musicdata.py:48,72-80
+ *   pfann_resample_to_mono  datautil/musicdata.py:28-65 (julius.ResampleFrac, minute-wise) + 72-80
  *   pfann_db_*              database.py:75-109 Database.__init__ (index + song_pos)
  *   pfann_search_topk       database.py:121  index.search(query, top_k)  (exact flat IP)
  *   pfann_match             database.py:117-166 query_embeddings_base (search + rerank)
@@ -108,6 +109,18 @@ int pfann_segment_embed_at(pfann_ctx *ctx, const float *wav_dev, const int64_t *
 /* int16 interleaved PCM -> float32 mono (x/32768, fake-stereo fix, channel mean). */
 int pfann_pcm16_to_mono(pfann_ctx *ctx, const int16_t *pcm_dev, int64_t n_frames, int n_ch,
                         float *wav_dev, void *stream);
+
+/* Files at another sample rate (datautil/musicdata.py:28-65: `julius.ResampleFrac(file_sr, sample_rate)`, applied to 60 s
+ * pieces that start every 59 s, half a second dropped at the inner seams), then the same mono conversion.
+ *   pcm_dev      int16 interleaved [n_in][n_ch]
+ *   kernels_dev  float [new_rate][2*width + old_rate]: the resampler's polyphase filters for the gcd-reduced rates
+ *                (pfann_amd/resample.py builds them as julius does)
+ *   plan_dev     int64 [n_pieces][5] = {in_start, in_len, out_skip, out_keep, out_off} per piece, in samples
+ *   tmp_dev      float [n_ch][n_out] scratch;  wav_dev float [n_out] result.
+ * julius is an un-vendored, unpinned dependency of the reference: this path is restated from its published algorithm. */
+int pfann_resample_to_mono(pfann_ctx *ctx, const int16_t *pcm_dev, int n_ch, const float *kernels_dev, int old_rate,
+                           int new_rate, int width, const int64_t *plan_dev, int n_pieces, int64_t n_out, float *tmp_dev,
+                           float *wav_dev, void *stream);
 
 /* Debug/verification taps: copy the activation after sub-layer `idx` (0..15) of the LAST
  * pfann_encode call's first `B` samples to host as NCHW floats.  Returns numel or <0. */

@@ -1,8 +1,9 @@
 """Oracle a1: WAV -> float32[n_seg, segment_size] (reference datautil/musicdata.py:21-93).
 
-Restated for the in-scope input class (16-bit PCM WAV already at the model sample rate,
-mono or stereo), where the reference's julius resampler is the identity and its
-minute-wise chunking (musicdata.py:33-65) reduces to a plain concatenation.
+Restated for 16-bit PCM WAV input, mono or stereo.  At the model sample rate the reference's julius
+resampler is the identity and its minute-wise chunking (musicdata.py:33-65) reduces to a plain
+concatenation (pinned: tests/golden/segmenter.npz); other rates go through oracle/resample.py (parity unpinned:
+julius is absent).
 """
 import wave
 
@@ -20,10 +21,13 @@ def read_wav_int16(path):
     return pcm, sr
 
 
-def pcm_to_mono(pcm):
-    """int16[n, ch] -> float32[n]: scale 1/32768 in fp32 (musicdata.py:48), fake-stereo
-    fix (musicdata.py:74-79), channel mean (musicdata.py:80)."""
+def pcm_to_mono(pcm, file_sr=None, sr=None):
+    """int16[n, ch] -> float32[n]: scale 1/32768 in fp32 (musicdata.py:48), resampling when the file's rate is not the
+    model's (musicdata.py:28-65), fake-stereo fix (musicdata.py:74-79), channel mean (musicdata.py:80)."""
     x = np.multiply(pcm, 1 / 32768, dtype=np.float32).T.copy()  # [ch, n]
+    if file_sr is not None and sr is not None and file_sr != sr:
+        from . import resample
+        x = np.ascontiguousarray(resample.resample_chunked(x, file_sr, sr))
     if x.shape[0] == 2:
         pow1 = np.mean((x[0] - x[1]) ** 2, dtype=np.float32)
         pow2 = np.mean((x[0] + x[1]) ** 2, dtype=np.float32)
@@ -51,8 +55,6 @@ def load_segments(path, params):
     hop = int(sr * params["hop_size"]) // params["indexer"].get("frame_shift_mul", 1)
     try:
         pcm, file_sr = read_wav_int16(path)
-        if file_sr != sr:
-            raise NotImplementedError("resampling is out of scope")
-        return segment(pcm_to_mono(pcm), seg_n, hop)
+        return segment(pcm_to_mono(pcm, file_sr, sr), seg_n, hop)
     except Exception:
         return np.zeros((0, seg_n), dtype=np.float32)

@@ -58,7 +58,7 @@ def embed_files(engine, dataset, hop, batch_windows=4096, timer=None, norm=True)
             with timer.stage("load"):
                 pcm = dataset.load_pcm(i)
             with timer.stage("stereo to mono"):
-                wav = engine.pcm16_to_mono(pcm)
+                wav = engine.pcm16_to_mono(pcm, sample_rate=getattr(dataset, "last_sample_rate", None))
                 if wav.shape[0] < seg:                                    # musicdata.py:82-84
                     wav = torch.nn.functional.pad(wav, (0, seg - wav.shape[0]))
             n_seg = (wav.shape[0] - seg) // hop + 1

@@ -497,6 +497,13 @@ int pfann_segment_embed_at(pfann_ctx *c, const float *wav, const int64_t *starts
     return segment_embed_impl(c, wav, B, 0, starts_dev, emb, normalize, stream);
 }
 
+int pfann_resample_to_mono(pfann_ctx *c, const int16_t *pcm, int n_ch, const float *kernels, int old_rate, int new_rate, int width,
+                           const int64_t *plan, int n_pieces, int64_t n_out, float *tmp, float *wav, void *stream) {
+    PF_HIP(hipSetDevice(c->device));
+    return launch_resample_to_mono(pcm, n_ch, kernels, old_rate, new_rate, width, plan, n_pieces, n_out, tmp, wav,
+                                   reinterpret_cast<float *>(c->scratch), (hipStream_t)stream);
+}
+
 int pfann_pcm16_to_mono(pfann_ctx *c, const int16_t *pcm, int64_t n_frames, int n_ch, float *wav, void *stream) {
     PF_HIP(hipSetDevice(c->device));
     if (n_ch < 1) { set_error("n_ch < 1"); return -1; }

@@ -18,6 +18,8 @@ struct MelPlan {
 };
 int launch_melspec(const MelPlan &mp, const float *segs, int64_t B, int64_t seg_stride,
                    const int64_t *starts, int remove_mean, float *out, hipStream_t s);
+int launch_resample_to_mono(const int16_t *pcm, int n_ch, const float *K, int old_r, int new_r, int width, const int64_t *plan,
+                            int n_pieces, int64_t n_out, float *tmp, float *wav, float *scratch2, hipStream_t s);
 int launch_pcm16_to_mono(const int16_t *pcm, int64_t n_frames, int n_ch, float *wav,
                          float *scratch2, hipStream_t s);
 

@@ -395,6 +395,81 @@ __global__ void pcm_to_mono_kernel(const int16_t *__restrict__ pcm, int64_t n, i
     wav[i] = acc / (float)n_ch;
 }
 
+// ------------------------------------------------------------------------------------
+// Files that are not at the model's sample rate (datautil/musicdata.py:28-65): julius.ResampleFrac as a polyphase
+// FIR, applied piece by piece like the reference does (60 s pieces starting every 59 s, each with replicate padding at
+// ITS edges, half a second dropped at the inner seams).  One thread per output sample and channel:
+//   y[j * new + i] = sum_t K[i][t] * x[clamp(j * old + t - width, 0, len - 1)],  x = int16 / 32768
+// plan[p] = {in_start, in_len, out_skip, out_keep, out_off}: piece p contributes outputs [out_off, out_off + out_keep).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resample_kernel(const int16_t *__restrict__ pcm, int n_ch, const float *__restrict__ K,
+                                                       int old_r, int new_r, int width, const int64_t *__restrict__ plan,
+                                                       int n_pieces, int64_t n_out, float *__restrict__ out) {
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (o >= n_out) return;
+    int lo = 0, hi = n_pieces - 1;                 // last piece whose out_off <= o
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (plan[5 * mid + 4] <= o) lo = mid; else hi = mid - 1;
+    }
+    const int64_t in_start = plan[5 * lo], in_len = plan[5 * lo + 1];
+    const int64_t jl = o - plan[5 * lo + 4] + plan[5 * lo + 2];
+    const int64_t frame = jl / new_r;
+    const int phase = (int)(jl - frame * new_r);
+    const int taps = 2 * width + old_r;
+    const float *kr = K + (int64_t)phase * taps;
+    const int64_t x0 = frame * old_r - width;
+    const int16_t *xs = pcm + in_start * n_ch + c;
+    float acc = 0.f;
+    for (int t = 0; t < taps; ++t) {
+        int64_t xi = x0 + t;
+        xi = xi < 0 ? 0 : (xi >= in_len ? in_len - 1 : xi);
+        acc = fmaf(kr[t], (float)xs[xi * n_ch] * (1.0f / 32768.0f), acc);
+    }
+    out[(int64_t)c * n_out + o] = acc;
+}
+__global__ void planar_power_kernel(const float *__restrict__ x, int64_t n, double *pw) {
+    double p1 = 0, p2 = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float l = x[i], r = x[n + i];
+        p1 += (double)((l - r) * (l - r));
+        p2 += (double)((l + r) * (l + r));
+    }
+    p1 = wave_sum_d(p1); p2 = wave_sum_d(p2);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&pw[0], p1); atomicAdd(&pw[1], p2); }
+}
+__global__ void planar_to_mono_kernel(const float *__restrict__ x, int64_t n, int n_ch, const double *pw, float *__restrict__ wav) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (n_ch == 1) { wav[i] = x[i]; return; }
+    const bool flip = n_ch == 2 && (float)(pw[0] / (double)n) > (float)(pw[1] / (double)n) * 1000.0f;
+    float acc = 0.f;
+    for (int c = 0; c < n_ch; ++c) {
+        float v = x[(int64_t)c * n + i];
+        if (flip && c == 1) v = -v;
+        acc += v;
+    }
+    wav[i] = acc / (float)n_ch;
+}
+
+int launch_resample_to_mono(const int16_t *pcm, int n_ch, const float *K, int old_r, int new_r, int width, const int64_t *plan,
+                            int n_pieces, int64_t n_out, float *tmp, float *wav, float *scratch2, hipStream_t s) {
+    if (n_out <= 0) return 0;
+    if (n_ch < 1 || old_r < 1 || new_r < 1 || width < 1 || n_pieces < 1) { set_error("resample: bad arguments"); return -1; }
+    double *pw = reinterpret_cast<double *>(scratch2);
+    ProfScope ps("resample_to_mono", s);
+    PF_LAUNCH(resample_kernel, dim3((unsigned)cdiv(n_out, 256), (unsigned)n_ch), dim3(256), 0, s, pcm, n_ch, K, old_r, new_r, width,
+              plan, n_pieces, n_out, tmp);
+    if (n_ch == 2) {
+        PF_HIP(hipMemsetAsync(pw, 0, 2 * sizeof(double), s));
+        PF_LAUNCH(planar_power_kernel, dim3(512), dim3(256), 0, s, tmp, n_out, pw);
+    }
+    PF_LAUNCH(planar_to_mono_kernel, dim3((unsigned)cdiv(n_out, 256)), dim3(256), 0, s, tmp, n_out, n_ch, pw, wav);
+    PF_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_pcm16_to_mono(const int16_t *pcm, int64_t n_frames, int n_ch, float *wav, float *scratch2,
                          hipStream_t s) {
     if (n_frames <= 0) return 0;

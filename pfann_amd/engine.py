@@ -84,6 +84,7 @@ class Engine:
         self.d, self.h, self.u, self.F, self.T = model_dims(params)
         self.seg_len = self.cfg.segment_len
         self.handle = self.lib.pfann_create(ctypes.byref(self.cfg), self.device.index)
+        self._resample_tables = {}
         if not self.handle:
             raise _l.PfannError("pfann_create failed: " + _l.last_error())
         n_frames = 1 + self.seg_len // self.cfg.stft_hop
@@ -169,14 +170,31 @@ class Engine:
                                                      1 if norm else 0, self._stream()), "pfann_segment_embed_at")
         return out
 
-    def pcm16_to_mono(self, pcm):
-        """int16 [n] or [n, ch] (torch / numpy) -> float32 mono [n] on device.  A tensor in PINNED host memory is uploaded
+    def pcm16_to_mono(self, pcm, sample_rate=None):
+        """int16 [n] or [n, ch] (torch / numpy) -> float32 mono [n] on device.  sample_rate: the file's rate when it is
+        not the model's (musicdata.py:28-65): the signal is resampled on the device first (pfann_amd/resample.py).  A tensor in PINNED host memory is uploaded
         asynchronously (the host does not wait for the stream, which may still be busy with the previous batch's encoder):
         the caller keeps it unchanged until the stream has passed this point."""
         p = pcm if isinstance(pcm, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(pcm))
         p = p.to(self.device, torch.int16, non_blocking=bool(p.device.type == "cpu" and p.is_pinned())).contiguous()
         n_ch = 1 if p.dim() == 1 else p.shape[1]
         n = p.shape[0]
+        if sample_rate is not None and int(sample_rate) != int(self.params["sample_rate"]) and n:
+            from . import resample
+            key = resample.reduced_rates(sample_rate, self.params["sample_rate"])
+            if key not in self._resample_tables:
+                tab, old, new, width = resample.filter_table(*key)
+                self._resample_tables[key] = (torch.from_numpy(tab).to(self.device), old, new, width)
+            tab, old, new, width = self._resample_tables[key]
+            plan, n_out = resample.piece_plan(n, int(sample_rate), int(self.params["sample_rate"]))
+            plan_dev = torch.from_numpy(plan).to(self.device)
+            tmp = torch.empty((n_ch, n_out), device=self.device, dtype=torch.float32)
+            out = torch.empty((n_out,), device=self.device, dtype=torch.float32)
+            if n_out:
+                _l.check(self.lib.pfann_resample_to_mono(self.handle, p.data_ptr(), n_ch, tab.data_ptr(), old, new, width,
+                                                         plan_dev.data_ptr(), plan.shape[0], n_out, tmp.data_ptr(),
+                                                         out.data_ptr(), self._stream()), "pfann_resample_to_mono")
+            return out
         out = torch.empty((n,), device=self.device, dtype=torch.float32)
         if n:
             _l.check(self.lib.pfann_pcm16_to_mono(self.handle, p.data_ptr(), n, n_ch, out.data_ptr(),

@@ -1,6 +1,7 @@
-"""Host mirror of the reference's segmenter interface (datautil/musicdata.py:9-104) for the
-in-scope input class: 16-bit PCM WAV already at the model sample rate (the reference's
-resampler is the identity there).  Other formats/rates need ffmpeg + julius: out of scope.
+"""Host mirror of the reference's segmenter interface (datautil/musicdata.py:9-104) for 16-bit PCM WAV input.
+At the model sample rate the reference's resampler is the identity; files at other rates are resampled on the
+device (Engine.pcm16_to_mono(pcm, sample_rate=...), pfann_amd/resample.py; parity with julius unpinned).  Other
+container formats need ffmpeg: out of scope.
 
 Two ways to consume a file:
   * `MusicDataset[i] -> (i, path, float32[n_seg, seg_len])`  -- the reference's contract
@@ -45,15 +46,18 @@ class MusicDataset:
         return (n - self.segment_size) // self.hop + 1
 
     def load_pcm(self, index):
+        """-> int16 [n, ch] as stored; the file's rate is left in `last_sample_rate` (the device path resamples:
+        Engine.pcm16_to_mono(pcm, sample_rate=...))."""
         pcm, sr = read_wav_pcm16(self.files[index])
-        if sr != self.sample_rate:
-            raise NotImplementedError("resampling %d -> %d Hz is out of scope" % (sr, self.sample_rate))
+        self.last_sample_rate = sr
         return pcm
 
     def unsafe_getitem(self, index):
         log = get_logger()
         t0 = time.time()
         pcm = self.load_pcm(index)
+        if self.last_sample_rate != self.sample_rate:          # host-side dataset contract: native rate only
+            raise NotImplementedError("resampling %d -> %d Hz runs on the device path only" % (self.last_sample_rate, self.sample_rate))
         t1 = time.time()
         x = np.multiply(pcm, 1 / 32768, dtype=np.float32).T.copy()
         if x.shape[0] == 2:                                    # musicdata.py:72-79

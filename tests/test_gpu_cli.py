@@ -55,7 +55,9 @@ def test_builder_and_matcher_cli_vs_oracle(tmp_path, cfgname):
             pcm = synth.make_song(100 + s, seconds=8.0 + s)
             if s == 6:
                 pcm = np.stack([pcm, pcm // 2], 1)
-            synth.write_wav(path, pcm)
+            # song 8 is stored at 16 kHz (its samples read twice as fast): the builder resamples it on the device,
+            # the oracle pipeline through oracle/resample.py
+            synth.write_wav(path, pcm, sr=16000 if s == 8 else 8000)
             songs[s] = pcm
         music.append(path)
     mlist = tmp_path / "music.txt"

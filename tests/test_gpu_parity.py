@@ -808,3 +808,29 @@ def test_two_phase_sharded_search_is_the_exact_global_topk(torch_cuda, storage):
     D1, I1 = shards[0].search_bounded(q_t, k, torch.full((nq,), float("-inf"), device="cuda"))
     D2, I2 = shards[0].search(q_t, k)
     assert torch.equal(I1, I2) and torch.equal(D1, D2)
+
+
+@pytest.mark.parametrize("file_sr,seconds,n_ch", [(44100, 125.3, 1), (44100, 61.0, 2), (16000, 7.3, 2), (11025, 0.4, 1),
+                                                  (48000, 60.0, 1), (22050, 119.02, 1)])
+def test_resample_to_mono_vs_oracle(torch_cuda, file_sr, seconds, n_ch):
+    """a1 at a non-native rate (musicdata.py:28-65): the device resampler + mono conversion against oracle/resample.py --
+    lengths, the minute-wise seams (one and two full pieces, a tail of exactly one second, a file shorter than the filter)
+    and the fake-stereo rule after resampling.  fp32 sums of up to 721 products in different orders: 2e-6."""
+    from oracle import segmenter
+    from pfann_amd.engine import Engine
+    params = cfg("tiny")
+    eng = Engine(params, 0)
+    n = int(file_sr * seconds)
+    rng = np.random.RandomState(file_sr % 1000 + n_ch)
+    t = np.arange(n) / file_sr
+    x = 0.4 * np.sin(2 * np.pi * 440 * t) + 0.2 * np.sin(2 * np.pi * 3100 * t + 1.0) + 0.1 * rng.randn(n)
+    pcm = np.clip(np.round(x * 32767), -32768, 32767).astype(np.int16)[:, None]
+    if n_ch == 2:
+        pcm = np.concatenate([pcm, -pcm if file_sr == 16000 else (pcm // 2)], 1)      # 16 kHz case: opposite-phase stereo
+    want = segmenter.pcm_to_mono(pcm, file_sr, 8000)
+    got = eng.pcm16_to_mono(pcm, sample_rate=file_sr).cpu().numpy()
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 2e-6
+    if n_ch == 2 and file_sr == 16000:
+        assert np.abs(got).max() > 0.3                                           # the flipped channel did not cancel
+    assert np.array_equal(eng.pcm16_to_mono(pcm, sample_rate=8000).cpu().numpy(), segmenter.pcm_to_mono(pcm))

@@ -284,3 +284,19 @@ def test_torch_synth_generators_are_pure_functions_of_ids():
     s0, s1 = synth.make_state_dict(params, 123), synth.make_state_dict_calibrated(params, 123)
     diff = [k for k in s0 if not np.array_equal(s0[k], s1[k])]
     assert diff == ["g.linear2.bias"]
+
+
+def test_resample_host_tables_match_the_oracle_restatement():
+    """pfann_amd/resample.py (what the device kernel is fed) against oracle/resample.py: filter table bit-identical, the
+    same pieces."""
+    from oracle import resample as R
+    from pfann_amd import resample as P
+    for old, new in ((44100, 8000), (16000, 8000), (11025, 8000), (48000, 8000), (22050, 8000), (7000, 8000)):
+        tab, o, n, width = P.filter_table(old, new)
+        k, w = R.kernels(old, new)
+        assert (o, n) == R.reduced(old, new) and width == w and np.array_equal(tab, k.numpy())
+        for n_in in (1, 999, old, old * 60 - 1, old * 60, old * 61 + 17, old * 125, old * 119 + 1):
+            plan, n_out = P.piece_plan(n_in, old, new)
+            ref = R.chunk_plan(n_in, old, new)
+            assert [tuple(r[:4]) for r in plan.tolist()] == [tuple(r) for r in ref]
+            assert n_out == sum(r[3] for r in ref) and plan[:, 4].tolist() == np.cumsum([0] + [r[3] for r in ref[:-1]]).tolist()

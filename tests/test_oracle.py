@@ -173,3 +173,32 @@ def test_melspec_oracle_vs_independent_third_party():
         loud = ref > ref.max() - 5.0
         assert np.abs(ref - lm)[loud].max() < 3e-4, np.abs(ref - lm)[loud].max()
         assert np.abs(ref - lm).max() < 3e-3
+
+
+# ------------------------------------------------------------------ a1 at other sample rates (parity unpinned: julius absent)
+def test_resampler_restatement_properties():
+    """No reference vector exists for julius.ResampleFrac (absent, unpinned): check what the published algorithm
+    guarantees -- unit-sum phases (constants preserved), the documented output length, a 1 kHz tone surviving 44.1 -> 8 kHz
+    to 1e-5 away from the edges, everything above the new Nyquist removed -- and the reference's minute-wise assembly."""
+    from oracle import resample as R
+    k, width = R.kernels(44100, 8000)
+    assert k.shape == (80, 2 * 140 + 441) and width == 140
+    assert float((k.sum(1) - 1).abs().max()) < 1e-6
+    assert R.resample_frac(np.full((2, 44100), 0.25, np.float32), 44100, 8000).shape == (2, 8000)
+    assert np.abs(R.resample_frac(np.full((1, 50000), 0.25, np.float32), 44100, 8000) - 0.25).max() < 1e-6
+    assert R.resample_frac(np.zeros((1, 12345), np.float32), 44100, 8000).shape[1] == int(80 * 12345 / 441)
+    x = np.zeros((1, 777), np.float32)
+    assert R.resample_frac(x, 8000, 8000) is not None and R.resample_frac(x, 16000, 16000).shape == (1, 777)
+    t = np.arange(44100 * 125) / 44100.0
+    tone = np.sin(2 * np.pi * 1000 * t).astype(np.float32)[None]
+    y = R.resample_chunked(tone, 44100, 8000)
+    assert y.shape == (1, 125 * 8000)                                  # two full pieces + tail: seams at 59.5 s and 118.5 s
+    ref = np.sin(2 * np.pi * 1000 * np.arange(y.shape[1]) / 8000.0)
+    assert np.abs(y[0] - ref)[4000:-4000].max() < 1e-5                 # incl. both seams
+    hiss = np.sin(2 * np.pi * 6000 * t[:44100 * 3]).astype(np.float32)[None]     # above the 4 kHz Nyquist
+    assert np.abs(R.resample_frac(hiss, 44100, 8000))[0, 400:-400].max() < 2e-3
+    # piece plan: 59 s stride, half-second strips, lengths add up
+    plan = R.chunk_plan(44100 * 125, 44100, 8000)
+    assert plan[0] == (0, 2646000, 0, 476000) and plan[1] == (2601900, 2646000, 4000, 472000)
+    assert sum(p[3] for p in plan) == 125 * 8000
+    assert R.chunk_plan(1000, 16000, 8000) == [(0, 1000, 0, 500)]
