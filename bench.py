@@ -43,6 +43,28 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def self_launch(n, backend):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this very command (one per GPU, RCCL unless
+    PFANN_DIST_BACKEND says otherwise) and return their exit status.  Fails before starting anything when the box does
+    not have N devices for an RCCL job."""
+    import socket
+    import subprocess
+    if backend == "nccl" and "PFANN_FORCE_DEVICE" not in os.environ:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            log("bench.py --gpus %d: only %d HIP device(s) visible; an RCCL job needs one device per rank -- refusing to "
+                "run fewer ranks than asked for" % (n, have))
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("bench.py: launching %d ranks: %s" % (n, " ".join(cmd)))
+    return subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,8 +88,29 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the informational fp16-storage run")
     ap.add_argument("--no-prof", action="store_true")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only start the ranks, meet in the process group, print who is there (n_gpus, ranks_seen, backend, "
+                         "devices) and exit: the launcher's own test, runs without a GPU under PFANN_DIST_BACKEND=gloo")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the sharded protocol (two-phase search, all-to-all, merge, all-gathers, device pick) even at "
+                         "world 1: every collective then really goes through the backend (RCCL on one GPU)")
     ap.add_argument("--dump-decisions", default=None, help="write (song, offset, score) per query as .npy (rank 0)")
     args = ap.parse_args()
+
+    # ------------------------------------------------------------------ ranks: launch, verify, never fall through
+    # `python bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment) starts its own N ranks, one per GPU, through
+    # torch.distributed.run on 127.0.0.1; launched externally (the driver's form), WORLD_SIZE must equal --gpus.  No code
+    # path below prints an `n_gpus` different from --gpus.
+    backend = os.environ.get("PFANN_DIST_BACKEND", "nccl")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus, backend))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log("bench.py: launched with WORLD_SIZE=%d but --gpus %d: refusing to run (start it as `python bench.py --gpus %d` "
+            "or with torch.distributed.run --nproc-per-node %d)" % (world, args.gpus, args.gpus, args.gpus))
+        sys.exit(2)
 
     import torch
     import torch.distributed as dist
@@ -78,29 +121,54 @@ def main():
     from pfann_amd.engine import Engine
     from pfann_amd.utils import read_config
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node = --gpus"
-    plib.require_gpu()
+    if not args.launch_check:
+        plib.require_gpu()
     # PFANN_FORCE_DEVICE / PFANN_DIST_BACKEND=gloo: debugging aid to run the N-rank path on a box
     # with a single GPU (all ranks share it); the driver's multi-GPU runs use neither.
     if "PFANN_FORCE_DEVICE" in os.environ:
         local_rank = int(os.environ["PFANN_FORCE_DEVICE"])
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        backend = os.environ.get("PFANN_DIST_BACKEND", "nccl")
+    have_gpu = torch.cuda.is_available()
+    if have_gpu:
+        if local_rank >= torch.cuda.device_count():
+            log("bench.py: rank %d wants HIP device %d but only %d are visible" % (rank, local_rank, torch.cuda.device_count()))
+            sys.exit(2)
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank) if have_gpu else torch.device("cpu")
+    in_group = "WORLD_SIZE" in os.environ            # also at world 1 under a launcher: the RCCL calls then really run
+    ranks_info = {"ranks_seen": 1, "backend": None, "devices": [local_rank if have_gpu else -1]}
+    if in_group:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        seen = [None] * world
+        dist.all_gather_object(seen, (rank, torch.cuda.current_device() if have_gpu else -1))
+        ranks_info = {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(),
+                      "devices": [dv for _, dv in sorted(seen)]}
+        if sorted(r for r, _ in seen) != list(range(world)) or dist.get_world_size() != args.gpus:
+            log("bench.py: rank set %r does not cover --gpus %d" % (seen, args.gpus))
+            sys.exit(2)
+        if backend == "nccl" and len(set(ranks_info["devices"])) != world:
+            log("bench.py: %d ranks share HIP devices %r: RCCL needs one device per rank" % (world, ranks_info["devices"]))
+            sys.exit(2)
+    if args.launch_check:
+        # what the CPU test of the launcher reads: the ranks really exist and have met in one process group
+        if in_group:
+            t = torch.ones(1, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t)
+            ranks_info["all_reduce_of_ones"] = int(t.item())
+        if rank == 0:
+            print(json.dumps(dict({"launch_check": True, "n_gpus": world}, **ranks_info)), flush=True)
+        if in_group:
+            dist.destroy_process_group()
+        return
 
     # PFANN_EMULATE_WORLD=N (tuning aid, single process): do rank 0's share of an N-rank job -- 1/N of the db,
     # 1/N of the queries embedded (then tiled to the full batch), the sharded query path with its merge and
     # owned-only rerank -- without the collectives.  Shows how the per-rank work shrinks with N; never a result.
     emu = int(os.environ.get("PFANN_EMULATE_WORLD", "0"))
     if emu > 1:
+        assert not in_group, "PFANN_EMULATE_WORLD is a single-process aid"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29611")
         dist.init_process_group("gloo", rank=0, world_size=1)
@@ -163,8 +231,12 @@ def main():
         builder_segs += len(ids) * SEG_PER_SONG
     index = DeviceIndex(d, local_rank)
     index.load(shard, song_pos, r_lo)
-    if world > 1 or emu > 1:
-        sharded = ShardedIndex(index, song_pos, k, 1, 0.0)
+    use_sharded = world > 1 or emu > 1 or args.force_sharded
+    if args.force_sharded and not in_group:
+        log("bench.py: --force-sharded needs a process group (start with torch.distributed.run --nproc-per-node 1)")
+        sys.exit(2)
+    if use_sharded:
+        sharded = ShardedIndex(index, song_pos, k, 1, 0.0, always_exchange=args.force_sharded)
 
     # ----------------------------------------------------------------- queries (untimed)
     Q = args.queries * ((emu if emu > 1 else world) if args.scaling == "weak" else 1)      # queries per step, whole job
@@ -185,7 +257,7 @@ def main():
         q_off_t.append(qo)
     q_pcm_mine = torch.cat(q_pcm_t)                                         # [my queries, 80000] int16 on the device
     q_off_mine = torch.cat(q_off_t)
-    if world > 1:
+    if in_group:
         q_off = all_gather_ragged(q_off_mine.reshape(-1, 1), [hi - lo for lo, hi in split_even(Q, world)]).reshape(-1).cpu().numpy()
     else:
         q_off = np.full(Q, 1e9)                                             # emulation: only rank 0's slice is known
@@ -210,7 +282,7 @@ def main():
         if emu > 1:
             emb = emb.repeat(emu, 1)[: Q * QUERY_SEGS].contiguous()
             return sharded.query_batch(emb, qstart, qlen), emb
-        if world > 1:
+        if use_sharded:
             emb = all_gather_ragged(emb, q_counts)
             return sharded.query_batch(emb, qstart, qlen), emb
         D, I = cur_index[0].search(emb, k)
@@ -218,7 +290,7 @@ def main():
         return res, emb
 
     def fence():
-        if world > 1:
+        if in_group:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -239,7 +311,7 @@ def main():
     lib.pfann_prof_marker(None)
     if prof:
         lib.pfann_prof_enable(0)
-    if world > 1:
+    if in_group:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -256,7 +328,7 @@ def main():
             step(True)
         fence()
         el = time.perf_counter() - tp
-        if world > 1:
+        if in_group:
             t = torch.tensor([el], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
@@ -266,7 +338,7 @@ def main():
 
     # ---- informational: fp16-only storage of the same db (BASELINE config 5's "fp16 embeddings"; never `value`)
     alt = None
-    if world == 1 and emu <= 1 and not args.no_alt:
+    if world == 1 and emu <= 1 and not use_sharded and not args.no_alt:
         idx16 = DeviceIndex(d, local_rank, storage="f16")
         idx16.load(shard, song_pos, r_lo)
         cur_index[0] = idx16
@@ -506,6 +578,7 @@ def main():
             "metric": "query segments/sec, 10 s @ SNR %g queries vs %s-segment db (exact flat IP top-100 + sequence match)"
                       % (args.snr, "1M" if n_rows == 1000050 else str(n_rows)),
             "value": round(value, 1), "unit": "segments/s", "n_gpus": world, "steps": args.steps,
+            "ranks_seen": ranks_info["ranks_seen"], "backend": ranks_info["backend"], "devices": ranks_info["devices"],
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
             "dtype_note": "all results exact fp32 (fp32 MFMA encoder; batched scan pre-filtered on fp16 MFMA with a rigorous "
@@ -536,7 +609,7 @@ def main():
                         for t, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if in_group:
         dist.destroy_process_group()
 
 

@@ -78,7 +78,10 @@ def all_gather_ragged(x, counts, group=None):
 
 
 class ShardedIndex:
-    def __init__(self, backend, song_pos, top_k, frame_shift_mul=1, score_alpha=0.0, group=None):
+    def __init__(self, backend, song_pos, top_k, frame_shift_mul=1, score_alpha=0.0, group=None, always_exchange=False):
+        """always_exchange: run the whole exchange protocol (bound all-gather, all-to-all, merge, all-gathers) even when
+        the group has one rank -- a one-GPU box then exercises every collective of the N-rank path on its real backend."""
+        self.always_exchange = always_exchange
         self.b = backend
         self.song_pos = np.asarray(song_pos, dtype=np.int64)
         self.k = top_k
@@ -99,7 +102,7 @@ class ShardedIndex:
         then the merged slices are all-gathered -- every rank receives 2*Q*k entries instead of G*Q*k
         (an all-gather of everything was 93 MB per rank and step at 8 GPUs) and merges 1/G of the rows."""
         G, k, Q = self.world, self.k, q.shape[0]
-        if G == 1:
+        if G == 1 and not self.always_exchange:
             return self.b.search(q, k)
         # Two-phase shard search: every rank extracts from its sampled pass the m best scores of each row (m different
         # real rows of its shard, lowered to bounds of their exact scores), the values are all-gathered (4 m bytes per row

@@ -62,3 +62,60 @@ def test_two_rank_sharded_path_matches_single_gpu(tmp_path, scaling):
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert out["n_gpus"] == 2 and out["scaling"] == scaling
     assert out["config"]["queries_per_step"] == 24 and out["config"]["queries_per_step_per_gpu"] == 12
+
+
+def _clean_env(**kw):
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PFANN_DIST_BACKEND", "PFANN_FORCE_DEVICE")}
+    e.update(kw)
+    return e
+
+
+def test_plain_gpus2_on_a_one_gpu_box_fails_loudly_or_runs_two_rccl_ranks():
+    """`python bench.py --gpus 2` never reports n_gpus 1: with fewer than 2 devices it refuses (non-zero, no JSON);
+    with 2+ devices it really runs two RCCL ranks on two devices."""
+    import torch
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--queries", "12", "--db-songs", "600", "--no-cpu-baseline", "--no-prof", "--max-batch", "512"],
+                       capture_output=True, text=True, timeout=900, cwd=REPO, env=_clean_env())
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and not lines, r.stdout[-1000:]
+        assert "refusing" in r.stderr
+    else:
+        assert r.returncode == 0, r.stderr[-3000:]
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["backend"] == "nccl" and len(set(out["devices"])) == 2
+
+
+def test_self_launched_two_ranks_report_two(tmp_path):
+    """the launcher itself on the real kernels: plain `python bench.py --gpus 2` (gloo-staged collectives, both ranks on
+    this box's one GPU) -> n_gpus 2, ranks_seen 2."""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--queries", "12", "--db-songs", "600", "--no-cpu-baseline", "--no-prof", "--max-batch", "512"],
+                       capture_output=True, text=True, timeout=900, cwd=REPO,
+                       env=_clean_env(PFANN_DIST_BACKEND="gloo", PFANN_FORCE_DEVICE="0"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["backend"] == "gloo" and out["devices"] == [0, 0]
+
+
+def test_rccl_collectives_of_the_sharded_path_on_one_gpu(tmp_path):
+    """RCCL really executes: one rank under torch.distributed.run with the default nccl backend and --force-sharded, so
+    the bound all-gather, the all-to-all of the shard lists, the merged-slice all-gathers, the key all-gather, the ragged
+    embedding gather, the barrier and the MAX all-reduce all go through RCCL; decisions equal the plain single-GPU run."""
+    import numpy as np
+    common = ["--steps", "1", "--warmup", "0", "--db-songs", "600", "--queries", "24", "--no-cpu-baseline", "--no-prof",
+              "--max-batch", "512"]
+    one, two = str(tmp_path / "one.npy"), str(tmp_path / "rccl.npy")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + common + ["--dump-decisions", one],
+                       capture_output=True, text=True, timeout=900, cwd=REPO, env=_clean_env())
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29741", os.path.join(REPO, "bench.py"),
+                        "--gpus", "1", "--force-sharded"] + common + ["--dump-decisions", two],
+                       capture_output=True, text=True, timeout=900, cwd=REPO, env=_clean_env(MASTER_ADDR="127.0.0.1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["backend"] == "nccl" and out["ranks_seen"] == 1 and out["n_gpus"] == 1
+    a, b = np.load(one), np.load(two)
+    assert np.array_equal(a[:, :2], b[:, :2]) and np.abs(a[:, 2] - b[:, 2]).max() < 1e-6
