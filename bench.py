@@ -9,11 +9,12 @@ int16 PCM is already resident in HBM:
     -> (song, offset) decisions on the host.
 The database is REAL: every one of the 16,950 synthetic songs (1,000,050 segments) is embedded by the path itself,
 through the builder's own loop (pfann_amd.builder.embed_files, host PCM in -> fingerprints in HBM), whose throughput
-is reported as `builder`.  `value` is timed with the query PCM resident in HBM (the contract's definition); the same
-step with the PCM handed over in pinned host memory (H2D inside the timed region) is reported as `pcie_inclusive`.
+is reported as `builder`.  `value` is SURVEY 8(d)'s metric: wall time from PCM in (pinned) HOST memory to decisions on
+the host, i.e. the H2D of the step's query PCM is inside the timed region; the same step with the PCM already resident in
+HBM is reported beside it as `hbm_resident` (about 1 % faster).
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W           (N > 1: starts its own N ranks, one per GPU, RCCL)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...     (the driver's form)
 
 N > 1: the db is sharded by songs over the ranks (strong scaling: same db, same query batch);
 each rank embeds 1/N of the query windows, embeddings and per-shard top-k are all-gathered
@@ -41,6 +42,93 @@ PEAK_HBM = 8000.0            # GB/s
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline_leg(args, params, sd, shard, song_pos, q_pcm_mine, res, k, n_rows):
+    """The oracle (a CPU restatement of the reference's path: `kind` = "port") timed on this box's host cores on a bounded
+    sample of the same queries against the same database, split by the reference's stage names (tools/stat.py:17):
+    compute embedding = torch-CPU mel + encoder, search = BLAS sgemm + argpartition top-k (the IndexFlatIP stand-in;
+    faiss-cpu is not installable here), rerank = the C restatement of cpp/seqscore.cpp (OpenMP).  The thread count is
+    swept on a small probe and the best setting runs the sample; also: encoder rates at the reference's batch sizes
+    (builder 32, matcher 16) and the reference's default Python double-loop rerank (database.py:143-163) on 3 queries."""
+    import torch
+    from threadpoolctl import threadpool_limits
+    from oracle import encoder as oe
+    from oracle import melspec as om
+    from oracle import native, search as osr, segmenter as osg, seqscore as osq
+    nq_cpu = min(args.cpu_queries, q_pcm_mine.shape[0])
+    db_host = shard.cpu().numpy()
+    q_pcm = q_pcm_mine[:nq_cpu].cpu().numpy()
+    native.lib()
+    ncpu = os.cpu_count() or 1
+    default_threads = torch.get_num_threads()
+
+    def run(js, nthreads):
+        """-> (stage seconds dict, decisions) for queries js with `nthreads` torch / BLAS / OpenMP threads"""
+        torch.set_num_threads(nthreads)
+        st = {"compute embedding": 0.0, "search": 0.0, "rerank": 0.0}
+        dec = []
+        with threadpool_limits(limits=nthreads):
+            for j in js:
+                t0 = time.perf_counter()
+                segs = osg.segment(osg.pcm_to_mono(q_pcm[j][:, None]), 8000, 4000)
+                e = oe.encode(om.melspec(segs, params), sd, params)
+                t1 = time.perf_counter()
+                Dc, Ic = osr.flat_ip_topk_blas(e, db_host, k)
+                t2 = time.perf_counter()
+                best, ss = native.seq_score(db_host, song_pos, e, Ic, 1, 0.0)
+                t3 = time.perf_counter()
+                st["compute embedding"] += t1 - t0
+                st["search"] += t2 - t1
+                st["rerank"] += t3 - t2
+                dec.append((best, int(ss[best, 1]) if best >= 0 else 0, e, Ic))
+        return st, dec
+
+    sweep = {}
+    for nt in sorted({min(16, ncpu), min(64, ncpu), default_threads, ncpu}):
+        run([0], nt)                                                       # warm this setting
+        stp, _ = run(list(range(min(4, nq_cpu))), nt)
+        sweep[nt] = round(min(4, nq_cpu) * QUERY_SEGS / sum(stp.values()), 1)
+    best_nt = max(sweep, key=lambda t: sweep[t])
+    tc = time.perf_counter()
+    st, dec = run(list(range(nq_cpu)), best_nt)
+    tcpu = time.perf_counter() - tc
+    agree = sum(1 for j, (b, off, _, _) in enumerate(dec) if b == int(res[j]["song"]) and off == int(res[j]["offset"]))
+    nseg = nq_cpu * QUERY_SEGS
+    # encoder alone at the reference's batch sizes (builder.py:88: 32, matcher.py:110: 16)
+    enc = {}
+    torch.set_num_threads(best_nt)
+    segs = osg.segment(osg.pcm_to_mono(np.concatenate([q_pcm[j] for j in range(min(2, nq_cpu))])[:, None]), 8000, 4000)[:32]
+    mel = om.melspec(segs, params)
+    for bsz in (16, 32):
+        if mel.shape[0] >= bsz:
+            oe.encode(mel[:bsz], sd, params)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                oe.encode(mel[:bsz], sd, params)
+            enc["batch_%d" % bsz] = round(3 * bsz / (time.perf_counter() - t0), 1)
+    # the reference's DEFAULT rerank: the Python double loop over candidates and rows (cpp_accelerate = False)
+    npy = min(3, nq_cpu)
+    t0 = time.perf_counter()
+    py_same = 0
+    for j in range(npy):
+        _, _, e, Ic = dec[j]
+        sco, (sid, sec), _ = osq.query_embeddings_base(e, Ic, db_host, song_pos, 0.5, 1)
+        py_same += int(sid == dec[j][0] and sec == dec[j][1] * 0.5)
+    t_py = (time.perf_counter() - t0) / max(npy, 1)
+    torch.set_num_threads(default_threads)
+    cpu = {"value": round(nseg / tcpu, 2), "unit": "segments/s", "cores": best_nt, "kind": "port",
+           "sample": "%d of the same 10 s queries (%d segments) vs the same %d-row db: torch-CPU mel+encoder, BLAS sgemm + "
+                     "argpartition top-%d, C seq_score (OpenMP); host has %d logical cores; torch default %d threads, "
+                     "OMP_NUM_THREADS=%s" % (nq_cpu, nseg, n_rows, k, ncpu, default_threads, os.environ.get("OMP_NUM_THREADS")),
+           "thread_sweep_segments_per_s": {str(t): v for t, v in sweep.items()},
+           "stages_s": {kk: round(v, 3) for kk, v in st.items()},
+           "stage_segments_per_s": {kk: round(nseg / v, 1) for kk, v in st.items() if v > 0},
+           "encoder_segments_per_s": enc,
+           "python_rerank": {"queries": npy, "seconds_per_query": round(t_py, 3), "segments_per_s": round(QUERY_SEGS / t_py, 1),
+                             "same_decision_as_c_path": "%d/%d" % (py_same, npy),
+                             "what": "database.py:143-163 restated (oracle/seqscore.py): Python loop over <= 1900 candidates x 19 rows"}}
+    return cpu, {"queries": nq_cpu, "identical_song_and_offset": int(agree)}
 
 
 def self_launch(n, backend):
@@ -82,7 +170,10 @@ def main():
     ap.add_argument("--max-batch", type=int, default=9728,
                     help="encoder chunk (segments); 9728 = the whole step in one chunk: 29 GB of activations, and the\n"
                          "small late layers get enough 128x128 tiles to fill the 512 resident workgroups")
-    ap.add_argument("--cpu-queries", type=int, default=12, help="bounded sample for the CPU baseline")
+    ap.add_argument("--cpu-queries", type=int, default=64, help="bounded sample for the CPU baseline")
+    ap.add_argument("--no-cli", action="store_true", help="skip the drop-in CLI leg (builder.py / matcher.py from WAV files)")
+    ap.add_argument("--cli-songs", type=int, default=10000, help="CLI leg: songs written as WAVs (BASELINE config 2: 10 k)")
+    ap.add_argument("--cli-queries", type=int, default=2000, help="CLI leg: 10 s queries written as WAVs")
     ap.add_argument("--encoder-precision", type=int, default=0, choices=[0, 1],
                     help="0: exact fp32 MFMA (default, the headline); 1: opt-in 3-term fp16 split (pfann_set_encoder_precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -276,7 +367,7 @@ def main():
 
     cur_index = [index]
 
-    def step(from_host=False):
+    def step(from_host=True):
         wav = eng.pcm16_to_mono(pcm_host.to(dev, non_blocking=True) if from_host else pcm_dev)
         emb = eng.embed_windows(wav, starts_dev)
         if emu > 1:
@@ -318,14 +409,14 @@ def main():
     n_seg = Q * QUERY_SEGS
     value = n_seg * args.steps / elapsed
 
-    # ---- the same step with the query PCM handed over in pinned host memory (never `value`)
+    # ---- the same step with the query PCM already resident in HBM (reported beside `value`)
     pcie = None
     if emu <= 1:
-        step(True)
+        step(False)
         fence()
         tp = time.perf_counter()
         for _ in range(args.steps):
-            step(True)
+            step(False)
         fence()
         el = time.perf_counter() - tp
         if in_group:
@@ -333,8 +424,50 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         pcie = {"value": round(n_seg * args.steps / el, 1), "unit": "segments/s", "ms_per_step": round(1e3 * el / args.steps, 3),
-                "what": "same step, int16 query PCM in pinned host memory, H2D (%.1f MB/step/rank) inside the timed region"
-                        % (pcm_host.numel() * 2 / 1e6)}
+                "what": "same step with the int16 query PCM already resident in HBM (`value` includes the H2D of %.1f MB per "
+                        "step and rank from pinned host memory)" % (pcm_host.numel() * 2 / 1e6)}
+
+    # ---- the reference's own native seam (cpp/seqscore.cpp:32-43 via database.py:178-189): host pointers in, best
+    # song out; 200 calls, median and p95, once here and once more after the fp16-storage leg below
+    seam_before = seam_after = None
+
+    def seam_leg():
+        import ctypes
+        from oracle import native
+        q1 = np.ascontiguousarray(emb[:QUERY_SEGS].cpu().numpy())
+        _, I1 = index.search(emb[:QUERY_SEGS].contiguous(), k)
+        lab1 = np.ascontiguousarray(I1.cpu().numpy())
+        f32p, i64p = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int64)
+        ss = np.zeros((n_songs, 2), np.float32)
+        args_c = (index.handle, song_pos.ctypes.data_as(i64p), n_songs, q1.ctypes.data_as(f32p), QUERY_SEGS,
+                  lab1.ctypes.data_as(i64p), k, ss.ctypes.data_as(f32p), 1, 0.0)
+        torch.cuda.synchronize()
+        for _ in range(20):
+            ss[:] = 0
+            b_gpu = lib.seq_score(*args_c)
+        ts = []
+        for _ in range(200):
+            ss[:] = 0                                                 # database.py:176: the caller zeroes the block
+            t1 = time.perf_counter()
+            lib.seq_score(*args_c)
+            ts.append(time.perf_counter() - t1)
+        ss_gpu = ss.copy()
+        ts = np.sort(np.asarray(ts)) * 1e6
+        db_host = shard.cpu().numpy()
+        b_cpu, ss_cpu = native.seq_score(db_host, song_pos, q1, lab1, 1, 0.0)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            native.seq_score(db_host, song_pos, q1, lab1, 1, 0.0)
+        seam_cpu_us = 1e6 * (time.perf_counter() - t1) / 5
+        return {"gpu_call_us_median": round(float(ts[len(ts) // 2]), 1), "gpu_call_us_p95": round(float(ts[int(len(ts) * 0.95)]), 1),
+                "gpu_call_us_min": round(float(ts[0]), 1), "calls": len(ts),
+                "cpu_oracle_call_us": round(seam_cpu_us, 1),
+                "same_best_song": bool(b_gpu == b_cpu), "max_abs_score_diff": float(np.abs(ss_gpu - ss_cpu)[:, 0].max()),
+                "what": "seq_score(index, song_pos, n_songs=%d, query[19x128], labels[19x100], song_scores, 1, 0) with host "
+                        "pointers, as database.py:178-189 calls it (the caller's zeroing of song_scores outside the clock); pinned "
+                        "staging + private stream in the handle; cpu_oracle = the C restatement of cpp/seqscore.cpp, OpenMP" % n_songs}
+    if rank == 0 and world == 1 and not use_sharded and emu <= 1 and not args.no_cpu_baseline:
+        seam_before = seam_leg()
 
     # ---- informational: fp16-only storage of the same db (BASELINE config 5's "fp16 embeddings"; never `value`)
     alt = None
@@ -359,6 +492,8 @@ def main():
             "value": round(n_seg / el, 1), "unit": "segments/s", "ms_per_step": round(1e3 * el, 3),
             "decisions_identical_to_fp32_db": "%d/%d" % (same, Q), "top1_hit_rate": round(hit16 / Q, 4)}}
         del idx16
+    if seam_before is not None:
+        seam_after = seam_leg()
 
     # ------------------------------------------------------------ per-kernel event times
     kernels = {}
@@ -519,56 +654,26 @@ def main():
     # ------------------------------------------- CPU baseline + decision parity (rank 0)
     cpu = None
     parity = None
-    seam_info = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import encoder as oe
-        from oracle import melspec as om
-        from oracle import native, search as osr, segmenter as osg
-        nq_cpu = min(args.cpu_queries, Q)
-        db_host = shard.cpu().numpy()
-        q_pcm = q_pcm_mine[:nq_cpu].cpu().numpy()
-        native.lib()
-        tc = time.perf_counter()
-        agree = 0
-        for j in range(nq_cpu):
-            segs = osg.segment(osg.pcm_to_mono(q_pcm[j][:, None]), 8000, 4000)
-            e = oe.encode(om.melspec(segs, params), sd, params)
-            Dc, Ic = osr.flat_ip_topk_blas(e, db_host, k)
-            best, ss = native.seq_score(db_host, song_pos, e, Ic, 1, 0.0)
-            agree += (best == int(res[j]["song"]) and int(ss[best, 1]) == int(res[j]["offset"]))
-        tcpu = time.perf_counter() - tc
-        cpu = {"value": round(nq_cpu * QUERY_SEGS / tcpu, 2), "unit": "segments/s",
-               "cores": torch.get_num_threads(), "kind": "port",
-               "sample": "%d of the same 10 s queries (%d segments) vs the same %d-row db: torch-CPU "
-                         "mel+encoder, BLAS sgemm + argpartition top-%d, C seq_score; host has %d logical cores"
-                         % (nq_cpu, nq_cpu * QUERY_SEGS, n_rows, k, os.cpu_count())}
-        parity = {"queries": nq_cpu, "identical_song_and_offset": int(agree)}
-        # the reference's own native seam (cpp/seqscore.cpp:32-43 via database.py:178-189): host pointers in, best song
-        # out, against the same call on the oracle's C restatement (OpenMP over candidates) on the host cores
-        import ctypes
-        q1 = np.ascontiguousarray(emb[:QUERY_SEGS].cpu().numpy())
-        _, I1 = index.search(emb[:QUERY_SEGS].contiguous(), k)
-        lab1 = np.ascontiguousarray(I1.cpu().numpy())
-        f32p, i64p = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int64)
+    if rank == 0 and world == 1 and not use_sharded and not args.no_cpu_baseline:
+        cpu, parity = cpu_baseline_leg(args, params, sd, shard, song_pos, q_pcm_mine, res, k, n_rows)
+    if seam_before is not None:
+        seam_info = dict(seam_after, before_fp16_leg={kk: seam_before[kk] for kk in ("gpu_call_us_median", "gpu_call_us_p95")})
+    else:
+        seam_info = None
 
-        def seam():
-            ss = np.zeros((n_songs, 2), np.float32)
-            return lib.seq_score(index.handle, song_pos.ctypes.data_as(i64p), n_songs, q1.ctypes.data_as(f32p), QUERY_SEGS,
-                                 lab1.ctypes.data_as(i64p), k, ss.ctypes.data_as(f32p), 1, 0.0), ss
-        b_gpu, ss_gpu = seam()
-        t1 = time.perf_counter()
-        for _ in range(50):
-            seam()
-        seam_us = 1e6 * (time.perf_counter() - t1) / 50
-        b_cpu, ss_cpu = native.seq_score(db_host, song_pos, q1, lab1, 1, 0.0)
-        t1 = time.perf_counter()
-        for _ in range(5):
-            native.seq_score(db_host, song_pos, q1, lab1, 1, 0.0)
-        seam_cpu_us = 1e6 * (time.perf_counter() - t1) / 5
-        seam_info = {"gpu_call_us": round(seam_us, 1), "cpu_oracle_call_us": round(seam_cpu_us, 1),
-                     "same_best_song": bool(b_gpu == b_cpu), "max_abs_score_diff": float(np.abs(ss_gpu - ss_cpu)[:, 0].max()),
-                     "what": "seq_score(index, song_pos, n_songs, query[19x128], labels[19x100], song_scores, 1, 0) with host "
-                             "pointers, as database.py:178-189 calls it; device scratch cached in the handle"}
+    # ------------------------------------------- the drop-in CLIs from WAV files on disk (rank 0, N = 1)
+    cli = None
+    if rank == 0 and world == 1 and not use_sharded and emu <= 1 and not args.no_cli:
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        import cli_bench
+        try:
+            cli = cli_bench.run(args.cli_songs, args.cli_queries, args.snr, device=local_rank, log=log)
+            if "builder" in cli:
+                cli["cli_builder_segments_per_s"] = cli["builder"]["segments_per_s"]
+                cli["cli_matcher_segments_per_s"] = cli["matcher"]["segments_per_s"]
+                cli["library_step_segments_per_s"] = round(value, 1)
+        except Exception as x:                                          # never lose the headline line to the side leg
+            cli = {"error": repr(x)[:500]}
 
     if rank == 0 and args.dump_decisions:
         np.save(args.dump_decisions, np.stack([res["song"].astype(np.float64), res["offset"].astype(np.float64),
@@ -603,7 +708,8 @@ def main():
                 "what": "pfann_amd.builder.embed_files over this rank's songs: int16 PCM in pinned host memory -> H2D -> mono -> "
                         "windows -> log-mel -> encoder -> unit-norm fingerprints in HBM (builder.py:75-103's loop), "
                         "%d windows per launch group" % args.max_batch},
-            "pcie_inclusive": pcie, "seq_score_seam": seam_info,
+            "value_includes": "H2D of the query PCM from pinned host memory (SURVEY 8d: PCM-in-host-memory to decisions)",
+            "hbm_resident": pcie, "seq_score_seam": seam_info, "cli": cli,
             "alt_modes": alt,
             "kernels": {t: {kk: (float("%.4g" % vv) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                         for t, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <map>
+#include <mutex>
 
 #include "kernels.h"
 
@@ -565,8 +566,15 @@ struct pfann_db {
     bool prefilter = true;
     void *match_scratch = nullptr;      // long-query candidate slab (keys + sums), grown on demand
     size_t match_scratch_bytes = 0;
-    void *seq_scratch = nullptr;        // device buffers of the seq_score seam, kept between calls
+    // the seq_score seam (the reference's ctypes call, database.py:178-189): device slab, PINNED host image and a
+    // private stream, kept between calls; seq_mu serialises concurrent callers on one handle (the reference's seam is
+    // re-entrant: cpp/seqscore.cpp keeps no state)
+    void *seq_scratch = nullptr;
     size_t seq_scratch_bytes = 0;
+    char *seq_host = nullptr;
+    size_t seq_host_bytes = 0;
+    hipStream_t seq_stream = nullptr;
+    std::mutex seq_mu;
 };
 
 extern "C" {
@@ -592,6 +600,8 @@ void pfann_db_destroy(pfann_db *db) {
     if (db->ws.row_ovf) (void)hipFree(db->ws.row_ovf);
     if (db->match_scratch) (void)hipFree(db->match_scratch);
     if (db->seq_scratch) (void)hipFree(db->seq_scratch);
+    if (db->seq_host) (void)hipHostFree(db->seq_host);
+    if (db->seq_stream) (void)hipStreamDestroy(db->seq_stream);
     if (db->emb_h) (void)hipFree(db->emb_h);
     delete db;
 }
@@ -775,45 +785,61 @@ int seq_score(void *index, const int64_t *song_pos, int n_songs, const float *qu
         return -1;
     }
     if (query_len <= 0 || top_k <= 0) return -1;
-    // One device slab, kept in the handle between calls (grown on demand), laid out
+    // One device slab and one pinned host image, kept in the handle between calls (grown on demand), laid out
     //   [song_scores f32 n_songs*2 | result | qstart i64 | qlen i32 | query f32 | labels i64]
-    // and filled with ONE upload from a host image of everything but the score block; one download brings
-    // back (song_scores, result).  Per call: 1 memset + 1 H2D + the match launches + 1 D2H, no allocation.
+    // Per call: host memcpy of the inputs into the pinned image, then on the handle's private stream 1 memset + 1 H2D
+    // + the match launches + 1 D2H, and ONE wait for that stream.  No allocation, no pageable staging copies, no
+    // null-stream synchronisation with whatever else the process has in flight.
+    std::lock_guard<std::mutex> lock(db->seq_mu);
     const size_t nq = (size_t)query_len;
     const size_t ss_bytes = (size_t)std::max(n_songs, 1) * 2 * sizeof(float);
     auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
     const size_t o_res = up16(ss_bytes), o_qs = o_res + up16(sizeof(pfann_match_result)), o_ql = o_qs + 16;
     const size_t o_q = o_ql + 16, o_l = o_q + up16(nq * db->d * sizeof(float));
     const size_t total = o_l + nq * top_k * sizeof(int64_t);
+    if (!db->seq_stream && hipStreamCreateWithFlags(&db->seq_stream, hipStreamNonBlocking) != hipSuccess) {
+        set_error("seq_score: stream creation failed");
+        return -1;
+    }
+    hipStream_t st = db->seq_stream;
     if (db->seq_scratch_bytes < total) {
-        if (db->seq_scratch) { (void)hipDeviceSynchronize(); (void)hipFree(db->seq_scratch); }
+        if (db->seq_scratch) { (void)hipStreamSynchronize(st); (void)hipFree(db->seq_scratch); }
         db->seq_scratch = nullptr; db->seq_scratch_bytes = 0;
         if (hipMalloc(&db->seq_scratch, total + (total >> 2)) != hipSuccess) { set_error("seq_score: device allocation failed"); return -1; }
         db->seq_scratch_bytes = total + (total >> 2);
     }
+    if (db->seq_host_bytes < total) {
+        if (db->seq_host) { (void)hipStreamSynchronize(st); (void)hipHostFree(db->seq_host); }
+        db->seq_host = nullptr; db->seq_host_bytes = 0;
+        if (hipHostMalloc(reinterpret_cast<void **>(&db->seq_host), total + (total >> 2), hipHostMallocDefault) != hipSuccess) {
+            set_error("seq_score: pinned host allocation failed");
+            return -1;
+        }
+        db->seq_host_bytes = total + (total >> 2);
+    }
     char *dev = reinterpret_cast<char *>(db->seq_scratch);
-    static thread_local std::vector<char> host;
-    host.resize(std::max(total - o_qs, o_qs));
+    char *host = db->seq_host;
     const int64_t zero = 0;
     const int32_t ql = query_len;
-    memcpy(host.data(), &zero, sizeof(zero));
-    memcpy(host.data() + (o_ql - o_qs), &ql, sizeof(ql));
-    memcpy(host.data() + (o_q - o_qs), query, nq * db->d * sizeof(float));
-    memcpy(host.data() + (o_l - o_qs), labels, nq * top_k * sizeof(int64_t));
-    if (hipMemsetAsync(dev, 0, ss_bytes, nullptr) != hipSuccess ||
-        hipMemcpyAsync(dev + o_qs, host.data(), total - o_qs, hipMemcpyHostToDevice, nullptr) != hipSuccess) {
+    memcpy(host + o_qs, &zero, sizeof(zero));
+    memcpy(host + o_ql, &ql, sizeof(ql));
+    memcpy(host + o_q, query, nq * db->d * sizeof(float));
+    memcpy(host + o_l, labels, nq * top_k * sizeof(int64_t));
+    if (hipMemsetAsync(dev, 0, ss_bytes, st) != hipSuccess ||
+        hipMemcpyAsync(dev + o_qs, host + o_qs, total - o_qs, hipMemcpyHostToDevice, st) != hipSuccess) {
         set_error("seq_score: upload failed");
         return -1;
     }
     if (pfann_match(db, reinterpret_cast<float *>(dev + o_q), reinterpret_cast<int64_t *>(dev + o_l), top_k,
                     reinterpret_cast<int64_t *>(dev + o_qs), reinterpret_cast<int32_t *>(dev + o_ql), 1, query_len,
                     frame_shift_mul, score_alpha, 1, 0, reinterpret_cast<pfann_match_result *>(dev + o_res),
-                    reinterpret_cast<float *>(dev), nullptr) != 0) return -1;
-    if (hipMemcpy(host.data(), dev, o_qs, hipMemcpyDeviceToHost) != hipSuccess) { set_error("seq_score: download failed"); return -1; }
+                    reinterpret_cast<float *>(dev), st) != 0) return -1;
+    if (hipMemcpyAsync(host, dev, o_qs, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) { set_error("seq_score: download failed"); return -1; }
     pfann_match_result res;
-    memcpy(&res, host.data() + o_res, sizeof(res));
+    memcpy(&res, host + o_res, sizeof(res));
     if (res.song == -2) { set_error("seq_score: query_len*top_k too large for the candidate buffer"); return -1; }
-    const float *ss = reinterpret_cast<const float *>(host.data());
+    const float *ss = reinterpret_cast<const float *>(host);
     for (int s = 0; s < n_songs; ++s)            // seqscore.cpp:126-133 against the caller's slots
         if (ss[2 * s] > song_scores[2 * s]) { song_scores[2 * s] = ss[2 * s]; song_scores[2 * s + 1] = ss[2 * s + 1]; }
     return res.song;

@@ -229,33 +229,49 @@ class Database:
         self.index.load(emb, self.song_pos, 0)
 
     # ---- batched form ------------------------------------------------------------------
-    def query_batch(self, emb, qstart, qlen, want_song_scores=False, mode=0):
-        """emb: torch cuda [sum(qlen), d] unit-norm rows; -> list of (score, (song, time), song_score|None)."""
-        tm_1 = time.time()
+    def query_launch(self, emb, qstart, qlen, want_song_scores=False, mode=0):
+        """First half of query_batch: search + sequence match launched asynchronously, nothing read back.  The CLIs launch
+        group g+1 before they finish group g, so the GPU never idles while the host formats and writes results."""
+        dev = self.index.device
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
         D, I = self.index.search(emb, self.top_k)
-        if self.timer is not None:
-            torch.cuda.synchronize(self.index.device)     # stage split as database.py:165 logs it
-        tm_2 = time.time()
+        ev[1].record()
         res, ss = self.index.match(emb, I, qstart, qlen, self.frame_shift_mul, self.score_alpha, mode,
-                                   False, want_song_scores)
-        if self.timer is not None:                        # match() ends with the D2H of the results
-            self.timer.add("search", tm_2 - tm_1)
-            self.timer.add("rerank", time.time() - tm_2)
-        ss_np = ss.cpu().numpy() if ss is not None else None
+                                   False, want_song_scores, to_host=False)
+        ev[2].record()
+        return {"res": res, "ss": ss, "ev": ev, "nq": len(qlen), "keep": (emb, I), "dev": dev}
+
+    def query_finish(self, p):
+        """Second half: wait for that group only (a side stream copies its results; later groups keep running) and
+        return the list of (score, (song, time), song_score|None)."""
+        if getattr(self, "_copy_stream", None) is None:
+            self._copy_stream = torch.cuda.Stream(p["dev"])
+        with torch.cuda.stream(self._copy_stream):
+            self._copy_stream.wait_event(p["ev"][2])
+            res = self.index.results_to_host(p["res"])
+            ss_np = p["ss"].cpu().numpy() if p["ss"] is not None else None
+        if self.timer is not None:                        # stage split as database.py:165 logs it, from events
+            self.timer.mark_gpu("search", p["ev"][0], p["ev"][1])
+            self.timer.mark_gpu("rerank", p["ev"][1], p["ev"][2])
+            self.timer.resolve()
         out = []
         fsm = self.frame_shift_mul
-        for j in range(len(qlen)):
+        if ss_np is not None:
+            ss_np[:, :, 1] = _fine_to_time(ss_np[:, :, 1].astype(np.int64), fsm, self.hop_size)
+        for j in range(p["nq"]):
             r = res[j]
-            song_score = None
-            if ss_np is not None:
-                song_score = ss_np[j].copy()
-                song_score[:, 1] = _fine_to_time(song_score[:, 1].astype(np.int64), fsm, self.hop_size)
+            song_score = ss_np[j] if ss_np is not None else None
             if self.index.ntotal == 0 or r["song"] < 0:
                 out.append((-1e999, (-1, 0), song_score))
                 continue
             real_time = (int(r["offset"]) - int(r["shift"]) / fsm) * self.hop_size
             out.append((float(r["score"]), (int(r["song"]), real_time), song_score))
         return out
+
+    def query_batch(self, emb, qstart, qlen, want_song_scores=False, mode=0):
+        """emb: torch cuda [sum(qlen), d] unit-norm rows; -> list of (score, (song, time), song_score|None)."""
+        return self.query_finish(self.query_launch(emb, qstart, qlen, want_song_scores, mode))
 
     # ---- the reference's per-query contract ---------------------------------------------
     def query_embeddings(self, query):

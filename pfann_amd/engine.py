@@ -75,8 +75,11 @@ def config_from_params(params, max_batch=512):
 
 
 class Engine:
-    def __init__(self, params, device=0, max_batch=512):
+    def __init__(self, params, device=0, max_batch=512, encoder_only=False):
+        """encoder_only: the context serves `encode` alone (FpNetwork built without a full config, model.py:132-146
+        knows only d, h, u, F, T and the "model" block); the front-end entry points then refuse to run."""
         _l.require_gpu()
+        self.encoder_only = encoder_only
         self.lib = _l.load()
         self.params = params
         self.device = torch.device("cuda", device if isinstance(device, int) else (device.index or 0))
@@ -121,8 +124,14 @@ class Engine:
             x = torch.as_tensor(np.asarray(x, dtype=np.float32))
         return x.to(self.device, torch.float32).contiguous()
 
+    def _need_front_end(self, what):
+        if self.encoder_only:
+            raise _l.PfannError("%s: this Engine was built encoder-only (FpNetwork without a full config); build it from "
+                                "the whole configs/*.json dict" % what)
+
     def melspec(self, segs):
         """MelSpec.forward: [..., seg_len] -> [..., n_mels, T]."""
+        self._need_front_end("melspec")
         x = self._prep(segs)
         lead = x.shape[:-1]
         x2 = x.reshape(-1, self.seg_len)
@@ -145,6 +154,7 @@ class Engine:
     def embed_wav(self, wav, hop, n_seg=None, norm=True):
         """Fused path: mono float wav [L] on device -> [n_seg, d] embeddings of the windows
         wav[i*hop : i*hop+seg_len] (mean removal, mel, encoder, optional L2 norm)."""
+        self._need_front_end("embed_wav")
         w = self._prep(wav).reshape(-1)
         if w.shape[0] < self.seg_len:                      # musicdata.py:82-84
             w = torch.nn.functional.pad(w, (0, self.seg_len - w.shape[0]))
@@ -160,6 +170,7 @@ class Engine:
     def embed_windows(self, wav, starts, norm=True):
         """wav: device float mono buffer (many recordings back to back); starts: int64 window
         start offsets (device tensor or array) -> [len(starts), d]."""
+        self._need_front_end("embed_windows")
         w = self._prep(wav).reshape(-1)
         st = starts if isinstance(starts, torch.Tensor) else torch.as_tensor(np.asarray(starts, np.int64))
         st = st.to(self.device, torch.int64).contiguous()

@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import torch
 
-from .builder import embed_files
+from .builder import embed_file_batches
 from .engine import Engine
 from .musicdata import MusicDataset
 from .utils import StageTimer, read_config
@@ -25,7 +25,8 @@ def main(argv=None):
     configs = os.path.join(dir_for_db, "configs.json")
     params = read_config(configs)
     print("loading model...")
-    engine = Engine(params, 0, max_batch=int(os.environ.get("PFANN_MAX_BATCH", "4096")))
+    max_batch = int(os.environ.get("PFANN_MAX_BATCH", "9728"))
+    engine = Engine(params, 0, max_batch=max_batch)
     engine.load_state_dict(torch.load(os.path.join(dir_for_db, "model.pt"), map_location="cpu"))
     print("model loaded")
     dataset = MusicDataset(file_list_for_query, params)
@@ -34,10 +35,12 @@ def main(argv=None):
     idx_pos = 0
     index = np.zeros((len(dataset), 2), dtype=np.int64)
     with open(os.path.join(out_embed_dir, "query_embeddings"), "wb") as fe:
-        for i, n_seg, emb in embed_files(engine, dataset, dataset.hop, timer=timer):
-            index[i] = (idx_pos, n_seg)
-            if n_seg:
-                fe.write(emb.cpu().numpy().tobytes())
+        for group in embed_file_batches(engine, dataset, dataset.hop, batch_windows=max_batch, timer=timer):
+            rows = [emb for _, n_seg, emb in group if n_seg]
+            if rows:
+                fe.write(torch.cat(rows).cpu().numpy().tobytes())       # one device-to-host copy per launch group
+            for i, n_seg, _ in group:
+                index[i] = (idx_pos, n_seg)
                 idx_pos += n_seg
     index.tofile(os.path.join(out_embed_dir, "query_index"))
     print("total", idx_pos, "embeddings")

@@ -37,7 +37,7 @@ def main(argv=None):
     assert query_index.shape[0] == len(file_list)
     tm_0 = time.time()
     out = ResultWriter(result_file, len(db.songList))
-    group = int(os.environ.get("PFANN_QUERY_GROUP", "64"))
+    group = int(os.environ.get("PFANN_QUERY_GROUP", "512"))
     qdev = torch.as_tensor(q).to(db.index.device)
     for g0 in range(0, len(file_list), group):
         ids = list(range(g0, min(g0 + group, len(file_list))))

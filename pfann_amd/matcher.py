@@ -15,7 +15,7 @@ import time
 import numpy as np
 import torch
 
-from .builder import embed_files
+from .builder import embed_file_batches
 from .database import Database
 from .engine import Engine
 from .musicdata import MusicDataset
@@ -61,7 +61,8 @@ def main(argv=None):
     init_logger("matcher")                                                 # matcher.py:31-32
 
     print("loading model...")
-    engine = Engine(params, 0, max_batch=int(os.environ.get("PFANN_MAX_BATCH", "4096")))
+    max_batch = int(os.environ.get("PFANN_MAX_BATCH", "9728"))
+    engine = Engine(params, 0, max_batch=max_batch)
     engine.load_state_dict(torch.load(os.path.join(dir_for_db, "model.pt"), map_location="cpu"))
     print("model loaded")
     print("loading database...")
@@ -72,19 +73,24 @@ def main(argv=None):
     timer = StageTimer()
     db.timer = timer
     tm_0 = time.time()
-    group = int(os.environ.get("PFANN_QUERY_GROUP", "64"))
     out = ResultWriter(result_file, len(db.songList))
 
-    def emit(items):
-        """items: list of (index, n_seg, emb) in list order."""
+    def launch(items):
+        """items: one launch group of (index, n_seg, emb) in list order -> search + match in flight."""
         good = [(i, n, e) for i, n, e in items if n]
-        results = {}
+        p = None
         if good:
             emb = torch.cat([e for _, _, e in good])
             qlen = [n for _, n, _ in good]
             qstart = np.concatenate([[0], np.cumsum(qlen)[:-1]])
-            res = db.query_batch(emb, qstart, qlen, want_song_scores=True)    # times "search" and "rerank"
-            for (i, _, _), r in zip(good, res):
+            p = db.query_launch(emb, qstart, qlen, want_song_scores=True)
+        return items, good, p
+
+    def finish(launched):
+        items, good, p = launched
+        results = {}
+        if p is not None:
+            for (i, _, _), r in zip(good, db.query_finish(p)):
                 results[i] = r
         with timer.stage("output answer"):
             for i, n, _ in items:
@@ -96,15 +102,19 @@ def main(argv=None):
                     out.write(name, db.songList[sid], sco, tim, song_score)   # sid == -1 -> last song (matcher.py:138)
             out.flush()
 
-    buf = []
-    # matcher.py:120-126 asks the model for norm=False and L2-normalises on the CPU; the same
-    # formula runs inside the projection kernel here.
-    for item in embed_files(engine, dataset, dataset.hop, batch_windows=group * 19, timer=timer):
-        buf.append(item)
-        if len(buf) >= group:
-            emit(buf)
-            buf = []
-    emit(buf)
+    # matcher.py:120-126 asks the model for norm=False and L2-normalises on the CPU; the same formula runs inside the
+    # projection kernel here.  One launch group = PFANN_MAX_BATCH windows (512 ten-second queries): enough 128x128
+    # tiles to fill the chip in every encoder layer.  Group g+1 is decoded, uploaded and launched before group g's
+    # results are read back and written.
+    in_flight = None
+    for items in embed_file_batches(engine, dataset, dataset.hop, batch_windows=max_batch, timer=timer):
+        nxt = launch(items)
+        if in_flight is not None:
+            finish(in_flight)
+        in_flight = nxt
+    if in_flight is not None:
+        finish(in_flight)
+    timer.resolve(wait=True)
     out.close()
     for name, secs in timer.t.items():                   # one stage per line, the format tools/stat.py:17 parses
         print("%s %.6fs" % (name, secs))

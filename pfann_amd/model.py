@@ -11,11 +11,12 @@ class FpNetwork:
         """`params` is the config's "model" dict as in the reference.  Either pass a shared
         `engine` (built from the full config) or let this build a private one."""
         if engine is None:
-            hop = 256
-            full = dict(sample_rate=8000, segment_size=((T - 1) * hop + hop // 2) / 8000.0, stft_n=1024,
-                        stft_hop=hop, n_mels=F, f_min=300, f_max=4000,
-                        model=dict(params, d=d, h=h, u=u))
-            engine = Engine(full, device, max_batch)
+            # the reference's constructor (model.py:132-146) sees no front-end settings: an ENCODER-ONLY context.  Its
+            # front-end fields only have to be self-consistent (any length with ceil(len/hop) = 1 + len//hop = T, builder.py:50-51);
+            # melspec / embed_* on such a context raise.
+            full = dict(sample_rate=8000, segment_size=((T - 1) * 256 + 128) / 8000.0, stft_n=1024, stft_hop=256, n_mels=F,
+                        f_min=300, f_max=4000, model=dict(params, d=d, h=h, u=u))
+            engine = Engine(full, device, max_batch, encoder_only=True)
         assert (engine.d, engine.h, engine.u, engine.F, engine.T) == (d, h, u, F, T)
         self.engine = engine
         self.d, self.h, self.u = d, h, u

@@ -6,7 +6,7 @@ container formats need ffmpeg: out of scope.
 Two ways to consume a file:
   * `MusicDataset[i] -> (i, path, float32[n_seg, seg_len])`  -- the reference's contract
     (materialised unfold on the host; used by the operator-seam API and tests);
-  * `MusicDataset.load_pcm(i) -> int16[n, ch]`               -- raw PCM for the fused device
+  * `MusicDataset.load_pcm_sr(i) -> (int16[n, ch], rate)`    -- raw PCM for the fused device
     path (Engine.pcm16_to_mono + Engine.embed_wav), which never materialises the unfold.
 """
 import time
@@ -45,19 +45,25 @@ class MusicDataset:
         n = max(n_samples, self.segment_size)
         return (n - self.segment_size) // self.hop + 1
 
+    def load_pcm_sr(self, index):
+        """-> (int16 [n, ch] as stored, the file's sample rate).  Stateless (decode workers call it concurrently); the
+        device path resamples when the rate is not the model's: Engine.pcm16_to_mono(pcm, sample_rate=sr)."""
+        return read_wav_pcm16(self.files[index])
+
     def load_pcm(self, index):
-        """-> int16 [n, ch] as stored; the file's rate is left in `last_sample_rate` (the device path resamples:
-        Engine.pcm16_to_mono(pcm, sample_rate=...))."""
-        pcm, sr = read_wav_pcm16(self.files[index])
-        self.last_sample_rate = sr
+        """-> int16 [n, ch]; kept for callers that know their files are at the model's rate (raises otherwise)."""
+        pcm, sr = self.load_pcm_sr(index)
+        if sr != self.sample_rate:
+            raise ValueError("%s is at %d Hz, not %d: use load_pcm_sr and hand the rate to Engine.pcm16_to_mono"
+                             % (self.files[index], sr, self.sample_rate))
         return pcm
 
     def unsafe_getitem(self, index):
         log = get_logger()
         t0 = time.time()
-        pcm = self.load_pcm(index)
-        if self.last_sample_rate != self.sample_rate:          # host-side dataset contract: native rate only
-            raise NotImplementedError("resampling %d -> %d Hz runs on the device path only" % (self.last_sample_rate, self.sample_rate))
+        pcm, sr = self.load_pcm_sr(index)
+        if sr != self.sample_rate:                             # host-side dataset contract: native rate only
+            raise NotImplementedError("resampling %d -> %d Hz runs on the device path only" % (sr, self.sample_rate))
         t1 = time.time()
         x = np.multiply(pcm, 1 / 32768, dtype=np.float32).T.copy()
         if x.shape[0] == 2:                                    # musicdata.py:72-79
@@ -85,3 +91,6 @@ class MusicDataset:
 
     def __len__(self):
         return len(self.files)
+
+    def __iter__(self):                     # __getitem__ swallows every exception, IndexError included
+        return (self[i] for i in range(len(self)))

@@ -67,3 +67,43 @@ class StageTimer:
 
     def stage(self, name):
         return StageTimer._Ctx(self, name)
+
+    # ---- stages that run asynchronously on the GPU: timed with events on the launching stream, so that the host never
+    # has to wait for a stage just to log it (the next batch's uploads and launches go out while this one computes);
+    # resolve() turns the finished pairs into the same '<stage> <seconds>s' records
+    class _GpuCtx:
+        def __init__(self, owner, name):
+            self.o, self.n = owner, name
+
+        def __enter__(self):
+            import torch
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+        def __exit__(self, *a):
+            self.e1.record()
+            self.o._pending.append((self.n, self.e0, self.e1))
+
+    def stage_gpu(self, name):
+        if not hasattr(self, "_pending"):
+            self._pending = []
+        return StageTimer._GpuCtx(self, name)
+
+    def mark_gpu(self, name, e0, e1):
+        """a stage bracketed by two already recorded timing events"""
+        if not hasattr(self, "_pending"):
+            self._pending = []
+        self._pending.append((name, e0, e1))
+
+    def resolve(self, wait=False):
+        """account every event pair that has completed (all of them with wait=True)"""
+        keep = []
+        for name, e0, e1 in getattr(self, "_pending", []):
+            if wait:
+                e1.synchronize()
+            if e1.query():
+                self.add(name, e0.elapsed_time(e1) * 1e-3)
+            else:
+                keep.append((name, e0, e1))
+        self._pending = keep

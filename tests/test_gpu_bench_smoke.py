@@ -13,7 +13,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_json_contract_small():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1",
-                        "--queries", "16", "--db-songs", "400", "--cpu-queries", "4"],
+                        "--queries", "16", "--db-songs", "400", "--cpu-queries", "4", "--cli-songs", "40", "--cli-queries", "8"],
                        capture_output=True, text=True, timeout=900, cwd=REPO)
     assert r.returncode == 0, r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -32,9 +32,18 @@ def test_bench_json_contract_small():
     par = out["oracle_decision_parity"]
     assert par["identical_song_and_offset"] == par["queries"]
     assert out["top1_hit_rate"] > 0.5
-    assert out["builder"]["value"] > 0 and out["pcie_inclusive"]["value"] > 0
+    assert out["builder"]["value"] > 0 and out["hbm_resident"]["value"] > 0 and "H2D" in out["value_includes"]
+    assert set(cb["stages_s"]) == {"compute embedding", "search", "rerank"} and cb["python_rerank"]["queries"] >= 1
+    assert cb["python_rerank"]["same_decision_as_c_path"].split("/")[0] == cb["python_rerank"]["same_decision_as_c_path"].split("/")[1]
+    cli = out["cli"]
+    assert cli["builder"]["segments"] == 40 * 59 and cli["matcher"]["segments"] == 8 * 19, cli
+    assert cli["cli_builder_segments_per_s"] > 0 and cli["cli_matcher_segments_per_s"] > 0
+    assert "compute embedding" in cli["builder"]["stages_s"] and "search" in cli["matcher"]["stages_s"]
+    assert cli["matcher"]["top1_hit_rate"] >= 0.5
+    assert out["ranks_seen"] == 1 and out["devices"] == [0]
     assert out["alt_modes"]["fp16_db"]["decisions_identical_to_fp32_db"].endswith("/16")
-    assert out["seq_score_seam"]["same_best_song"] is True
+    assert out["seq_score_seam"]["same_best_song"] is True and out["seq_score_seam"]["calls"] == 200
+    assert out["seq_score_seam"]["gpu_call_us_median"] <= out["seq_score_seam"]["gpu_call_us_p95"]
 
 
 @pytest.mark.parametrize("scaling", ["strong", "weak"])
@@ -43,7 +52,7 @@ def test_two_rank_sharded_path_matches_single_gpu(tmp_path, scaling):
     aid) must reach exactly the single-GPU decisions.  strong: the 24 queries split over the ranks; weak (bench.py's
     default): every rank brings 12 of its own -- the same 24 queries either way."""
     import numpy as np
-    common = ["--steps", "1", "--warmup", "0", "--db-songs", "600", "--no-cpu-baseline", "--no-prof", "--max-batch", "512"]
+    common = ["--steps", "1", "--warmup", "0", "--db-songs", "600", "--no-cpu-baseline", "--no-cli", "--no-prof", "--max-batch", "512"]
     one = str(tmp_path / "one.npy")
     two = str(tmp_path / "two.npy")
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + common + ["--queries", "24", "--dump-decisions", one],
@@ -75,7 +84,7 @@ def test_plain_gpus2_on_a_one_gpu_box_fails_loudly_or_runs_two_rccl_ranks():
     with 2+ devices it really runs two RCCL ranks on two devices."""
     import torch
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
-                        "--queries", "12", "--db-songs", "600", "--no-cpu-baseline", "--no-prof", "--max-batch", "512"],
+                        "--queries", "12", "--db-songs", "600", "--no-cpu-baseline", "--no-cli", "--no-prof", "--max-batch", "512"],
                        capture_output=True, text=True, timeout=900, cwd=REPO, env=_clean_env())
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     if torch.cuda.device_count() < 2:
@@ -91,7 +100,7 @@ def test_self_launched_two_ranks_report_two(tmp_path):
     """the launcher itself on the real kernels: plain `python bench.py --gpus 2` (gloo-staged collectives, both ranks on
     this box's one GPU) -> n_gpus 2, ranks_seen 2."""
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
-                        "--queries", "12", "--db-songs", "600", "--no-cpu-baseline", "--no-prof", "--max-batch", "512"],
+                        "--queries", "12", "--db-songs", "600", "--no-cpu-baseline", "--no-cli", "--no-prof", "--max-batch", "512"],
                        capture_output=True, text=True, timeout=900, cwd=REPO,
                        env=_clean_env(PFANN_DIST_BACKEND="gloo", PFANN_FORCE_DEVICE="0"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
@@ -104,7 +113,7 @@ def test_rccl_collectives_of_the_sharded_path_on_one_gpu(tmp_path):
     the bound all-gather, the all-to-all of the shard lists, the merged-slice all-gathers, the key all-gather, the ragged
     embedding gather, the barrier and the MAX all-reduce all go through RCCL; decisions equal the plain single-GPU run."""
     import numpy as np
-    common = ["--steps", "1", "--warmup", "0", "--db-songs", "600", "--queries", "24", "--no-cpu-baseline", "--no-prof",
+    common = ["--steps", "1", "--warmup", "0", "--db-songs", "600", "--queries", "24", "--no-cpu-baseline", "--no-cli", "--no-prof",
               "--max-batch", "512"]
     one, two = str(tmp_path / "one.npy"), str(tmp_path / "rccl.npy")
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + common + ["--dump-decisions", one],

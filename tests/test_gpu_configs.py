@@ -254,7 +254,7 @@ def test_config4_100k_songs_single_gpu():
 def test_config4_sharded_protocol_at_eighth_shard_size(tmp_path):
     """Two ranks on this GPU, 12,500 songs (737,500 rows = 1/8 of the 100 k-song db) per shard: all-to-all of per-shard
     top-k by query slice, merge, all-gather, owner-side rerank, winner pick -- against one index over the same 25 k songs."""
-    common = ["--steps", "1", "--warmup", "0", "--queries", "256", "--db-songs", "25000", "--no-cpu-baseline", "--no-prof",
+    common = ["--steps", "1", "--warmup", "0", "--queries", "256", "--db-songs", "25000", "--no-cpu-baseline", "--no-cli", "--no-prof",
               "--no-alt", "--max-batch", "4864", "--scaling", "strong"]
     one, two = str(tmp_path / "one.npy"), str(tmp_path / "two.npy")
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + common + ["--dump-decisions", one],
