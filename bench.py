@@ -367,23 +367,40 @@ def main():
 
     cur_index = [index]
 
-    def step(from_host=True):
-        wav = eng.pcm16_to_mono(pcm_host.to(dev, non_blocking=True) if from_host else pcm_dev)
-        emb = eng.embed_windows(wav, starts_dev)
+    def make_workload(counts):
+        """counts[r] = queries rank r brings per step (the first counts[r] of the ones it synthesised)"""
+        n_me, tot = counts[rank], sum(counts)
+        return {"pcm_dev": pcm_dev[: n_me * q_len], "pcm_host": pcm_host[: n_me * q_len],
+                "starts": starts_dev[: n_me * QUERY_SEGS].contiguous(), "q_counts": [c * QUERY_SEGS for c in counts],
+                "qstart": np.arange(tot, dtype=np.int64) * QUERY_SEGS, "qlen": np.full(tot, QUERY_SEGS, dtype=np.int32), "Q": tot}
+    main_w = make_workload([hi - lo for lo, hi in split_even(Q, world)])
+    if emu > 1:
+        main_w.update(qstart=qstart, qlen=qlen, Q=Q)
+
+    def step(from_host=True, w=main_w):
+        wav = eng.pcm16_to_mono(w["pcm_host"].to(dev, non_blocking=True) if from_host else w["pcm_dev"])
+        emb = eng.embed_windows(wav, w["starts"])
         if emu > 1:
             emb = emb.repeat(emu, 1)[: Q * QUERY_SEGS].contiguous()
-            return sharded.query_batch(emb, qstart, qlen), emb
+            return sharded.query_batch(emb, w["qstart"], w["qlen"]), emb
         if use_sharded:
-            emb = all_gather_ragged(emb, q_counts)
-            return sharded.query_batch(emb, qstart, qlen), emb
+            emb = all_gather_ragged(emb, w["q_counts"])
+            return sharded.query_batch(emb, w["qstart"], w["qlen"]), emb
         D, I = cur_index[0].search(emb, k)
-        res, _ = cur_index[0].match(emb, I, qstart, qlen)
+        res, _ = cur_index[0].match(emb, I, w["qstart"], w["qlen"])
         return res, emb
 
     def fence():
         if in_group:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(sec):
+        if not in_group:
+            return sec
+        t = torch.tensor([sec], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     for _ in range(args.warmup):
         step()
@@ -402,10 +419,7 @@ def main():
     lib.pfann_prof_marker(None)
     if prof:
         lib.pfann_prof_enable(0)
-    if in_group:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed)
     n_seg = Q * QUERY_SEGS
     value = n_seg * args.steps / elapsed
 
@@ -418,14 +432,27 @@ def main():
         for _ in range(args.steps):
             step(False)
         fence()
-        el = time.perf_counter() - tp
-        if in_group:
-            t = torch.tensor([el], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
+        el = max_over_ranks(time.perf_counter() - tp)
         pcie = {"value": round(n_seg * args.steps / el, 1), "unit": "segments/s", "ms_per_step": round(1e3 * el / args.steps, 3),
                 "what": "same step with the int16 query PCM already resident in HBM (`value` includes the H2D of %.1f MB per "
                         "step and rank from pinned host memory)" % (pcm_host.numel() * 2 / 1e6)}
+
+    # ---- N > 1, default (weak) mode: the same job in the OTHER scaling mode as a side figure, so SCALE runs stay
+    # comparable with round 1's strong-scaling numbers: --queries queries for the WHOLE job, split over the ranks
+    other_mode = None
+    if world > 1 and args.scaling == "weak" and emu <= 1:
+        sw = make_workload([hi - lo for lo, hi in split_even(args.queries, world)])
+        step(True, sw)
+        fence()
+        tp = time.perf_counter()
+        for _ in range(args.steps):
+            step(True, sw)
+        fence()
+        el = max_over_ranks(time.perf_counter() - tp)
+        other_mode = {"scaling": "strong", "value": round(sw["Q"] * QUERY_SEGS * args.steps / el, 1), "unit": "segments/s",
+                      "ms_per_step": round(1e3 * el / args.steps, 3), "queries_per_step": sw["Q"],
+                      "what": "the same 1 M-segment job with a FIXED %d queries per step split over the %d ranks (each rank "
+                              "encodes %d segments per step)" % (sw["Q"], world, sw["q_counts"][0])}
 
     # ---- the reference's own native seam (cpp/seqscore.cpp:32-43 via database.py:178-189): host pointers in, best
     # song out; 200 calls, median and p95, once here and once more after the fp16-storage leg below
@@ -645,7 +672,8 @@ def main():
 
     # ------------------------------------------------------------------------- hit-rate
     hits = near = exact = 0
-    for j in range(Q):
+    hit_js = range(Q) if emu <= 1 else range(my_q[0], my_q[1])        # emulation: only rank 0's queries are real
+    for j in hit_js:
         if int(res[j]["song"]) == q_song[j]:
             hits += 1
             tm = int(res[j]["offset"]) * 0.5
@@ -699,8 +727,8 @@ def main():
                        "db_rows": n_rows, "queries_per_step": Q, "queries_per_step_per_gpu": Q // world,
                        "segments_per_step": n_seg,
                        "parallelism": "song-sharded db x%d" % world, "max_batch": args.max_batch},
-            "top1_hit_rate": round(hits / Q, 4), "top1_near_0.5s": round(near / Q, 4),
-            "top1_exact_0.25s": round(exact / Q, 4),
+            "top1_hit_rate": round(hits / len(hit_js), 4), "top1_near_0.5s": round(near / len(hit_js), 4),
+            "top1_exact_0.25s": round(exact / len(hit_js), 4), "hit_rates_cover": "%d of %d queries" % (len(hit_js), Q),
             "roofline": roofline, "single_query_scan_roofline": single, "cpu_baseline": cpu, "oracle_decision_parity": parity,
             "builder": None if not builder_segs else {
                 "value": round(builder_segs / builder_s, 1), "unit": "segments/s", "segments": builder_segs,
@@ -710,7 +738,7 @@ def main():
                         "%d windows per launch group" % args.max_batch},
             "value_includes": "H2D of the query PCM from pinned host memory (SURVEY 8d: PCM-in-host-memory to decisions)",
             "hbm_resident": pcie, "seq_score_seam": seam_info, "cli": cli,
-            "alt_modes": alt,
+            "alt_modes": alt, "other_scaling_mode": other_mode,
             "kernels": {t: {kk: (float("%.4g" % vv) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                         for t, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
         }

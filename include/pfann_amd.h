@@ -165,8 +165,12 @@ int pfann_db_load(pfann_db *db, const float *emb, int emb_is_device, int64_t n,
  *   PFANN_DB_F16: ONLY fp16 rows are kept (n*d*2 bytes, half the HBM footprint and half the bytes per scan
  *     pass).  Search returns the k best s16 = sum_i fl16(q_i)*fl16(x_i) (exact products, fp32 accumulation on
  *     v_mfma_f32_32x32x16_f16) with no fp32 re-scoring; the sequence matcher scores against the stored fp16
- *     rows.  Approximate with respect to the fp32 path, like the reference's only fp16 precedent, faiss'
- *     GpuMultipleClonerOptions.useFloat16 (database.py:101-104; cpp/faisscputest.cpp:97-108).  d % 8 == 0. */
+ *     rows.  Approximate with respect to the fp32 path.  This goes FURTHER than the reference's only fp16
+ *     precedent, faiss' GpuMultipleClonerOptions.useFloat16 (database.py:101-104; cpp/faisscputest.cpp:97-108):
+ *     there only the GPU search index is fp16 and the rerank still reconstructs fp32 rows from the CPU index
+ *     (database.py:148-152); here the rerank scores -- and so tie / argmax decisions between near-equal
+ *     candidates -- also carry fp16 rounding of the database rows (measured: 99.85 % identical decisions on
+ *     BASELINE config 5).  Keep PFANN_DB_F32 when the reference's exact scores are wanted.  d % 8 == 0. */
 #define PFANN_DB_F32 0
 #define PFANN_DB_F16 1
 int pfann_db_set_storage(pfann_db *db, int mode);

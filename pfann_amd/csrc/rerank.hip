@@ -223,7 +223,9 @@ __global__ __launch_bounds__(NT) void match_kernel(RerankArgs a) {
             if (a.db != nullptr) {
                 const float *v = a.db + ro;
                 for (int e = lane; e < a.d; e += 64) part = fmaf(v[e], qv[e], part);
-            } else {                      // fp16-only storage: the stored rows are what a reconstruct() returns
+            } else {                      // fp16-only storage: ONLY fp16 rows exist, so the sequence score is fp16-grade too
+                                          // (in the reference useFloat16 touches the GPU search index alone; its rerank
+                                          // reconstructs fp32 rows from the CPU index, database.py:148-152)
                 const _Float16 *v = reinterpret_cast<const _Float16 *>(a.dbh) + ro;
                 for (int e = lane; e < a.d; e += 64) part = fmaf((float)v[e], qv[e], part);
             }
@@ -330,6 +332,9 @@ __global__ void match_pack_kernel(const pfann_match_result *__restrict__ res, in
     const pfann_match_result r = res[j];
     unsigned long long hi = ~0ull, lo = ~0ull;
     if (r.song >= 0) { hi = ~ord64(r.score + 0.0); lo = pack_cand(0, r.song, r.offset, r.shift); }   // -0.0 + 0.0 = +0.0: equal scores, equal bits
+    // a REFUSED query (song == -2: candidate buffer sizing error on this rank) must not read as "no candidate": the
+    // all-zero key beats every real key (hi == 0 would need a NaN score), and the pick hands -2 on to the host
+    if (r.song == -2) { hi = 0ull; lo = 0ull; }
     keys[2 * j] = hi;
     keys[2 * j + 1] = lo;
 }
@@ -345,6 +350,8 @@ __global__ void match_pick_kernel(const unsigned long long *__restrict__ keys, i
     r.n_cand = 0;
     if (bh == ~0ull && bl == ~0ull) {
         r.song = -1; r.offset = 0; r.shift = 0; r.score = -INFINITY;
+    } else if (bh == 0ull && bl == 0ull) {          // some rank refused this query
+        r.song = -2; r.offset = 0; r.shift = 0; r.score = -INFINITY;
     } else {
         const Cand c = unpack_cand(0, bl);
         r.song = c.song; r.offset = c.off; r.shift = c.shift;

@@ -228,6 +228,15 @@ class Database:
         self.index = DeviceIndex(self.d, device, storage)
         self.index.load(emb, self.song_pos, 0)
 
+    def warmup(self):
+        """one throw-away query through search + match: kernel code objects and scratch buffers exist afterwards"""
+        if self.index.ntotal:
+            q = torch.zeros((19, self.d), device=self.index.device)
+            q[:, 0] = 1.0
+            self.query_finish(self.query_launch(q, [0], [19], want_song_scores=True))
+            n = min(2048, 19 * 64)
+            self.query_finish(self.query_launch(q.repeat(n // 19, 1), np.arange(n // 19) * 19, [19] * (n // 19)))
+
     # ---- batched form ------------------------------------------------------------------
     def query_launch(self, emb, qstart, qlen, want_song_scores=False, mode=0):
         """First half of query_batch: search + sequence match launched asynchronously, nothing read back.  The CLIs launch
@@ -240,25 +249,49 @@ class Database:
         res, ss = self.index.match(emb, I, qstart, qlen, self.frame_shift_mul, self.score_alpha, mode,
                                    False, want_song_scores, to_host=False)
         ev[2].record()
+        ev[2].record()
+        if ss is not None:
+            # frames -> seconds where the block lives (database.py:148,193 do it on the host): (t - shift/fsm) * hop_size
+            # with fine = t*fsm - shift, in double like the reference's Python floats, stored as float32
+            fine = ss[:, :, 1].to(torch.int64)
+            shift = (-fine) % self.frame_shift_mul
+            t = (fine + shift) // self.frame_shift_mul
+            ss[:, :, 1] = ((t.double() - shift.double() / self.frame_shift_mul) * self.hop_size).float()
         return {"res": res, "ss": ss, "ev": ev, "nq": len(qlen), "keep": (emb, I), "dev": dev}
 
-    def query_finish(self, p):
+    def _pinned(self, shape, dtype):
+        """one reusable pinned landing buffer per result kind (a pinned allocation costs milliseconds)"""
+        n = int(np.prod(shape))
+        key = str(dtype)
+        buf = self._pin.get(key)
+        if buf is None or buf.numel() < n:
+            buf = torch.empty(max(n, 1), dtype=dtype).pin_memory()
+            self._pin[key] = buf
+        return buf[:n].view(shape)
+
+    def query_finish(self, p, reuse_buffers=False):
         """Second half: wait for that group only (a side stream copies its results; later groups keep running) and
-        return the list of (score, (song, time), song_score|None)."""
+        return the list of (score, (song, time), song_score|None).  reuse_buffers: the song_score blocks are views of a
+        pinned buffer that the NEXT query_finish overwrites (the CLIs write them out at once)."""
         if getattr(self, "_copy_stream", None) is None:
             self._copy_stream = torch.cuda.Stream(p["dev"])
+            self._pin = {}
         with torch.cuda.stream(self._copy_stream):
             self._copy_stream.wait_event(p["ev"][2])
-            res = self.index.results_to_host(p["res"])
-            ss_np = p["ss"].cpu().numpy() if p["ss"] is not None else None
+            ss_np = None
+            if p["ss"] is not None:
+                land = self._pinned(p["ss"].shape, torch.float32)
+                land.copy_(p["ss"], non_blocking=True)
+            res = self.index.results_to_host(p["res"])    # synchronises the copy stream: `land` is complete too
+            if p["ss"] is not None:
+                self._copy_stream.synchronize()
+                ss_np = land.numpy() if reuse_buffers else land.numpy().copy()
         if self.timer is not None:                        # stage split as database.py:165 logs it, from events
             self.timer.mark_gpu("search", p["ev"][0], p["ev"][1])
             self.timer.mark_gpu("rerank", p["ev"][1], p["ev"][2])
             self.timer.resolve()
         out = []
         fsm = self.frame_shift_mul
-        if ss_np is not None:
-            ss_np[:, :, 1] = _fine_to_time(ss_np[:, :, 1].astype(np.int64), fsm, self.hop_size)
         for j in range(p["nq"]):
             r = res[j]
             song_score = ss_np[j] if ss_np is not None else None

@@ -212,6 +212,16 @@ class Engine:
                                                   self._stream()), "pfann_pcm16_to_mono")
         return out
 
+    def warmup(self, windows=512):
+        """Allocates the activation workspace (max_batch segments: 29 GB at 9728) and makes the runtime load every
+        kernel of the path by embedding `windows` windows of silence once.  The CLIs call it while "loading model...",
+        so that first-use costs are not billed to the first batch of files."""
+        n = max(1, min(int(windows), int(self.cfg.max_batch)))
+        wav = torch.zeros(self.seg_len + (n - 1) * 16, device=self.device, dtype=torch.float32)
+        self.embed_windows(wav, np.arange(n, dtype=np.int64) * 16)
+        self.pcm16_to_mono(torch.zeros((64, 1), dtype=torch.int16))
+        torch.cuda.synchronize(self.device)
+
     def set_fused_layernorm(self, on=True):
         """-> True if the LayerNorm-fused GEMM path is now active."""
         return bool(self.lib.pfann_set_fused_layernorm(self.handle, 1 if on else 0))

@@ -36,7 +36,7 @@ class ResultWriter:
     def write(self, name, ans, sco, tim, song_score):
         self.fout.write("%s\t%s\n" % (name, ans))
         self.detail.writerow([name, ans, sco, tim])
-        self.fout_score.write(song_score.tobytes())
+        self.fout_score.write(memoryview(np.ascontiguousarray(song_score, dtype=np.float32)).cast("B"))
 
     def write_error(self, name):
         self.write(name, "error", -1e999, 0, np.zeros([self.n_songs, 2], dtype=np.float32))
@@ -64,9 +64,11 @@ def main(argv=None):
     max_batch = int(os.environ.get("PFANN_MAX_BATCH", "9728"))
     engine = Engine(params, 0, max_batch=max_batch)
     engine.load_state_dict(torch.load(os.path.join(dir_for_db, "model.pt"), map_location="cpu"))
+    engine.warmup()
     print("model loaded")
     print("loading database...")
     db = Database(dir_for_db, params["indexer"], params["hop_size"], device=0, d=params["model"]["d"])
+    db.warmup()
     print("database loaded")
 
     dataset = MusicDataset(file_list_for_query, params)
@@ -90,7 +92,7 @@ def main(argv=None):
         items, good, p = launched
         results = {}
         if p is not None:
-            for (i, _, _), r in zip(good, db.query_finish(p)):
+            for (i, _, _), r in zip(good, db.query_finish(p, reuse_buffers=True)):
                 results[i] = r
         with timer.stage("output answer"):
             for i, n, _ in items:

@@ -78,6 +78,9 @@ class OracleIndex:
         none = res["song"] < 0
         hi = np.where(none, ~np.uint64(0), hi)
         lo = np.where(none, ~np.uint64(0), lo)
+        refused = res["song"] == -2                                 # a refused query beats every real key
+        hi = np.where(refused, np.uint64(0), hi)
+        lo = np.where(refused, np.uint64(0), lo)
         return torch.from_numpy(np.stack([hi, lo], 1).view(np.int64).copy())
 
     def pick_winner(self, all_keys):
@@ -89,6 +92,9 @@ class OracleIndex:
             hi, lo = int(k[g, j, 0]), int(k[g, j, 1])
             if hi == (1 << 64) - 1 and lo == (1 << 64) - 1:
                 out[j] = (-1, 0, 0, 0, -np.inf)
+                continue
+            if hi == 0 and lo == 0:
+                out[j] = (-2, 0, 0, 0, -np.inf)
                 continue
             o = ~np.uint64(hi)
             bits = o ^ np.uint64(1 << 63) if int(o) >> 63 else ~o

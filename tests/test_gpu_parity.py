@@ -747,6 +747,17 @@ def test_winner_keys_pack_and_pick_vs_numpy_statement(torch_cuda):
     for f in ("song", "offset", "shift"):
         assert np.array_equal(got[f], want[f]), f
     assert np.array_equal(got["score"], want["score"]) and got["song"][7] == -1 and got["score"][7] == -np.inf
+    # a query REFUSED on one rank (song == -2: candidate buffer sizing error) is not "no candidate": the pick hands the
+    # -2 on and the host raises, whatever the other ranks found
+    from pfann_amd.lib import PfannError
+    res2 = res.copy()
+    res2["song"][3, 11] = -2
+    keys2 = [idx.pack_winner_keys(torch_cuda.as_tensor(np.frombuffer(res2[g].tobytes(), np.uint8).reshape(nQ, 24).copy()).cuda()).cpu()
+             for g in range(G)]
+    assert np.array_equal(keys2[3].numpy(), ob.pack_winner_keys(res2[3]).numpy())
+    assert ob.pick_winner(torch_cuda.stack(keys2))["song"][11] == -2
+    with pytest.raises(PfannError):
+        idx.pick_winner(torch_cuda.stack(keys2).cuda())
     # and against the definition: highest score, ties -> smallest (shift, song, offset)
     for j in range(nQ):
         c = [(-(res["score"][g, j] + 0.0), res["shift"][g, j], res["song"][g, j], res["offset"][g, j]) for g in range(G) if res["song"][g, j] >= 0]
