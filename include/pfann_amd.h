@@ -110,6 +110,13 @@ int pfann_segment_embed_at(pfann_ctx *ctx, const float *wav_dev, const int64_t *
 int pfann_pcm16_to_mono(pfann_ctx *ctx, const int16_t *pcm_dev, int64_t n_frames, int n_ch,
                         float *wav_dev, void *stream);
 
+/* Many MONO files at the model's rate in one call (the per-song loop of builder.py:75-103 / matcher.py:87-110 spends its
+ * host time per file): file i = n_samples[i] int16 samples at host_pcm[i] (pinned host memory uploads asynchronously)
+ * is copied to pcm_dev[dst_off[i] ..] and the whole slab pcm_dev[0 .. total) is converted to wav_dev (x/32768) by ONE
+ * launch.  Gaps between files (zero padding of short files, slots other paths fill afterwards) are the caller's. */
+int pfann_pcm16_files_to_mono(pfann_ctx *ctx, const void *const *host_pcm, const int64_t *n_samples, const int64_t *dst_off,
+                              int n_files, int16_t *pcm_dev, int64_t total, float *wav_dev, void *stream);
+
 /* Files at another sample rate (datautil/musicdata.py:28-65: `julius.ResampleFrac(file_sr, sample_rate)`, applied to 60 s
  * pieces that start every 59 s, half a second dropped at the inner seams), then the same mono conversion.
  *   pcm_dev      int16 interleaved [n_in][n_ch]

@@ -8,6 +8,7 @@ converted/segmented/mel-ed/encoded by the HIP kernels, several songs per launch,
 fingerprints only come back to the host once, to be written to disk.
 """
 import collections
+import ctypes
 import os
 import shutil
 import sys
@@ -19,6 +20,7 @@ import numpy as np
 import torch
 
 from . import faissio
+from . import lib as _l
 from .engine import Engine
 from .musicdata import MusicDataset
 from .utils import StageTimer, init_logger, read_config
@@ -48,9 +50,18 @@ class _PinnedPool:
 
 
 def _decode(dataset, i, pool, native_rate):
-    """Runs on a decode worker: file -> int16 PCM in a pinned buffer.  -> (pcm [n, ch] pinned view, rate, buffer)."""
+    """Runs on a decode worker: file -> int16 PCM in a pinned buffer.  -> (pcm [n, ch] pinned tensor view, rate, buffer)."""
+    taken = []
+
+    def alloc(n):                           # MusicDataset reads the samples straight into pinned memory
+        buf = pool.get(max(n, 1))
+        taken.append(buf)
+        return buf.numpy()[:n]
     if hasattr(dataset, "load_pcm_sr"):
-        pcm, sr = dataset.load_pcm_sr(i)
+        try:
+            pcm, sr = dataset.load_pcm_sr(i, alloc)
+        except TypeError:                   # a dataset whose load_pcm_sr takes no allocator
+            pcm, sr = dataset.load_pcm_sr(i)
     else:                                   # a list of PCM the caller vouches is at the model's rate (bench.py)
         pcm, sr = dataset.load_pcm(i), native_rate
     if sr is None:
@@ -62,6 +73,9 @@ def _decode(dataset, i, pool, native_rate):
         raise ValueError("16-bit PCM expected, got %s" % pcm.dtype)
     if pcm.size == 0 and int(sr) != int(native_rate):
         raise ValueError("empty file at a foreign rate")      # the reference's resampler raises there: 0-segment song
+    if taken:
+        buf = taken[0]
+        return buf[:pcm.size].view(pcm.shape), sr, buf
     buf = pool.get(max(pcm.size, 1))
     view = buf[:pcm.size].view(pcm.shape)
     np.copyto(view.numpy(), pcm)
@@ -79,7 +93,7 @@ def embed_file_batches(engine, dataset, hop, batch_windows=4096, timer=None, nor
     timer = timer or StageTimer()
     seg = engine.seg_len
     native = int(engine.params["sample_rate"])
-    workers = int(os.environ.get("PFANN_DECODE_WORKERS", "4")) if workers is None else workers
+    workers = int(os.environ.get("PFANN_DECODE_WORKERS", "8")) if workers is None else workers
     ahead = max(4 * workers, 16) if ahead is None else ahead
     pool = _PinnedPool()
     pending, held, in_flight = [], [], collections.deque()
@@ -87,28 +101,48 @@ def embed_file_batches(engine, dataset, hop, batch_windows=4096, timer=None, nor
     t_load = t_mono = 0.0
 
     def flush():
+        """pending: (index, n_seg, item) with item = ("host", pinned int16 view [n] (mono, native rate), n) -- uploaded and
+        converted here, all files of the group by ONE library call -- or ("dev", float32 mono wav on the device) for
+        files that needed their own path (stereo, another sample rate, PCM handed over as a tensor), or None (error)."""
         nonlocal pending, held, n_win, t_load, t_mono
         if not pending:
             return None
+        t1 = time.perf_counter()
+        starts, layout, total, short = [], [], 0, False
+        for _, n_seg, item in pending:
+            if n_seg:
+                ln = max(item[2] if item[0] == "host" else item[1].shape[0], seg)          # musicdata.py:82-84 zero padding
+                short |= ln > (item[2] if item[0] == "host" else item[1].shape[0])
+                starts.append(total + np.arange(n_seg, dtype=np.int64) * hop)
+                layout.append((item, total))
+                total += ln
+        out = [(idx, 0, None) for idx, _, _ in pending]
+        if layout:
+            hosts = [(it, off) for it, off in layout if it[0] == "host"]
+            wav_all = (torch.zeros if short else torch.empty)(total, device=engine.device, dtype=torch.float32)
+            if hosts:
+                pcm_all = (torch.zeros if short else torch.empty)(total, device=engine.device, dtype=torch.int16)
+                m = len(hosts)
+                ptrs = (ctypes.c_void_p * m)(*[it[1].data_ptr() for it, _ in hosts])
+                lens = (ctypes.c_int64 * m)(*[it[2] for it, _ in hosts])
+                offs = (ctypes.c_int64 * m)(*[off for _, off in hosts])
+                _l.check(engine.lib.pfann_pcm16_files_to_mono(engine.handle, ptrs, lens, offs, m, pcm_all.data_ptr(), total,
+                                                              wav_all.data_ptr(), _l.current_stream_ptr(engine.device)),
+                         "pfann_pcm16_files_to_mono")
+            for it, off in layout:
+                if it[0] == "dev":
+                    wav_all[off:off + it[1].shape[0]].copy_(it[1])
+        t_mono += time.perf_counter() - t1
         timer.add("load", t_load)                      # one record per launch group (the reference: one per file)
         timer.add("stereo to mono", t_mono)
         t_load = t_mono = 0.0
-        with timer.stage_gpu("compute embedding"):
-            wavs, starts, base = [], [], 0
-            for _, n_seg, w in pending:
-                if n_seg:
-                    wavs.append(w)
-                    starts.append(base + np.arange(n_seg, dtype=np.int64) * hop)
-                    base += w.shape[0]
-            out = []
-            if wavs:
-                emb = engine.embed_windows(torch.cat(wavs) if len(wavs) > 1 else wavs[0], np.concatenate(starts), norm=norm)
-                o = 0
-                for idx, n_seg, _ in pending:
-                    out.append((idx, n_seg, emb[o:o + n_seg] if n_seg else None))
-                    o += n_seg
-            else:
-                out = [(idx, 0, None) for idx, _, _ in pending]
+        if layout:
+            with timer.stage_gpu("compute embedding"):
+                emb = engine.embed_windows(wav_all, np.concatenate(starts), norm=norm)
+            out, o = [], 0
+            for idx, n_seg, _ in pending:
+                out.append((idx, n_seg, emb[o:o + n_seg] if n_seg else None))
+                o += n_seg
         # the pinned buffers of this group are free again once the stream has passed their uploads
         ev = torch.cuda.Event()
         ev.record()
@@ -135,17 +169,24 @@ def embed_file_batches(engine, dataset, hop, batch_windows=4096, timer=None, nor
                 t_load += t1 - t0
                 if buf is not None:
                     held.append(buf)
-                wav = engine.pcm16_to_mono(pcm, sample_rate=sr)
-                if wav.shape[0] < seg:                                        # musicdata.py:82-84
-                    wav = torch.nn.functional.pad(wav, (0, seg - wav.shape[0]))
-                n_seg = (wav.shape[0] - seg) // hop + 1
+                n_in = pcm.shape[0]
+                pinned_host = buf is not None or (isinstance(pcm, torch.Tensor) and pcm.device.type == "cpu" and
+                                                  pcm.dtype == torch.int16 and pcm.is_contiguous() and pcm.is_pinned())
+                if pinned_host and int(sr) == native and (pcm.dim() == 1 or pcm.shape[1] == 1):
+                    item = ("host", pcm.reshape(-1), n_in)                    # the common case: uploaded with its group
+                    n_out = n_in
+                else:                                                         # stereo / another rate / a caller's tensor
+                    wav = engine.pcm16_to_mono(pcm, sample_rate=sr)
+                    item = ("dev", wav)
+                    n_out = wav.shape[0]
+                n_seg = (max(n_out, seg) - seg) // hop + 1
                 t_mono += time.perf_counter() - t1
             except Exception as x:                                            # musicdata.py:95-101
                 print("load %s error! (%s)" % (dataset.files[i], x))
-                wav, n_seg = None, 0
+                item, n_seg = None, 0
             if pending and n_win + n_seg > batch_windows:     # a group never exceeds the encoder's chunk (no small tail pass)
                 yield flush()
-            pending.append((i, n_seg, wav))
+            pending.append((i, n_seg, item))
             n_win += n_seg
             if n_win >= batch_windows:
                 yield flush()

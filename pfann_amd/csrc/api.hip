@@ -511,6 +511,19 @@ int pfann_pcm16_to_mono(pfann_ctx *c, const int16_t *pcm, int64_t n_frames, int 
     return launch_pcm16_to_mono(pcm, n_frames, n_ch, wav, reinterpret_cast<float *>(c->scratch), (hipStream_t)stream);
 }
 
+int pfann_pcm16_files_to_mono(pfann_ctx *c, const void *const *host_pcm, const int64_t *n_samples, const int64_t *dst_off,
+                              int n_files, int16_t *pcm_dev, int64_t total, float *wav_dev, void *stream) {
+    PF_HIP(hipSetDevice(c->device));
+    for (int i = 0; i < n_files; ++i) {
+        if (n_samples[i] <= 0) continue;
+        if (dst_off[i] < 0 || dst_off[i] + n_samples[i] > total) { set_error("pcm16_files_to_mono: file %d outside the slab", i); return -1; }
+        PF_HIP(hipMemcpyAsync(pcm_dev + dst_off[i], host_pcm[i], (size_t)n_samples[i] * sizeof(int16_t), hipMemcpyHostToDevice,
+                              (hipStream_t)stream));
+    }
+    if (total <= 0) return 0;
+    return launch_pcm16_to_mono(pcm_dev, total, 1, wav_dev, reinterpret_cast<float *>(c->scratch), (hipStream_t)stream);
+}
+
 void pfann_debug_keep(pfann_ctx *c, int on) { c->keep = on != 0; }
 
 int pfann_set_streams(pfann_ctx *c, int n) {

@@ -43,6 +43,8 @@ SYMBOLS = {
     "pfann_segment_embed": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p]),
     "pfann_segment_embed_at": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p]),
     "pfann_pcm16_to_mono": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "pfann_pcm16_files_to_mono": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64), POINTER(c_int64), c_int, c_void_p, c_int64,
+                                          c_void_p, c_void_p]),
     "pfann_resample_to_mono": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int64,
                                        c_void_p, c_void_p, c_void_p]),
     "pfann_debug_activation": (c_int64, [c_void_p, c_int, c_int64, c_void_p, c_int64]),

@@ -9,6 +9,7 @@ Two ways to consume a file:
   * `MusicDataset.load_pcm_sr(i) -> (int16[n, ch], rate)`    -- raw PCM for the fused device
     path (Engine.pcm16_to_mono + Engine.embed_wav), which never materialises the unfold.
 """
+import struct
 import time
 import wave
 
@@ -18,14 +19,51 @@ import torch
 from .utils import get_logger, read_file_list
 
 
-def read_wav_pcm16(path):
-    """-> (int16[n_frames, n_ch], sample_rate).  16-bit PCM only (audio.py:130-149)."""
-    with wave.open(path, "rb") as w:
-        if w.getsampwidth() != 2:
-            raise NotImplementedError("wave stream currently only supports 16bit wav")
-        n_ch, sr = w.getnchannels(), w.getframerate()
-        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16).reshape(-1, n_ch)
-    return pcm, sr
+def read_wav_pcm16(path, alloc=None):
+    """-> (int16[n_frames, n_ch], sample_rate).  16-bit PCM only (audio.py:130-149: the reference reads WAV files with
+    the `wave` module and refuses other sample widths).  The RIFF chunks are walked here so that the samples can be read
+    by ONE readinto() straight into the caller's buffer: alloc(n_int16) -> writable int16 numpy array (the decode
+    workers hand out pinned memory); without alloc a fresh array is returned."""
+    with open(path, "rb", buffering=0) as f:
+        head = f.read(12)
+        if len(head) < 12 or head[:4] != b"RIFF" or head[8:12] != b"WAVE":
+            raise wave.Error("file does not start with RIFF id / not a WAVE file")
+        fmt = None
+        while True:
+            ch = f.read(8)
+            if len(ch) < 8:
+                raise wave.Error("fmt chunk and/or data chunk missing")
+            cid, size = ch[:4], struct.unpack("<I", ch[4:])[0]
+            if cid == b"fmt ":
+                body = f.read(size + (size & 1))
+                if len(body) < 16:
+                    raise wave.Error("fmt chunk too short")
+                tag, n_ch, sr, _, _, bits = struct.unpack("<HHIIHH", body[:16])
+                if tag == 0xFFFE and len(body) >= 26:                     # WAVE_FORMAT_EXTENSIBLE: the sub-format's tag
+                    tag = struct.unpack("<H", body[24:26])[0]
+                if tag != 1:
+                    raise wave.Error("unknown format: %r" % (tag,))
+                if n_ch < 1:
+                    raise wave.Error("bad # of channels")
+                if (bits + 7) // 8 != 2:
+                    raise NotImplementedError("wave stream currently only supports 16bit wav")
+                fmt = (n_ch, sr)
+            elif cid == b"data":
+                if fmt is None:
+                    raise wave.Error("data chunk before fmt chunk")
+                n_ch, sr = fmt
+                n = size // (2 * n_ch) * n_ch                               # whole frames only
+                buf = alloc(n) if alloc is not None else np.empty(n, dtype=np.int16)
+                got = f.readinto(memoryview(buf).cast("B")[: n * 2]) if n else 0
+                while 0 < got < n * 2:                                      # short reads (pipes, network file systems)
+                    more = f.readinto(memoryview(buf).cast("B")[got: n * 2])
+                    if not more:
+                        break
+                    got += more
+                n = (got or 0) // (2 * n_ch) * n_ch                         # truncated file: what is there
+                return buf[:n].reshape(-1, n_ch), sr
+            else:
+                f.seek(size + (size & 1), 1)
 
 
 class MusicDataset:
@@ -45,10 +83,11 @@ class MusicDataset:
         n = max(n_samples, self.segment_size)
         return (n - self.segment_size) // self.hop + 1
 
-    def load_pcm_sr(self, index):
-        """-> (int16 [n, ch] as stored, the file's sample rate).  Stateless (decode workers call it concurrently); the
-        device path resamples when the rate is not the model's: Engine.pcm16_to_mono(pcm, sample_rate=sr)."""
-        return read_wav_pcm16(self.files[index])
+    def load_pcm_sr(self, index, alloc=None):
+        """-> (int16 [n, ch] as stored, the file's sample rate).  Stateless (decode workers call it concurrently, each
+        with an `alloc` that hands out pinned memory); the device path resamples when the rate is not the model's:
+        Engine.pcm16_to_mono(pcm, sample_rate=sr)."""
+        return read_wav_pcm16(self.files[index], alloc)
 
     def load_pcm(self, index):
         """-> int16 [n, ch]; kept for callers that know their files are at the model's rate (raises otherwise)."""

@@ -127,7 +127,7 @@ def run(n_songs=10000, n_queries=2000, snr=0.0, device=0, keep=False, workdir=No
             env.pop(k, None)
         db = os.path.join(work, "db")
         out = {"songs": n_songs, "queries": n_queries, "snr_db": snr, "dir": os.path.dirname(work),
-               "decode_workers": int(os.environ.get("PFANN_DECODE_WORKERS", "4")),
+               "decode_workers": int(os.environ.get("PFANN_DECODE_WORKERS", "8")),
                "wav_bytes": int(n_songs * SEG_PER_SONG * 8000 + n_queries * 160000)}
         # ---- builder
         t0 = time.time()
