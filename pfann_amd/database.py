@@ -164,9 +164,9 @@ class DeviceIndex:
         tensor of results --, song_scores or None)."""
         q = q.to(self.device, torch.float32).contiguous()
         labels = labels.to(self.device, torch.int64).contiguous()
-        qs = torch.as_tensor(np.asarray(qstart, dtype=np.int64)).to(self.device)
+        qs = _l.upload_async(qstart, self.device, np.int64)
         ql_np = np.asarray(qlen, dtype=np.int32)
-        ql = torch.as_tensor(ql_np).to(self.device)
+        ql = _l.upload_async(ql_np, self.device, np.int32)
         nQ = int(ql_np.shape[0])
         k = labels.shape[1]
         res = torch.empty((nQ, ctypes.sizeof(_l.MatchResult)), device=self.device, dtype=torch.uint8)

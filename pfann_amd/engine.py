@@ -172,8 +172,10 @@ class Engine:
         start offsets (device tensor or array) -> [len(starts), d]."""
         self._need_front_end("embed_windows")
         w = self._prep(wav).reshape(-1)
-        st = starts if isinstance(starts, torch.Tensor) else torch.as_tensor(np.asarray(starts, np.int64))
-        st = st.to(self.device, torch.int64).contiguous()
+        if isinstance(starts, torch.Tensor):
+            st = starts.to(self.device, torch.int64).contiguous()
+        else:
+            st = _l.upload_async(starts, self.device, np.int64)
         B = st.shape[0]
         out = torch.empty((B, self.d), device=self.device, dtype=torch.float32)
         if B:
@@ -198,7 +200,7 @@ class Engine:
                 self._resample_tables[key] = (torch.from_numpy(tab).to(self.device), old, new, width)
             tab, old, new, width = self._resample_tables[key]
             plan, n_out = resample.piece_plan(n, int(sample_rate), int(self.params["sample_rate"]))
-            plan_dev = torch.from_numpy(plan).to(self.device)
+            plan_dev = _l.upload_async(plan, self.device, np.int64)
             tmp = torch.empty((n_ch, n_out), device=self.device, dtype=torch.float32)
             out = torch.empty((n_out,), device=self.device, dtype=torch.float32)
             if n_out:

@@ -113,6 +113,16 @@ def current_stream_ptr(device=None):
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def upload_async(arr, device, dtype):
+    """Small host array -> device tensor WITHOUT making the host wait for the stream: staged through torch's caching
+    pinned allocator.  A copy from pageable memory blocks the calling thread until everything queued before it on
+    the stream has run, which would serialise the host-side pipeline (decode, launches, result writing) with the GPU."""
+    import numpy as np
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(arr, dtype=dtype))
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def require_gpu():
     import torch
     if not torch.cuda.is_available():
