@@ -117,6 +117,30 @@ int pfann_pcm16_to_mono(pfann_ctx *ctx, const int16_t *pcm_dev, int64_t n_frames
 int pfann_pcm16_files_to_mono(pfann_ctx *ctx, const void *const *host_pcm, const int64_t *n_samples, const int64_t *dst_off,
                               int n_files, int16_t *pcm_dev, int64_t total, float *wav_dev, void *stream);
 
+/* ---- host-side WAV input (no GPU involved): the reference's decode workers (DataLoader(num_workers=4) over
+ * MusicDataset, builder.py:66; datautil/audio.py:130-149: `wave` module, 16-bit PCM only) as native threads that fill
+ * one pinned slab per launch group.  pfann_wav_probe walks each file's RIFF chunks ("fmt " then "data", other chunks
+ * skipped) and reports the frames that are really in the file; pfann_wav_read reads file i's n_frames*n_ch interleaved
+ * samples to dst + dst_off[i] (int16 units).  status: 0 ok, or one of the codes below (such a file is what the reference
+ * logs as a load error and treats as a 0-segment song, musicdata.py:95-101).  Both return 0, or <0 on bad arguments
+ * (-2: a file does not fit dst_cap). */
+typedef struct pfann_wav_info {
+    int64_t n_frames;      /* per channel */
+    int64_t data_pos;      /* byte offset of the samples in the file */
+    int32_t n_ch;
+    int32_t sample_rate;
+    int32_t status;
+    int32_t reserved;
+} pfann_wav_info;
+#define PFANN_WAV_EOPEN (-1)    /* cannot open / stat */
+#define PFANN_WAV_EFORMAT (-2)  /* not RIFF/WAVE, or fmt / data chunk missing */
+#define PFANN_WAV_ECODEC (-3)   /* not PCM (format tag != 1), or no channels */
+#define PFANN_WAV_EWIDTH (-4)   /* not 16-bit samples */
+#define PFANN_WAV_EREAD (-5)    /* read error */
+int pfann_wav_probe(const char *const *paths, int n, int n_threads, pfann_wav_info *info);
+int pfann_wav_read(const char *const *paths, int n, int n_threads, pfann_wav_info *info, const int64_t *dst_off,
+                   int16_t *dst, int64_t dst_cap);
+
 /* Files at another sample rate (datautil/musicdata.py:28-65: `julius.ResampleFrac(file_sr, sample_rate)`, applied to 60 s
  * pieces that start every 59 s, half a second dropped at the inner seams), then the same mono conversion.
  *   pcm_dev      int16 interleaved [n_in][n_ch]

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libpfann_amd.so")
-SOURCES = ["api.hip", "mel.hip", "encoder.hip", "encoder_fused.hip", "search.hip", "search_f16.hip", "rerank.hip"]
+SOURCES = ["api.hip", "mel.hip", "encoder.hip", "encoder_fused.hip", "search.hip", "search_f16.hip", "rerank.hip", "wavio.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "search_common.h"),
            os.path.join(HERE, "..", "include", "pfann_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"] + os.environ.get("PFANN_HIPCC_FLAGS", "").split()

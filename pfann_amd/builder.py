@@ -10,6 +10,7 @@ fingerprints only come back to the host once, to be written to disk.
 import collections
 import ctypes
 import os
+import queue
 import shutil
 import sys
 import threading
@@ -82,81 +83,23 @@ def _decode(dataset, i, pool, native_rate):
     return view, sr, buf
 
 
-def embed_file_batches(engine, dataset, hop, batch_windows=4096, timer=None, norm=True, workers=None, ahead=None):
-    """Yields one list per launch group: [(index, n_seg, embeddings cuda tensor [n_seg, d] or None), ...] in list order;
-    a file that fails to load has n_seg = 0 (the reference's 0-segment-song convention, builder.py:82-86).
+_WAV_INFO = np.dtype([("n_frames", "<i8"), ("data_pos", "<i8"), ("n_ch", "<i4"), ("sample_rate", "<i4"), ("status", "<i4"),
+                      ("reserved", "<i4")])
+_WAV_ERR = {-1: "cannot open the file", -2: "not a RIFF/WAVE file, or fmt/data chunk missing", -3: "not PCM",
+            -4: "wave stream currently only supports 16bit wav", -5: "read error"}
 
-    Decode runs ahead of the GPU on `workers` host threads (the reference: DataLoader(num_workers=4), builder.py:66;
-    PFANN_DECODE_WORKERS) that read each file into pinned memory; the main thread only issues the asynchronous upload
-    and the launches, and never waits for the GPU: stage times of GPU work are taken with events
-    (utils.StageTimer.stage_gpu)."""
-    timer = timer or StageTimer()
+
+def _threaded_groups(engine, dataset, hop, batch_windows, pool, workers, ahead):
+    """Generic source: any dataset with load_pcm_sr / load_pcm, decoded by a pool of Python threads.  Yields
+    (items, slab, release, t_load) per launch group; items = [(index, n_seg, item)], item = ("host", pinned int16 1-D view, n)
+    | ("dev", mono float wav on the device) | None (load error)."""
     seg = engine.seg_len
     native = int(engine.params["sample_rate"])
-    workers = int(os.environ.get("PFANN_DECODE_WORKERS", "8")) if workers is None else workers
-    ahead = max(4 * workers, 16) if ahead is None else ahead
-    pool = _PinnedPool()
-    pending, held, in_flight = [], [], collections.deque()
-    n_win = 0
-    t_load = t_mono = 0.0
-
-    def flush():
-        """pending: (index, n_seg, item) with item = ("host", pinned int16 view [n] (mono, native rate), n) -- uploaded and
-        converted here, all files of the group by ONE library call -- or ("dev", float32 mono wav on the device) for
-        files that needed their own path (stereo, another sample rate, PCM handed over as a tensor), or None (error)."""
-        nonlocal pending, held, n_win, t_load, t_mono
-        if not pending:
-            return None
-        t1 = time.perf_counter()
-        starts, layout, total, short = [], [], 0, False
-        for _, n_seg, item in pending:
-            if n_seg:
-                ln = max(item[2] if item[0] == "host" else item[1].shape[0], seg)          # musicdata.py:82-84 zero padding
-                short |= ln > (item[2] if item[0] == "host" else item[1].shape[0])
-                starts.append(total + np.arange(n_seg, dtype=np.int64) * hop)
-                layout.append((item, total))
-                total += ln
-        out = [(idx, 0, None) for idx, _, _ in pending]
-        if layout:
-            hosts = [(it, off) for it, off in layout if it[0] == "host"]
-            wav_all = (torch.zeros if short else torch.empty)(total, device=engine.device, dtype=torch.float32)
-            if hosts:
-                pcm_all = (torch.zeros if short else torch.empty)(total, device=engine.device, dtype=torch.int16)
-                m = len(hosts)
-                ptrs = (ctypes.c_void_p * m)(*[it[1].data_ptr() for it, _ in hosts])
-                lens = (ctypes.c_int64 * m)(*[it[2] for it, _ in hosts])
-                offs = (ctypes.c_int64 * m)(*[off for _, off in hosts])
-                _l.check(engine.lib.pfann_pcm16_files_to_mono(engine.handle, ptrs, lens, offs, m, pcm_all.data_ptr(), total,
-                                                              wav_all.data_ptr(), _l.current_stream_ptr(engine.device)),
-                         "pfann_pcm16_files_to_mono")
-            for it, off in layout:
-                if it[0] == "dev":
-                    wav_all[off:off + it[1].shape[0]].copy_(it[1])
-        t_mono += time.perf_counter() - t1
-        timer.add("load", t_load)                      # one record per launch group (the reference: one per file)
-        timer.add("stereo to mono", t_mono)
-        t_load = t_mono = 0.0
-        if layout:
-            with timer.stage_gpu("compute embedding"):
-                emb = engine.embed_windows(wav_all, np.concatenate(starts), norm=norm)
-            out, o = [], 0
-            for idx, n_seg, _ in pending:
-                out.append((idx, n_seg, emb[o:o + n_seg] if n_seg else None))
-                o += n_seg
-        # the pinned buffers of this group are free again once the stream has passed their uploads
-        ev = torch.cuda.Event()
-        ev.record()
-        in_flight.append((ev, held))
-        while in_flight and in_flight[0][0].query():
-            pool.put(in_flight.popleft()[1])
-        timer.resolve()
-        pending, held, n_win = [], [], 0
-        return out
-
     n = len(dataset)
     ex = ThreadPoolExecutor(max_workers=max(workers, 1)) if workers > 0 else None
     futs = collections.deque()
     nxt = 0
+    pending, held, n_win, t_load = [], [], 0, 0.0
     try:
         for i in range(n):
             while ex is not None and nxt < n and nxt - i < ahead:
@@ -165,8 +108,7 @@ def embed_file_batches(engine, dataset, hop, batch_windows=4096, timer=None, nor
             try:
                 t0 = time.perf_counter()                # "load": what the GPU-feeding thread waited for the decoders
                 pcm, sr, buf = futs.popleft().result() if ex is not None else _decode(dataset, i, pool, native)
-                t1 = time.perf_counter()
-                t_load += t1 - t0
+                t_load += time.perf_counter() - t0
                 if buf is not None:
                     held.append(buf)
                 n_in = pcm.shape[0]
@@ -180,22 +122,210 @@ def embed_file_batches(engine, dataset, hop, batch_windows=4096, timer=None, nor
                     item = ("dev", wav)
                     n_out = wav.shape[0]
                 n_seg = (max(n_out, seg) - seg) // hop + 1
-                t_mono += time.perf_counter() - t1
             except Exception as x:                                            # musicdata.py:95-101
                 print("load %s error! (%s)" % (dataset.files[i], x))
                 item, n_seg = None, 0
             if pending and n_win + n_seg > batch_windows:     # a group never exceeds the encoder's chunk (no small tail pass)
-                yield flush()
+                yield pending, None, held, t_load
+                pending, held, n_win, t_load = [], [], 0, 0.0
             pending.append((i, n_seg, item))
             n_win += n_seg
             if n_win >= batch_windows:
-                yield flush()
-        out = flush()
-        if out is not None:
-            yield out
+                yield pending, None, held, t_load
+                pending, held, n_win, t_load = [], [], 0, 0.0
+        if pending:
+            yield pending, None, held, t_load
     finally:
         if ex is not None:
             ex.shutdown(wait=True, cancel_futures=True)
+
+
+def _native_groups(engine, dataset, hop, batch_windows, pool, workers):
+    """WAV files through the library's native reader (csrc/wavio.hip): a producer thread probes the headers, cuts the
+    list into launch groups, and has `workers` native threads read each group's samples into ONE pinned slab, two
+    groups ahead of the GPU.  Yields like _threaded_groups; slab = (pinned int16 tensor, samples used) when the group
+    is uniform (every readable file mono, at the model's rate, at least one segment long: the slab IS the group's
+    concatenated PCM and goes up in one copy)."""
+    from . import resample
+    lib = engine.lib
+    seg = engine.seg_len
+    native = int(engine.params["sample_rate"])
+    files = dataset.files
+    n = len(files)
+    paths = [os.fsencode(f) for f in files]
+    out_q = queue.Queue(maxsize=2)
+    stop = threading.Event()
+    PROBE = 1024
+
+    def produce():
+        try:
+            pos = 0
+            info = np.zeros(0, _WAV_INFO)
+            nseg = np.zeros(0, np.int64)
+            base = 0                        # file index of info[0]
+            while (pos < n or info.shape[0]) and not stop.is_set():
+                if info.shape[0] == 0 or (pos < n and nseg.sum() < batch_windows):
+                    m = min(PROBE, n - pos)
+                    if m > 0:
+                        more = np.zeros(m, _WAV_INFO)
+                        arr = (ctypes.c_char_p * m)(*paths[pos:pos + m])
+                        lib.pfann_wav_probe(arr, m, workers, more.ctypes.data_as(ctypes.POINTER(_l.WavInfo)))
+                        n_out = more["n_frames"].copy()
+                        for j in np.nonzero((more["status"] == 0) & (more["sample_rate"] != native))[0]:
+                            if more["n_frames"][j] == 0 or more["sample_rate"][j] <= 0:
+                                more["status"][j] = -2            # the reference's resampler raises on an empty signal
+                            else:
+                                n_out[j] = resample.piece_plan(int(more["n_frames"][j]), int(more["sample_rate"][j]), native)[1]
+                        more_seg = np.where(more["status"] == 0, (np.maximum(n_out, seg) - seg) // hop + 1, 0)
+                        info = np.concatenate([info, more])
+                        nseg = np.concatenate([nseg, more_seg])
+                        pos += m
+                        continue
+                # cut one group off the front: as many files as fit batch_windows (at least one)
+                c = np.cumsum(nseg)
+                take = max(1, int(np.searchsorted(c, batch_windows, side="right")))       # files whose windows still fit
+                g_info, g_seg = info[:take].copy(), nseg[:take].copy()
+                info, nseg = info[take:], nseg[take:]
+                ok = g_info["status"] == 0
+                sizes = np.where(ok, g_info["n_frames"] * g_info["n_ch"], 0)
+                offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+                tot = int(sizes.sum())
+                slab = pool.get(max(tot, 1))
+                arr = (ctypes.c_char_p * take)(*paths[base:base + take])
+                rc = lib.pfann_wav_read(arr, take, workers, g_info.ctypes.data_as(ctypes.POINTER(_l.WavInfo)),
+                                        offs.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), slab.data_ptr(), slab.numel())
+                if rc != 0:
+                    raise _l.PfannError("pfann_wav_read failed (%d)" % rc)
+                g_seg = np.where(g_info["status"] == 0, g_seg, 0)          # a read error after a good probe
+                out_q.put((base, g_info, g_seg, offs, slab, tot))
+                base += take
+            out_q.put(None)
+        except BaseException as x:          # hand the failure to the consumer instead of dying silently
+            out_q.put(x)
+
+    th = threading.Thread(target=produce, name="pfann-wav-loader", daemon=True)
+    th.start()
+    try:
+        while True:
+            t0 = time.perf_counter()
+            got = out_q.get()
+            t_load = time.perf_counter() - t0
+            if got is None:
+                break
+            if isinstance(got, BaseException):
+                raise got
+            base, g_info, g_seg, offs, slab, tot = got
+            ok = g_info["status"] == 0
+            for j in np.nonzero(~ok)[0]:
+                print("load %s error! (%s)" % (files[base + j], _WAV_ERR.get(int(g_info["status"][j]), "error")))
+            uniform = bool(ok.any()) and bool(np.all(~ok | ((g_info["n_ch"] == 1) & (g_info["sample_rate"] == native) &
+                                                            (g_info["n_frames"] >= seg))))
+            items = []
+            for j in range(g_info.shape[0]):
+                if not ok[j]:
+                    items.append((base + j, 0, None))
+                    continue
+                nf, ch, o = int(g_info["n_frames"][j]), int(g_info["n_ch"][j]), int(offs[j])
+                if uniform:
+                    items.append((base + j, int(g_seg[j]), ("slab", o, nf)))
+                elif ch == 1 and int(g_info["sample_rate"][j]) == native:
+                    items.append((base + j, int(g_seg[j]), ("host", slab[o:o + nf], nf)))
+                else:
+                    try:
+                        wav = engine.pcm16_to_mono(slab[o:o + nf * ch].view(nf, ch), sample_rate=int(g_info["sample_rate"][j]))
+                        assert (max(wav.shape[0], seg) - seg) // hop + 1 == int(g_seg[j])
+                        items.append((base + j, int(g_seg[j]), ("dev", wav)))
+                    except Exception as x:
+                        print("load %s error! (%s)" % (files[base + j], x))
+                        items.append((base + j, 0, None))
+            yield items, ((slab, tot) if uniform else None), [slab], t_load
+    finally:
+        stop.set()
+        while th.is_alive():                # unblock a producer waiting on the full queue
+            try:
+                out_q.get_nowait()
+            except queue.Empty:
+                th.join(0.05)
+
+
+def embed_file_batches(engine, dataset, hop, batch_windows=4096, timer=None, norm=True, workers=None, ahead=None):
+    """Yields one list per launch group: [(index, n_seg, embeddings cuda tensor [n_seg, d] or None), ...] in list order;
+    a file that fails to load has n_seg = 0 (the reference's 0-segment-song convention, builder.py:82-86).
+
+    Decode runs ahead of the GPU on `workers` host threads (the reference: DataLoader(num_workers=4), builder.py:66;
+    PFANN_DECODE_WORKERS): for a MusicDataset the library's native WAV reader fills one pinned slab per group
+    (PFANN_NATIVE_WAV=0: Python threads, as for any other dataset); the main thread only issues the asynchronous uploads
+    and the launches and never waits for the GPU: stage times of GPU work are taken with events
+    (utils.StageTimer.stage_gpu)."""
+    timer = timer or StageTimer()
+    seg = engine.seg_len
+    workers = int(os.environ.get("PFANN_DECODE_WORKERS", "8")) if workers is None else workers
+    ahead = max(4 * workers, 16) if ahead is None else ahead
+    pool = _PinnedPool()
+    in_flight = collections.deque()
+    if isinstance(dataset, MusicDataset) and workers > 0 and os.environ.get("PFANN_NATIVE_WAV", "1") != "0":
+        source = _native_groups(engine, dataset, hop, batch_windows, pool, workers)
+    else:
+        source = _threaded_groups(engine, dataset, hop, batch_windows, pool, workers, ahead)
+
+    for pending, slab, release, t_load in source:
+        t1 = time.perf_counter()
+        out = [(idx, 0, None) for idx, _, _ in pending]
+        wav_all = starts = None
+        if slab is not None:
+            # uniform group: the slab is the concatenated PCM of the group -- one upload, one conversion
+            pcm_all = slab[0][:slab[1]].to(engine.device, non_blocking=True)
+            wav_all = torch.empty(slab[1], device=engine.device, dtype=torch.float32)
+            _l.check(engine.lib.pfann_pcm16_to_mono(engine.handle, pcm_all.data_ptr(), slab[1], 1, wav_all.data_ptr(),
+                                                    _l.current_stream_ptr(engine.device)), "pfann_pcm16_to_mono")
+            live = [(it[1], n_seg) for _, n_seg, it in pending if n_seg]
+            o = np.asarray([a for a, _ in live], np.int64)
+            c = np.asarray([b for _, b in live], np.int64)
+            first = np.concatenate([[0], np.cumsum(c)[:-1]])
+            starts = np.repeat(o, c) + (np.arange(int(c.sum()), dtype=np.int64) - np.repeat(first, c)) * hop
+        else:
+            parts, layout, total, short = [], [], 0, False
+            for _, n_seg, item in pending:
+                if n_seg:
+                    have = item[2] if item[0] == "host" else item[1].shape[0]
+                    ln = max(have, seg)                                            # musicdata.py:82-84 zero padding
+                    short |= ln > have
+                    parts.append(total + np.arange(n_seg, dtype=np.int64) * hop)
+                    layout.append((item, total))
+                    total += ln
+            if layout:
+                hosts = [(it, off) for it, off in layout if it[0] == "host"]
+                wav_all = (torch.zeros if short else torch.empty)(total, device=engine.device, dtype=torch.float32)
+                if hosts:
+                    pcm_all = (torch.zeros if short else torch.empty)(total, device=engine.device, dtype=torch.int16)
+                    m = len(hosts)
+                    ptrs = (ctypes.c_void_p * m)(*[it[1].data_ptr() for it, _ in hosts])
+                    lens = (ctypes.c_int64 * m)(*[it[2] for it, _ in hosts])
+                    offs = (ctypes.c_int64 * m)(*[off for _, off in hosts])
+                    _l.check(engine.lib.pfann_pcm16_files_to_mono(engine.handle, ptrs, lens, offs, m, pcm_all.data_ptr(), total,
+                                                                  wav_all.data_ptr(), _l.current_stream_ptr(engine.device)),
+                             "pfann_pcm16_files_to_mono")
+                for it, off in layout:
+                    if it[0] == "dev":
+                        wav_all[off:off + it[1].shape[0]].copy_(it[1])
+                starts = np.concatenate(parts)
+        timer.add("load", t_load)                      # one record per launch group (the reference: one per file)
+        timer.add("stereo to mono", time.perf_counter() - t1)
+        if wav_all is not None:
+            with timer.stage_gpu("compute embedding"):
+                emb = engine.embed_windows(wav_all, starts, norm=norm)
+            out, o = [], 0
+            for idx, n_seg, _ in pending:
+                out.append((idx, n_seg, emb[o:o + n_seg] if n_seg else None))
+                o += n_seg
+        # the pinned buffers of this group are free again once the stream has passed their uploads
+        ev = torch.cuda.Event()
+        ev.record()
+        in_flight.append((ev, release))
+        while in_flight and in_flight[0][0].query():
+            pool.put(in_flight.popleft()[1])
+        timer.resolve()
+        yield out
     timer.resolve(wait=True)
 
 

@@ -27,6 +27,11 @@ class MatchResult(Structure):
                 ("score", c_double)]
 
 
+class WavInfo(Structure):
+    _fields_ = [("n_frames", c_int64), ("data_pos", c_int64), ("n_ch", c_int32), ("sample_rate", c_int32),
+                ("status", c_int32), ("reserved", c_int32)]
+
+
 # every symbol include/pfann_amd.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "version": (c_longlong, []),
@@ -45,6 +50,8 @@ SYMBOLS = {
     "pfann_pcm16_to_mono": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "pfann_pcm16_files_to_mono": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64), POINTER(c_int64), c_int, c_void_p, c_int64,
                                           c_void_p, c_void_p]),
+    "pfann_wav_probe": (c_int, [POINTER(c_char_p), c_int, c_int, POINTER(WavInfo)]),
+    "pfann_wav_read": (c_int, [POINTER(c_char_p), c_int, c_int, POINTER(WavInfo), POINTER(c_int64), c_void_p, c_int64]),
     "pfann_resample_to_mono": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int64,
                                        c_void_p, c_void_p, c_void_p]),
     "pfann_debug_activation": (c_int64, [c_void_p, c_int, c_int64, c_void_p, c_int64]),

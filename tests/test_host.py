@@ -300,3 +300,80 @@ def test_resample_host_tables_match_the_oracle_restatement():
             ref = R.chunk_plan(n_in, old, new)
             assert [tuple(r[:4]) for r in plan.tolist()] == [tuple(r) for r in ref]
             assert n_out == sum(r[3] for r in ref) and plan[:, 4].tolist() == np.cumsum([0] + [r[3] for r in ref[:-1]]).tolist()
+
+
+def test_native_wav_loader_groups_and_slabs(tmp_path):
+    """Host logic of the CLI input pipeline without a GPU: the library's native WAV reader (pfann_wav_probe /
+    pfann_wav_read, csrc/wavio.hip) behind builder._native_groups cuts the list into launch groups that never exceed
+    the window budget, reads every group's samples into one pinned-pool slab identical to what the `wave` module
+    returns, flags unreadable files as 0-segment songs, and marks a group "uniform" only when every readable file is
+    mono, at the model's rate and at least one segment long."""
+    import types
+    import wave
+    from pfann_amd import builder, lib as L
+    from pfann_amd.musicdata import MusicDataset, read_wav_pcm16
+    params = json.load(open(os.path.join(REPO, "configs", "tiny.json")))
+    rng = np.random.default_rng(3)
+    files, want = [], []
+    for j in range(23):
+        path = str(tmp_path / ("f%02d.wav" % j))
+        n = int(rng.integers(9000, 30000))
+        pcm = rng.integers(-3000, 3000, n).astype(np.int16)
+        if j == 5:
+            open(path, "wb").write(b"not a wav")
+            want.append(None)
+        elif j == 9:
+            want.append(None)                                   # missing file
+        elif j == 20:
+            synth.write_wav(path, np.stack([pcm, pcm // 2], 1))  # stereo -> its group is not uniform
+            want.append(np.stack([pcm, pcm // 2], 1))
+        elif j == 21:
+            synth.write_wav(path, pcm[:3000])                   # shorter than a segment -> not uniform
+            want.append(pcm[:3000, None])
+        else:
+            synth.write_wav(path, pcm)
+            want.append(pcm[:, None])
+        files.append(path)
+    # a data chunk behind a LIST chunk, and a truncated file: same samples as the wave module gives
+    raw = open(files[0], "rb").read()
+    open(files[1], "wb").write(raw[:36] + b"LIST" + (6).to_bytes(4, "little") + b"abcdef" + raw[36:])
+    want[1] = want[0]
+    open(files[2], "wb").write(raw[:-777])
+    with wave.open(files[2]) as w:
+        b = w.readframes(w.getnframes())
+    want[2] = np.frombuffer(b[:len(b) // 2 * 2], np.int16)[:, None]
+    for j in (0, 1, 2):
+        got, sr = read_wav_pcm16(files[j])
+        assert sr == 8000 and np.array_equal(got, want[j])
+    ds = MusicDataset(files, params)
+    calls = []
+
+    def fake_mono(pcm, sample_rate=None):
+        calls.append(tuple(pcm.shape))
+        return types.SimpleNamespace(shape=(pcm.shape[0],))
+    eng = types.SimpleNamespace(lib=L.load(), seg_len=8000, params=params, pcm16_to_mono=fake_mono)
+    budget = 12
+    seen = []
+
+    class PageablePool:                                         # no GPU here: nothing can be pinned
+        def get(self, n):
+            import torch
+            return torch.empty(max(n, 1), dtype=torch.int16)
+    for items, slab, release, t_load in builder._native_groups(eng, ds, 4000, budget, PageablePool(), 3):
+        assert sum(n for _, n, _ in items) <= budget or len(items) == 1
+        for idx, n_seg, item in items:
+            seen.append(idx)
+            if want[idx] is None:
+                assert n_seg == 0 and item is None
+                continue
+            nf = want[idx].shape[0]
+            assert n_seg == (max(nf, 8000) - 8000) // 4000 + 1
+            if slab is not None:
+                assert item[0] == "slab" and np.array_equal(slab[0][item[1]:item[1] + item[2]].numpy(), want[idx][:, 0])
+            elif item[0] == "host":
+                assert np.array_equal(item[1].numpy(), want[idx][:, 0])
+        ids = [i for i, _, _ in items]
+        if slab is not None:
+            assert not any(i in (20, 21) for i in ids)
+    assert seen == list(range(23))
+    assert calls == [(want[20].shape[0], 2)]
