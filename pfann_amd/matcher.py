@@ -8,6 +8,7 @@ an "error" row with -inf score and a zero block (matcher.py:94-107).  Queries ar
 searched (exact flat IP top-k) and sequence-matched on the MI355X, many queries per launch.
 """
 import csv
+import ctypes
 import os
 import sys
 import time
@@ -32,20 +33,39 @@ class ResultWriter:
         self.detail = csv.writer(self.fout2)
         self.detail.writerow(["query", "answer", "score", "time", "part_scores"])
         self.n_songs = n_songs
+        self._run = None            # [address, bytes, arrays kept alive] of the pending run of score blocks
 
     def write(self, name, ans, sco, tim, song_score):
         self.fout.write("%s\t%s\n" % (name, ans))
         self.detail.writerow([name, ans, sco, tim])
-        self.fout_score.write(memoryview(np.ascontiguousarray(song_score, dtype=np.float32)).cast("B"))
+        # score blocks of one launch group are consecutive rows of one buffer: they go out as ONE write at flush()
+        # (a write per query is a system call and a GIL hand-over per query)
+        blk = np.ascontiguousarray(song_score, dtype=np.float32)
+        ptr, nb = blk.ctypes.data, blk.nbytes
+        if self._run is not None and ptr == self._run[0] + self._run[1]:
+            self._run[1] += nb
+            self._run[2].append(blk)
+        else:
+            self._flush_run()
+            self._run = [ptr, nb, [blk]]
+
+    def _flush_run(self):
+        if self._run is not None:
+            ptr, nb, _keep = self._run
+            if nb:
+                self.fout_score.write((ctypes.c_char * nb).from_address(ptr))
+            self._run = None
 
     def write_error(self, name):
         self.write(name, "error", -1e999, 0, np.zeros([self.n_songs, 2], dtype=np.float32))
 
     def flush(self):
+        self._flush_run()
         self.fout.flush()
         self.fout2.flush()
 
     def close(self):
+        self._flush_run()
         self.fout.close()
         self.fout2.close()
         self.fout_score.close()
