@@ -5,8 +5,8 @@ PARITY UNPINNED: torchaudio is not installed here and its version is not pinned 
 reference (readme.md:14), so the transform is restated from its documented semantics:
 torch.stft(n_fft, hop, window=hann_window(n_fft) periodic, center=True, pad_mode,
 normalized=False, onesided=True) -> |.|**power -> fb^T @ spec, with fb[n_freqs, n_mels]
-the triangular bank built in fp32 from linspace(0, sr//2, n_freqs) and
-linspace(mel(f_min), mel(f_max), n_mels+2) as max(0, min(down, up)).
+the triangular bank over bins at linspace(0, sr//2, n_freqs) Hz with n_mels+2 edges equally spaced in
+mel between f_min and f_max (written here filter by filter in float64, see mel_filterbank).
 Everything outside the transform follows melspec.py:33-50 line by line.
 Second opinion (not a pin): tests/test_oracle.py compares this restatement with
 transformers.audio_utils (an unrelated numpy/fp64 implementation of the same semantics).
@@ -18,40 +18,48 @@ import torch
 
 
 def _hz_to_mel(f, scale):
+    """HTK: 2595 log10(1 + f/700).  Slaney: linear (200/3 Hz per mel) below 1 kHz, logarithmic above (27 steps per
+    factor 6.4).  float64."""
     if scale == "htk":
         return 2595.0 * math.log10(1.0 + f / 700.0)
-    f_sp = 200.0 / 3
     if f >= 1000.0:
-        return 15.0 + math.log(f / 1000.0) / (math.log(6.4) / 27.0)
-    return f / f_sp
+        return 15.0 + 27.0 * math.log(f / 1000.0) / math.log(6.4)
+    return 3.0 * f / 200.0
 
 
 def _mel_to_hz(m, scale):
     if scale == "htk":
         return 700.0 * (10.0 ** (m / 2595.0) - 1.0)
-    f_sp = 200.0 / 3
-    freqs = f_sp * m
-    logstep = math.log(6.4) / 27.0
-    return torch.where(m >= 15.0, 1000.0 * torch.exp(logstep * (m - 15.0)), freqs)
+    if m >= 15.0:
+        return 1000.0 * 6.4 ** ((m - 15.0) / 27.0)
+    return 200.0 * m / 3.0
 
 
 def mel_filterbank(sample_rate, n_fft, n_mels, f_min, f_max, naf_mode=False):
-    """fb float32[n_fft//2+1, n_mels]; htk/no-norm by default, slaney/slaney in naf_mode
-    (melspec.py:27-30)."""
+    """fb float32[n_fft//2+1, n_mels]: htk scale / no normalisation by default, slaney scale / slaney (area) normalisation
+    in naf_mode (melspec.py:27-30).
+
+    Written from the PUBLISHED DEFINITION of the triangular bank, filter by filter, in float64 -- deliberately not the
+    vectorised fp32 torch op sequence the product's host code (pfann_amd/engine.py:mel_filterbank, which imitates how
+    torchaudio builds its bank) uses, so that the two are independent statements: n_mels + 2 band edges equally spaced
+    on the mel scale between f_min and f_max; filter m rises linearly from 0 at edge m to 1 at edge m+1 and falls back to
+    0 at edge m+2; bin k sits at k * (sample_rate // 2) / (n_freqs - 1) Hz.  tests/test_host.py measures the gap between
+    the two (fp32 vs fp64 construction) and uses it as the tolerance."""
     scale = "slaney" if naf_mode else "htk"
     n_freqs = n_fft // 2 + 1
-    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
-    m_pts = torch.linspace(_hz_to_mel(f_min, scale), _hz_to_mel(f_max, scale), n_mels + 2)
-    f_pts = _mel_to_hz(m_pts, scale)
-    f_diff = f_pts[1:] - f_pts[:-1]
-    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
-    down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
-    up = slopes[:, 2:] / f_diff[1:]
-    fb = torch.max(torch.zeros(1), torch.min(down, up))
-    if naf_mode:
-        enorm = 2.0 / (f_pts[2:n_mels + 2] - f_pts[:n_mels])
-        fb = fb * enorm.unsqueeze(0)
-    return fb.to(torch.float32)
+    lo_mel, hi_mel = _hz_to_mel(float(f_min), scale), _hz_to_mel(float(f_max), scale)
+    edges = [_mel_to_hz(lo_mel + (hi_mel - lo_mel) * j / (n_mels + 1), scale) for j in range(n_mels + 2)]
+    fb = np.zeros((n_freqs, n_mels), dtype=np.float64)
+    step = (sample_rate // 2) / (n_freqs - 1)
+    for m in range(n_mels):
+        left, centre, right = edges[m], edges[m + 1], edges[m + 2]
+        for k in range(int(math.floor(left / step)), min(int(math.ceil(right / step)) + 1, n_freqs)):
+            f = k * step
+            if left < f < right:
+                fb[k, m] = min((f - left) / (centre - left), (right - f) / (right - centre))
+        if naf_mode:
+            fb[:, m] *= 2.0 / (right - left)
+    return torch.from_numpy(fb.astype(np.float32))
 
 
 def melspec(x, params):

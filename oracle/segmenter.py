@@ -21,13 +21,13 @@ def read_wav_int16(path):
     return pcm, sr
 
 
-def pcm_to_mono(pcm, file_sr=None, sr=None):
+def pcm_to_mono(pcm, file_sr=None, sr=None, resample_table=None):
     """int16[n, ch] -> float32[n]: scale 1/32768 in fp32 (musicdata.py:48), resampling when the file's rate is not the
     model's (musicdata.py:28-65), fake-stereo fix (musicdata.py:74-79), channel mean (musicdata.py:80)."""
     x = np.multiply(pcm, 1 / 32768, dtype=np.float32).T.copy()  # [ch, n]
     if file_sr is not None and sr is not None and file_sr != sr:
         from . import resample
-        x = np.ascontiguousarray(resample.resample_chunked(x, file_sr, sr))
+        x = np.ascontiguousarray(resample.resample_chunked(x, file_sr, sr, resample_table))
     if x.shape[0] == 2:
         pow1 = np.mean((x[0] - x[1]) ** 2, dtype=np.float32)
         pow2 = np.mean((x[0] + x[1]) ** 2, dtype=np.float32)

@@ -60,13 +60,25 @@ def test_product_never_imports_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
 
 
-def test_host_melbank_matches_oracle_restatement():
+def test_host_melbank_vs_independent_float64_statement():
+    """The product builds the bank the way torchaudio does (vectorised fp32 torch ops); the oracle states the same bank
+    from the published definition, filter by filter in float64.  Two independent texts: same support, values within the
+    fp32-vs-fp64 construction gap -- measured 3.83e-5 (htk, peak 1) and 1.5e-6 (slaney-normalised, peak 0.126), i.e. what
+    SURVEY 8a2 probed against transformers' float64 bank (3.8e-5)."""
     from oracle import melspec as om
     from pfann_amd.engine import mel_filterbank
-    for naf in (False, True):
+    for naf, tol in ((False, 4.5e-5), (True, 2e-6)):
         a = mel_filterbank(8000, 1024, 256, 300, 4000, naf).numpy()
         b = om.mel_filterbank(8000, 1024, 256, 300, 4000, naf).numpy()
-        assert np.array_equal(a, b)
+        assert a.shape == b.shape == (513, 256)
+        assert np.array_equal(a > 0, b > 0)
+        gap = np.abs(a.astype(np.float64) - b).max()
+        print("mel bank naf=%s: fp32-torch vs fp64-definition gap %.3e" % (naf, gap))
+        assert gap < tol
+    # another geometry (96 filters on a 512-point FFT)
+    a = mel_filterbank(8000, 512, 96, 300, 4000, False).numpy()
+    b = om.mel_filterbank(8000, 512, 96, 300, 4000, False).numpy()
+    assert np.array_equal(a > 0, b > 0) and np.abs(a - b).max() < 4.5e-5
 
 
 def test_musicdata_mirror_matches_reference_golden(tmp_path):
@@ -286,15 +298,22 @@ def test_torch_synth_generators_are_pure_functions_of_ids():
     assert diff == ["g.linear2.bias"]
 
 
-def test_resample_host_tables_match_the_oracle_restatement():
-    """pfann_amd/resample.py (what the device kernel is fed) against oracle/resample.py: filter table bit-identical, the
-    same pieces."""
+def test_resample_host_tables_vs_independent_float64_statement():
+    """pfann_amd/resample.py (what the device kernel is fed; fp32 torch ops in julius' order) against oracle/resample.py
+    (float64 numpy from the formula): same geometry, every phase sums to 1, taps within the measured fp32-vs-fp64 gap
+    (worst 1.4e-5 at 11025 -> 8000 Hz, where fp32 rounds the sinc argument of far taps), a 1 kHz tone resampled through
+    both tables within 1.5e-5 (measured 7.9e-6 at 11025 Hz); and the same minute-wise pieces."""
     from oracle import resample as R
     from pfann_amd import resample as P
     for old, new in ((44100, 8000), (16000, 8000), (11025, 8000), (48000, 8000), (22050, 8000), (7000, 8000)):
         tab, o, n, width = P.filter_table(old, new)
         k, w = R.kernels(old, new)
-        assert (o, n) == R.reduced(old, new) and width == w and np.array_equal(tab, k.numpy())
+        assert (o, n) == R.reduced(old, new) and width == w and tab.shape == tuple(k.shape)
+        gap = np.abs(tab.astype(np.float64) - k.numpy()).max()
+        assert gap < 2e-5, (old, gap)
+        assert np.abs(tab.astype(np.float64).sum(1) - 1).max() < 1e-6 and np.abs(k.numpy().astype(np.float64).sum(1) - 1).max() < 1e-6
+        tone = (0.5 * np.sin(2 * np.pi * 1000.0 * np.arange(old) / old)).astype(np.float32)[None]
+        assert np.abs(R.resample_frac(tone, old, new) - R.resample_frac(tone, old, new, tab)).max() < 1.5e-5
         for n_in in (1, 999, old, old * 60 - 1, old * 60, old * 61 + 17, old * 125, old * 119 + 1):
             plan, n_out = P.piece_plan(n_in, old, new)
             ref = R.chunk_plan(n_in, old, new)
