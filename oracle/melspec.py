@@ -62,8 +62,11 @@ def mel_filterbank(sample_rate, n_fft, n_mels, f_min, f_max, naf_mode=False):
     return torch.from_numpy(fb.astype(np.float32))
 
 
-def melspec(x, params):
-    """x float32 [B, L] (numpy or torch) -> numpy float32 [B, n_mels, 1 + L//hop]."""
+def melspec(x, params, bank=None):
+    """x float32 [B, L] (numpy or torch) -> numpy float32 [B, n_mels, 1 + L//hop].  bank: a filter bank
+    float32 [n_freqs, n_mels] to use instead of mel_filterbank() -- the device-kernel parity tests hand in the bank the
+    kernel was given (so that they check the STFT / mel / log arithmetic to fp32 rounding); how far that bank is from
+    this module's float64 statement is bounded separately (tests/test_host.py)."""
     x = torch.as_tensor(np.asarray(x, dtype=np.float32))
     naf = params.get("naf_mode", False)
     mel_log = params.get("mel_log", "log")
@@ -77,7 +80,7 @@ def melspec(x, params):
                       normalized=False, onesided=True, return_complex=True)
     spec = spec.abs().pow(1.0 if naf else 2.0)                      # melspec.py:27
     fb = mel_filterbank(params["sample_rate"], n_fft, params["n_mels"],
-                        params["f_min"], params["f_max"], naf)
+                        params["f_min"], params["f_max"], naf) if bank is None else torch.as_tensor(np.asarray(bank, np.float32))
     mel = torch.matmul(spec.transpose(-1, -2), fb).transpose(-1, -2)
     mel = mel + (0.06 if naf else 1e-8)                             # melspec.py:38-41
     if mel_log == "log10":
@@ -89,7 +92,7 @@ def melspec(x, params):
     return mel.numpy()
 
 
-def melspec_f64(x, params):
+def melspec_f64(x, params, bank=None):
     """Independent float64 check of the default mode (explicit frame gather + numpy rfft);
     used only to size the fp32 error of melspec() and of the HIP kernel."""
     x = np.asarray(x, dtype=np.float64)
@@ -104,7 +107,7 @@ def melspec_f64(x, params):
     idx = np.where(idx > L - 1, 2 * (L - 1) - idx, idx)
     frames = x[..., idx] * win
     power = np.abs(np.fft.rfft(frames, axis=-1)) ** 2              # [B, frames, bins]
-    fb = mel_filterbank(params["sample_rate"], n_fft, params["n_mels"],
-                        params["f_min"], params["f_max"], False).double().numpy()
+    fb = (mel_filterbank(params["sample_rate"], n_fft, params["n_mels"], params["f_min"], params["f_max"], False)
+          if bank is None else torch.as_tensor(np.asarray(bank, np.float32))).double().numpy()
     mel = np.einsum("...tk,km->...mt", power, fb)
     return np.log(mel + 1e-8)

@@ -79,6 +79,8 @@ struct pfann_ctx {
     hipStream_t side[8] = {};
     hipEvent_t ev_fork = nullptr, ev_join[8] = {};
     float *part[2] = {nullptr, nullptr};
+    float *splitk = nullptr;        // partial tiles of the split-K GEMMs (small batches), allocated on first use
+    size_t splitk_bytes = 0;
     float *stats = nullptr;         // [max_batch][2] (mean, rstd) of the current GEMM input
     int64_t part_slots = 0;         // per sample
     bool keep = false;
@@ -199,7 +201,7 @@ void pfann_destroy(pfann_ctx *c) {
         if (c->sub[i].ln_b) (void)hipFree(c->sub[i].ln_b);
         if (c->dbg[i]) (void)hipFree(c->dbg[i]);
     }
-    float *ptrs[] = {c->g_w1, c->g_b1, c->g_w2, c->g_b2, c->buf[0], c->buf[1], c->part[0], c->part[1], c->stats, c->mel_buf, c->mel.window,
+    float *ptrs[] = {c->g_w1, c->g_b1, c->g_w2, c->g_b2, c->buf[0], c->buf[1], c->part[0], c->part[1], c->splitk, c->stats, c->mel_buf, c->mel.window,
                      c->mel.fb_val, c->dbg_tmp};
     for (float *p : ptrs) if (p) (void)hipFree(p);
     if (c->mel.twiddle) (void)hipFree(c->mel.twiddle);
@@ -392,6 +394,17 @@ static int encode_chunk_fused(pfann_ctx *c, const float *mel, int64_t B, float *
     // only when verification taps are requested.
     const bool fold_first = !c->keep && c->sub[1].axis == 1 && c->sub[0].co <= 256 &&
                             getenv("PFANN_NO_FOLD_FIRST") == nullptr;
+    if (B <= 64 && c->splitk == nullptr) {       // 64 segments x the largest split layer's [n_splits][rows][N] partials
+        size_t need = 0;
+        for (int i = 1; i < 16; ++i) {
+            const SubLayer &L = c->sub[i];
+            if (!L.depthwise && L.ci % 32 == 0)
+                need = std::max(need, (size_t)((3 * L.ci / 32 + 3) / 4) * 64 * L.Fo * L.To * L.co * sizeof(float));
+        }
+        need = std::min<size_t>(need, (size_t)64 << 20);
+        if (need && hipMalloc(&c->splitk, need) == hipSuccess) c->splitk_bytes = need;
+        else c->splitk = nullptr;
+    }
     if (fold_first && g.relu_after_bn && (int)c->w1_host.size() == 3 * c->sub[0].co && (int)c->b1_host.size() == c->sub[0].co) {
         if (!c->gram_ready) build_gram(c);
         if (launch_conv_first_gram_stats(c->sub[0], mel, part[0], B, c->gram, s)) return -1;
@@ -400,13 +413,16 @@ static int encode_chunk_fused(pfann_ctx *c, const float *mel, int64_t B, float *
     }
     int P = fused_out_slots(c->sub[0], B);
     if (c->keep && keep_tap_fused(c, 0, buf[0], part[0], P, B, s)) return -1;
+    int stats_final = 0;             // c->stats already holds (mean, rstd) of the next layer's input (split-K reduction)
     for (int i = 1; i < 16; ++i) {
         const bool first = fold_first && i == 1;
         if (c->sub[i].depthwise) {
+            stats_final = 0;
             if (launch_conv_dw_ln(c->sub[i], c->sub[i - 1], first ? mel : buf[(i - 1) & 1], part[(i - 1) & 1], P, c->stats + slot0 * 2,
                                   buf[i & 1], part[i & 1], B, g.activation, g.relu_after_bn, first ? &c->sub[0] : nullptr, s)) return -1;
         } else if (launch_conv_gemm_ln(c->sub[i], c->sub[i - 1], first ? mel : buf[(i - 1) & 1], part[(i - 1) & 1], P, c->stats + slot0 * 2, buf[i & 1],
-                                part[i & 1], B, g.activation, g.relu_after_bn, first ? &c->sub[0] : nullptr, c->precision, s)) return -1;
+                                part[i & 1], B, g.activation, g.relu_after_bn, first ? &c->sub[0] : nullptr, c->precision, s,
+                                c->n_streams == 1 || B < 128 ? c->splitk : nullptr, c->splitk_bytes, &stats_final)) return -1;
         P = fused_out_slots(c->sub[i], B);
         if (c->keep && keep_tap_fused(c, i, buf[i & 1], part[i & 1], P, B, s)) return -1;
     }

@@ -54,6 +54,8 @@ struct FusedGemmParams {
     // FIRST variant: the input is the C_in = 1 first conv computed on the fly from the log-mel
     const float *w1, *b1;        // first conv weights [3][Ci] and bias [Ci]
     int T0, s1, pad1;            // mel frames, first conv stride and left pad along T
+    // SPLITK variant: the grid is blocks_mn x n_splits; split ks covers k in [k_begin + ks*k_chunk, ... + k_chunk)
+    int blocks_mn, k_chunk;
 };
 
 // RELU_BN = true: the default model (ReLU applied after LayerNorm) with the activation folded
@@ -67,7 +69,11 @@ struct FusedGemmParams {
 // SPLIT: operands as two fp16 terms each (x = hi + lo to 2^-22 relative), three fp16 MFMAs per product
 // term (hi*hi + lo*hi + hi*lo, fp32 accumulate) instead of one fp32 MFMA: ~fp32 accuracy at 3/16 of the
 // MFMA cycles.  Opt-in (pfann_set_encoder_precision); the default path is the exact fp32 one.
-template <int BM, int BN, int WM, int WN, bool RELU_BN, bool FIRST, bool UNI, int BK = 32, bool SPLIT = false>
+// SPLITK: small batches (one query = 19 segments): the deep layers have a handful of output tiles and K loops of up to
+// 96 K-tiles, a serial MFMA chain of 70 us on 16 of 256 CUs.  The K range is cut into chunks of <= 8 K-tiles, one
+// workgroup each; a workgroup stores its raw partial tile (no bias, no statistics) to p.y[ks][M][N] and
+// splitk_reduce_ln_kernel adds the chunks in a FIXED order (deterministic), the bias, and takes the statistics.
+template <int BM, int BN, int WM, int WN, bool RELU_BN, bool FIRST, bool UNI, int BK = 32, bool SPLIT = false, bool SPLITK = false>
 __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM / WM) * (BN / WN) == 8 ? 4 : (BK == 16 ? 3 : 1))
 void conv_gemm_ln_kernel(FusedGemmParams p) {
     constexpr int LDK = BK + 4, TPR = BK / 4;         // TPR loader threads per tile row (4 floats each)
@@ -91,7 +97,11 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
                  "s"(p.dv_tile.mul), "s"(p.dv_tile.shift), "s"(p.dv_n.mul), "s"(p.dv_n.shift));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    int L = xcd_remap(blockIdx.x, gridDim.x);
+    int ks = 0;
+    if (SPLITK) { ks = L / p.blocks_mn; L -= ks * p.blocks_mn; }
+    const int k_begin = SPLITK ? p.k_begin + ks * p.k_chunk : p.k_begin;
+    const int k_end = SPLITK ? (p.k_end < k_begin + p.k_chunk ? p.k_end : k_begin + p.k_chunk) : p.k_end;
     const int rps = p.rows_per_sample;
     int mt, nt;
     if (rps >= 2 * BM) {
@@ -177,7 +187,7 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
         vb[j] = n < p.N ? (unsigned)n * (unsigned)p.K * 4u + (UNI ? (unsigned)col4 * 16u : 0u) : BUF_OOB;
     }
     const int tap_stride = (int)p.tap_stride;
-    int kap = p.k_begin + (UNI ? 0 : col4 * 4);          // UNI: uniform (scalar) cursor
+    int kap = k_begin + (UNI ? 0 : col4 * 4);            // UNI: uniform (scalar) cursor
     int tap = kap / p.Ci, c = kap - tap * p.Ci;
     // byte offsets of this thread's operands for filter tap `tp`, channel offset `cc`
     auto set_offsets = [&](int tp, int cc, bool kok) {
@@ -234,7 +244,7 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
             so_c = c * 4;
             so_k = kap * 4;
         } else {
-            kok = kap < p.k_end;
+            kok = kap < k_end;
             set_offsets(tap, c, kok);
         }
 #pragma unroll
@@ -242,7 +252,7 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
             if (FIRST) {
                 // the three log-mel taps of a row do not depend on the channel: with a uniform cursor they
                 // are fetched on the first K-tile of each filter tap only and stay in S.ra for the others
-                if (!UNI || c == 0 || kap == p.k_begin) {
+                if (!UNI || c == 0 || kap == k_begin) {
 #pragma unroll
                     for (int t1 = 0; t1 < NA; ++t1) S.ra[0][i][t1] = buf_load1(srd_a, va[i][t1]);
                 }
@@ -349,7 +359,7 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // LDS double buffer, one barrier per K-tile (see csrc/encoder.hip for the schedule)
-    const int nk = (p.k_end - p.k_begin + BK - 1) / BK;
+    const int nk = (k_end - k_begin + BK - 1) / BK;
     const int l31 = lane & 31, lhalf = lane >> 5;
     Stage S;
     if (EA) { set_offsets_A(tapA); load_A(S, 0); }
@@ -482,7 +492,8 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
     // m = lane&31 and the columns n = 8g + 4*(lane>>5) + e for register 4g + e: four consecutive channels
     // per register quad, stored with one dwordx4 (the texture addresser takes as long for a 64-lane dword
     // store as for a dwordx4 one; scalar stores made the epilogue 6 % of the kernel).
-    const __amdgpu_buffer_rsrc_t srd_y = make_srd(p.y + (int64_t)m0 * p.N, (unsigned long long)(p.M - m0) * p.N * 4ull);
+    const __amdgpu_buffer_rsrc_t srd_y = make_srd(p.y + (SPLITK ? (int64_t)ks * p.M * p.N : 0) + (int64_t)m0 * p.N,
+                                                  (unsigned long long)(p.M - m0) * p.N * 4ull);
     const __amdgpu_buffer_rsrc_t srd_bias = make_srd(p.bias, (unsigned long long)p.N * 4ull);
     // The output tile goes through LDS so that it reaches memory as whole rows: straight from the accumulators a store
     // instruction covers 32 rows x 32 B (a quarter cache line per row, four waves completing each 512 B row at different
@@ -509,7 +520,7 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int n = n0 + wn * WN + j * 32 + 8 * g + 4 * lhalf;
-            bias4[j][g] = buf_load4(srd_bias, n < p.N ? (unsigned)n * 4u : BUF_OOB);
+            bias4[j][g] = buf_load4(srd_bias, (!SPLITK && n < p.N) ? (unsigned)n * 4u : BUF_OOB);     // SPLITK: raw partial sums
         }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -526,7 +537,7 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float z = SPLIT ? fmaf(acc[i][j][4 * g + e], p.w_inv_scale, b4v[e]) : acc[i][j][4 * g + e] + b4v[e];
-                    if (!RELU_BN && !p.after_bn) z = act_fn(z, p.act);
+                    if (!SPLITK && !RELU_BN && !p.after_bn) z = act_fn(z, p.act);
                     a1 += z;
                     a2 = fmaf(z, z, a2);
                     z4[e] = z;
@@ -553,6 +564,7 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
             buf_store4(srd_y, nb + (unsigned)row * rowbytes, *reinterpret_cast<const f32x4 *>(&Cs[row * LDC + cl * 4]));
         }
     }
+    if (SPLITK) return;                  // statistics come from splitk_reduce_ln_kernel
     // rows -> statistics groups of G rows (one per sample touched), in a fixed order: thread r owns row r
     float t1 = 0.f, t2 = 0.f;
     if (tid < BM) {
@@ -598,6 +610,47 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float *__restric
     }
 }
 
+// Second half of a SPLITK layer: one workgroup per sample.  z = PRE(bias + sum_s partial[s]) in the order s = 0, 1, ...
+// (deterministic), written once; the sample's LayerNorm partial (sum, sum of squares) reduced in a fixed order into slot 0
+// of its partial row (the other slots zeroed), which is what the consumer's ln_finalize_kernel expects.
+__global__ __launch_bounds__(1024) void splitk_reduce_ln_kernel(const float *__restrict__ part_c, int n_splits, int64_t MN,
+                                                                const float *__restrict__ bias, int N, int n_el,
+                                                                float *__restrict__ y, float *__restrict__ out_part, int P,
+                                                                int act, int after_bn, float *__restrict__ stats, double inv_n) {
+    __shared__ float red[2][16];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int64_t base = (int64_t)b * n_el;
+    float s1 = 0.f, s2 = 0.f;
+    for (int e = tid * 4; e < n_el; e += 4096) {          // N % 4 == 0: a float4 never straddles two rows
+        f32x4 z = *reinterpret_cast<const f32x4 *>(bias + (e % N));
+        for (int s = 0; s < n_splits; ++s) z += *reinterpret_cast<const f32x4 *>(part_c + (int64_t)s * MN + base + e);
+        if (!after_bn) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) z[q] = act_fn(z[q], act);
+        }
+        *reinterpret_cast<f32x4 *>(y + base + e) = z;
+        s1 += (z[0] + z[1]) + (z[2] + z[3]);
+        s2 += (z[0] * z[0] + z[1] * z[1]) + (z[2] * z[2] + z[3] * z[3]);
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s1; red[1][tid >> 6] = s2; }
+    __syncthreads();
+    if (tid == 0) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int w = 0; w < 16; ++w) { t1 += red[0][w]; t2 += red[1][w]; }
+        float *o = out_part + (int64_t)b * P * 2;
+        o[0] = t1; o[1] = t2;
+        for (int i = 1; i < P; ++i) { o[2 * i] = 0.f; o[2 * i + 1] = 0.f; }
+        // ... and (mean, rstd) exactly as ln_finalize_kernel would derive them from that partial row, so the consumer
+        // can skip its ln_finalize launch
+        const double mean = (double)t1 * inv_n;
+        double var = (double)t2 * inv_n - mean * mean;
+        if (var < 0) var = 0;
+        stats[2 * b] = (float)mean;
+        stats[2 * b + 1] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+}
+
 static void live_taps(const SubLayer &L, int in_len, int &k_begin, int &k_end) {
     const int out_len = L.axis == 0 ? L.To : L.Fo;
     int lo = 3, hi = -1;
@@ -614,7 +667,8 @@ static void live_taps(const SubLayer &L, int in_len, int &k_begin, int &k_end) {
 static int gemm_tile(const SubLayer &L, int64_t B) {
     const int64_t M = B * L.Fo * L.To;
     const int64_t blocks128 = (int64_t)cdiv(M, 128) * cdiv(L.co, 128);
-    return (L.co >= 128 && blocks128 >= 512 && L.ci % 32 == 0) ? 128 : 64;
+    static const int64_t min128 = getenv("PFANN_TILE128_MIN") ? atoll(getenv("PFANN_TILE128_MIN")) : 512;
+    return (L.co >= 128 && blocks128 >= min128 && L.ci % 32 == 0) ? 128 : 64;
 }
 
 int fused_out_slots(const SubLayer &L, int64_t B) {
@@ -641,8 +695,14 @@ static int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
 
 int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, const float *in_part, int in_P,
                         float *in_stats, float *y, float *out_part, int64_t B, int act, int after_bn,
-                        const SubLayer *Lfirst, int precision, hipStream_t s) {
+                        const SubLayer *Lfirst, int precision, hipStream_t s, float *splitk_scratch, size_t splitk_bytes,
+                        int *stats_final) {
+    // stats_final (in/out, may be null): in: in_stats already holds (mean, rstd) of the input (written by the previous
+    // layer's split-K reduction) -> no ln_finalize launch; out: whether this layer left its OUTPUT statistics there.
+    const bool in_final = stats_final != nullptr && *stats_final != 0;
+    if (stats_final) *stats_final = 0;
     FusedGemmParams p;
+    p.blocks_mn = 0; p.k_chunk = 0;
     if (B * L.Fo * L.To >= (int64_t)0x7FFF0000) { set_error("conv_gemm_ln: batch too large"); return -1; }
     p.x = x; p.w = L.w; p.bias = L.bias; p.y = y;
     p.w_hi = L.w_hi; p.w_lo = L.w_lo; p.w_inv_scale = L.w_inv_scale;
@@ -666,7 +726,7 @@ int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, 
         p.w1 = Lfirst->w; p.b1 = Lfirst->bias;
         p.T0 = Lfirst->T; p.s1 = Lfirst->stride; p.pad1 = Lfirst->pad_lo;
     }
-    {
+    if (!in_final) {
         ProfScope ps("ln_finalize", s);
         PF_LAUNCH(ln_finalize_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, s, in_part, in_P, 1.0 / (double)p.in_elems,
                   in_stats, (int)B);
@@ -710,6 +770,32 @@ int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, 
         p.dv_n = make_fastdiv(p.n_tiles_n); p.dv_tile = make_fastdiv(64 * p.n_tiles_n);
         p.dv_group = make_fastdiv(64 * (p.rows_per_sample >= 64 ? p.rows_per_sample / 64 : 1) * p.n_tiles_n);
         const int64_t blocks = (int64_t)cdiv(p.M, 64) * p.n_tiles_n;
+        // split-K for launches that cannot fill the chip and have a long K loop (the one-query regime): chunks of 8
+        // K-tiles (measured on one 19-segment query: 12 -> 344 us, 8 -> 323, 6 -> 323, 4 -> 331 for the whole embed).  The cut depends on the layer only, never on B, so results do not depend on the batch size as long as
+        // the batch stays in this regime.
+        const int nk = (p.k_end - p.k_begin) / 32;
+        static const int chunk_kt = getenv("PFANN_SPLITK_CHUNK") ? atoi(getenv("PFANN_SPLITK_CHUNK")) : 8;
+        const int n_splits = (nk + chunk_kt - 1) / chunk_kt;
+        static const bool no_splitk = getenv("PFANN_NO_SPLITK") != nullptr;
+        if (uni && !first && !no_splitk && B <= 64 && blocks < 192 && nk >= 16 && chunk_kt > 0 && (p.k_end - p.k_begin) % 32 == 0 && n_splits > 1 &&
+            splitk_scratch != nullptr && (size_t)n_splits * p.M * p.N * sizeof(float) <= splitk_bytes) {
+            p.blocks_mn = (int)blocks;
+            p.k_chunk = chunk_kt * 32;
+            p.y = splitk_scratch;
+            {
+                ProfScope ps(layer_tag("conv_gemm_ln_64"), s, flops);
+                const dim3 g((unsigned)(blocks * n_splits)), t(256);
+                if (relu_bn) PF_LAUNCH((conv_gemm_ln_kernel<64, 64, 32, 32, true, false, true, 32, false, true>), g, t, 0, s, p);
+                else PF_LAUNCH((conv_gemm_ln_kernel<64, 64, 32, 32, false, false, true, 32, false, true>), g, t, 0, s, p);
+            }
+            ProfScope ps2("splitk_reduce_ln", s);
+            PF_LAUNCH(splitk_reduce_ln_kernel, dim3((unsigned)B), dim3(1024), 0, s, splitk_scratch, n_splits, (int64_t)p.M * p.N,
+                      L.bias, p.N, p.rows_per_sample * p.N, y, out_part, p.out_P, act, after_bn, in_stats,
+                      1.0 / ((double)p.rows_per_sample * p.N));
+            PF_HIP(hipGetLastError());
+            if (stats_final) *stats_final = 1;
+            return 0;
+        }
         ProfScope ps(layer_tag("conv_gemm_ln_64"), s, flops);
         if (uni) {
             constexpr bool UNI_ = true;
@@ -1099,6 +1185,64 @@ __global__ void myg_ln_kernel(const float *__restrict__ z, const float *__restri
         if (g < d && seg0 + sg < B) emb[(seg0 + sg) * d + g] = y[sg];
 }
 
+// Small batches (one query): the kernel above walks a thread's u hidden units one after the other, u dependent
+// round trips to the weights (39 us for 19 segments).  Here one workgroup per segment spreads the d*u hidden units
+// over all its threads (every weight row is one independent load) and leaves them in LDS; thread g then adds its u
+// terms IN THE SAME ORDER as myg_ln_kernel does, so the two kernels give bit-identical embeddings.
+__global__ __launch_bounds__(1024) void myg_ln_small_kernel(const float *__restrict__ z, const float *__restrict__ part, int P,
+                                                            const float *__restrict__ lw, const float *__restrict__ lb, int act,
+                                                            int after_bn, const float *__restrict__ w1, const float *__restrict__ b1,
+                                                            const float *__restrict__ w2, const float *__restrict__ b2, int d, int u,
+                                                            int v, float *__restrict__ emb, int normalize) {
+    extern __shared__ float sm[];               // xn[h] | hid[d*u]
+    __shared__ float stat[2];
+    __shared__ float red[16];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int h = d * v;
+    const int64_t b = blockIdx.x;
+    float *xn = sm, *hid = sm + h;
+    if (tid == 0) {
+        const float *pp = part + b * P * 2;
+        double s1 = 0, s2 = 0;
+        for (int i = 0; i < P; ++i) { s1 += (double)pp[2 * i]; s2 += (double)pp[2 * i + 1]; }
+        const double mean = s1 / h;
+        double var = s2 / h - mean * mean;
+        if (var < 0) var = 0;
+        stat[0] = (float)mean;
+        stat[1] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+    __syncthreads();
+    const float mean = stat[0], rstd = stat[1];
+    for (int e = tid; e < h; e += nt) {
+        float t = (z[b * h + e] - mean) * rstd * lw[e] + lb[e];
+        xn[e] = after_bn ? act_fn(t, act) : t;
+    }
+    __syncthreads();
+    for (int pi = tid; pi < d * u; pi += nt) {              // hidden unit (g, k) = pi
+        const int g = pi / u;
+        const float *wr = w1 + (int64_t)pi * v;
+        float hsum = 0.f;
+        for (int j = 0; j < v; ++j) hsum = fmaf(wr[j], xn[g * v + j], hsum);
+        hsum += b1[pi];
+        hid[pi] = hsum > 0.f ? hsum : expm1f(hsum);
+    }
+    __syncthreads();
+    float y = 0.f;
+    if (tid < d) {
+        for (int k = 0; k < u; ++k) y = fmaf(w2[tid * u + k], hid[tid * u + k], y);
+        y += b2[tid];
+    }
+    if (normalize) {
+        const float ss = wave_sum(tid < d ? y * y : 0.f);
+        if ((tid & 63) == 0 && (tid >> 6) < 16) red[tid >> 6] = ss;
+        __syncthreads();
+        float tot = 0.f;
+        for (int i = 0; i < (d + 63) / 64; ++i) tot += red[i];       // the waves that hold outputs, in order
+        y = y / fmaxf(sqrtf(tot), 1e-12f);
+    }
+    if (tid < d) emb[b * d + tid] = y;
+}
+
 int launch_myg_ln(const SubLayer &Llast, const float *z, const float *part, int P, int act, int after_bn,
                   const float *w1, const float *b1, const float *w2, const float *b2, int d, int u, int v, int64_t B,
                   float *emb, int normalize, hipStream_t s) {
@@ -1106,6 +1250,16 @@ int launch_myg_ln(const SubLayer &Llast, const float *z, const float *part, int 
     const int nt = ((d + 63) / 64) * 64;
     if (nt > 1024) { set_error("MyG: d = %d > 1024 unsupported", d); return -1; }
     ProfScope ps("myg_ln", s);
+    static const bool no_small = getenv("PFANN_NO_SMALL_HEAD") != nullptr;
+    const size_t small_lds = ((size_t)d * v + (size_t)d * u) * sizeof(float);
+    if (B <= 64 && !no_small && small_lds <= 60 * 1024) {
+        int thr = d * u < 1024 ? ((d * u + 63) / 64) * 64 : 1024;
+        if (thr < nt) thr = nt;
+        PF_LAUNCH(myg_ln_small_kernel, dim3((unsigned)B), dim3(thr), small_lds, s, z, part, P, Llast.ln_w, Llast.ln_b, act, after_bn,
+                  w1, b1, w2, b2, d, u, v, emb, normalize);
+        PF_HIP(hipGetLastError());
+        return 0;
+    }
     if (v <= 8)
         PF_LAUNCH((myg_ln_kernel<4, 8>), dim3((unsigned)cdiv(B, 4)), dim3(nt), 0, s, z, part, P, Llast.ln_w, Llast.ln_b, act,
                   after_bn, w1, b1, w2, b2, d, u, v, emb, normalize, B);

@@ -43,7 +43,8 @@ int launch_conv_first_gram_stats(const SubLayer &L, const float *x, float *part,
 // in_stats: workspace for B x (mean, rstd) of the input, filled here from in_part
 int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, const float *in_part, int in_P,
                         float *in_stats, float *y, float *out_part, int64_t B, int act, int after_bn,
-                        const SubLayer *Lfirst, int precision, hipStream_t s);
+                        const SubLayer *Lfirst, int precision, hipStream_t s, float *splitk_scratch = nullptr,
+                        size_t splitk_bytes = 0, int *stats_final = nullptr);
 int launch_conv_dw_ln(const SubLayer &L, const SubLayer &Lin, const float *x, const float *in_part, int in_P, float *in_stats,
                       float *y, float *out_part, int64_t B, int act, int after_bn, const SubLayer *Lfirst, hipStream_t s);
 int launch_ln_apply(const SubLayer &L, const float *z, const float *part, int P, float *out, int64_t B, int act,
@@ -107,6 +108,7 @@ struct RerankArgs {
     int *ncand;             // [nQ] scratch of the phased launch (few queries: scoring spread over the whole GPU)
     int phase;              // 0: whole query in one workgroup; 1: candidates; 2: scores; 3: argmax (1-3 need gkeys)
     pfann_match_result *results; float *song_scores;
+    int dbg;                // PFANN_MATCH_ABLATE bits (timing experiments only; results are garbage): 1 no sort, 2 no lookup, 4 no dedup
 };
 int launch_match(const RerankArgs &a, hipStream_t s);
 int launch_match_pack(const pfann_match_result *res, int64_t nQ, unsigned long long *keys, hipStream_t s);

@@ -39,10 +39,17 @@ __device__ __forceinline__ Cand unpack_cand(int mode, unsigned long long key) {
     return c;
 }
 
+// Thread tid owns the positions i = tid + m*NT.  A compare-exchange distance j < 64 pairs positions of the same 64-aligned
+// group, i.e. two lanes of ONE wave: those steps need no workgroup barrier (a wave's LDS operations execute in order, and
+// within one instruction all 64 lanes read before any of them writes), only the steps with j >= 64 and the hand-over
+// between the two kinds do.  For P = 2048 that is 21 barriers instead of 66 (the one-query matcher spent 30 us of its
+// 74 us candidate phase in them).
 template <int NT>
 __device__ void bitonic_sort_keys(unsigned long long *sk, int P, int tid) {
     for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 32 || j == (k >> 1)) __syncthreads();     // positions written by other waves are read from here on
+            else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             for (int i = tid; i < P; i += NT) {
                 const int ixj = i ^ j;
                 if (ixj > i) {
@@ -51,15 +58,117 @@ __device__ void bitonic_sort_keys(unsigned long long *sk, int P, int tid) {
                     if ((x > y) == up) { sk[i] = y; sk[ixj] = x; }
                 }
             }
-            __syncthreads();
         }
     }
+    __syncthreads();
+}
+
+// ---- candidates (database.py:133-138 / seqscore.cpp:49-60): labels[t][i] -> packed (song, offset, shift) keys in sk[0..P)
+// (SENT for label -1, songs of other shards under only_owned, and the padding up to P).  No trailing barrier.
+template <int NT>
+__device__ void make_candidate_keys(const RerankArgs &a, int64_t q0, int ntot, int P, unsigned long long *sk, long long *s_cpos, int tid) {
+        // song of a label = upper_bound over song_pos: 15+ dependent global loads per label when searched directly
+        // (a third of this phase for one query); the first ~10 levels run on a coarse copy in LDS instead
+        int cshift = 0;
+        while ((a.n_songs >> cshift) > 1023) ++cshift;
+        const int n_coarse = (a.n_songs >> cshift) + 1;
+        for (int i = tid; i < n_coarse; i += NT) s_cpos[i] = a.song_pos[(int64_t)i << cshift];
+        __syncthreads();
+        for (int i = tid; i < P; i += NT) {
+            unsigned long long key = SENT;
+            if (i < ntot) {
+                const int t = i / a.k;
+                const int64_t lab = a.labels[(q0 + t) * a.k + (i - t * a.k)];
+                if (lab >= 0) {
+                    // largest s with song_pos[s] <= lab  (searchsorted side='right' - 1)
+                    int cl = 0, ch = n_coarse;    // coarse: entries before cl are <= lab, from ch on > lab
+                    while (cl < ch) {
+                        const int mid = (cl + ch) >> 1;
+                        if (s_cpos[mid] <= lab) cl = mid + 1; else ch = mid;
+                    }
+                    // song_pos[(cl-1) << cshift] <= lab < song_pos[cl << cshift] (when those exist): the same predicate
+                    // on the narrowed range gives the same answer as on [0, n_songs)
+                    int lo = cl > 0 ? (cl - 1) << cshift : 0;
+                    int hi = min(a.n_songs, cl << cshift);   // song_pos has n_songs+1 entries; search [0, n_songs)
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (a.song_pos[mid] <= lab) lo = mid + 1; else hi = mid;
+                    }
+                    const int song = lo - 1;
+                    const int tim = t / a.fsm, shift = t - tim * a.fsm;
+                    const int off = (int)(lab - a.song_pos[song] - tim);
+                    const bool owned = song >= a.song_lo && song < a.song_hi;
+                    if (song >= 0 && (owned || !a.only_owned)) key = pack_cand(a.mode, song, off, shift);
+                }
+            }
+            sk[i] = key;
+        }
+}
+
+// Phase 1 of the phased launch for a handful of queries, spread over the chip: a bitonic sort of one query's 2048 keys
+// inside ONE workgroup is 66 dependent LDS round trips (53 us of the one-query matcher's 70 us candidate phase, measured
+// by ablation).  A RANK sort has no dependent steps and parallelises over workgroups: each of the gridDim.y workgroups
+// builds all P keys in its LDS (redundantly, in parallel), then ranks its own slice of P / gridDim.y keys against all of
+// them -- rank = #{keys smaller} + #{equal keys at a lower index}, a permutation -- and stores them at their rank in
+// gkeys.  Duplicates are NOT removed here: equal candidates score equal, so the first-wins argmax, the per-song replay
+// and (counted in phase 3) n_cand come out the same.  ncand = number of real (non-sentinel) keys.
+template <int NT>
+__global__ __launch_bounds__(NT) void match_rank_kernel(RerankArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sk_lds[];   // [P] keys
+    __shared__ long long s_cpos[1024];
+    __shared__ int s_rank[128];
+    __shared__ int s_cnt;
+    const int64_t qi = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int64_t q0 = a.qstart[qi];
+    const int qlen = a.qlen[qi];
+    const int ntot = qlen * a.k;
+    int P = 1;
+    while (P < ntot) P <<= 1;
+    const int G = (int)gridDim.y;
+    const int SL = a.pmax / G;                    // slice length when P == pmax; shorter queries use fewer slices
+    if (P > a.pmax) {
+        if (tid == 0 && blockIdx.y == 0) {
+            pfann_match_result r; r.song = -2; r.offset = 0; r.shift = 0; r.n_cand = -1; r.score = -INFINITY; a.results[qi] = r;
+            a.ncand[qi] = -1;
+        }
+        return;
+    }
+    const int slice0 = (int)blockIdx.y * SL;
+    if (slice0 >= P) return;
+    if (tid < 128) s_rank[tid] = 0;
+    if (tid == 0) s_cnt = 0;
+    make_candidate_keys<NT>(a, q0, ntot, P, sk_lds, s_cpos, tid);
+    __syncthreads();
+    if (blockIdx.y == 0) {                        // number of real keys
+        int c = 0;
+        for (int i = tid; i < P; i += NT) c += sk_lds[i] != SENT ? 1 : 0;
+        c = (int)wave_sum((float)c);              // <= 16 per lane, <= 1024 per wave: exact in fp32
+        if ((tid & 63) == 0) atomicAdd(&s_cnt, c);
+    }
+    // thread = (slice key s, partition of the j range): SL <= 128 keys x NT / SL partitions of P * SL / NT positions
+    const int s = tid % SL, part = tid / SL, nparts = NT / SL;
+    const int gi = slice0 + s;
+    const bool live = gi < P;                     // a short query among longer ones: P < SL
+    const unsigned long long K = live ? sk_lds[gi] : SENT;
+    int cnt = 0;
+    if (live)
+        for (int j = part; j < P; j += nparts) {  // every lane of a wave reads the same j: an LDS broadcast
+            const unsigned long long kj = sk_lds[j];
+            cnt += (kj < K || (kj == K && j < gi)) ? 1 : 0;
+        }
+    if (live) atomicAdd(&s_rank[s], cnt);
+    __syncthreads();
+    unsigned long long *gk = a.gkeys + qi * (int64_t)a.pmax;
+    if (tid < SL && slice0 + tid < P) gk[s_rank[tid]] = sk_lds[slice0 + tid];
+    if (blockIdx.y == 0 && tid == 0) a.ncand[qi] = s_cnt;
 }
 
 template <int NT>
 __global__ __launch_bounds__(NT) void match_kernel(RerankArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long sk_lds[];   // [P] keys
     __shared__ int s_nc;
+    __shared__ long long s_cpos[1024];     // every 2^cshift-th entry of song_pos: the first levels of the song lookup
     const int64_t qi = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t q0 = a.qstart[qi];
@@ -83,28 +192,7 @@ __global__ __launch_bounds__(NT) void match_kernel(RerankArgs a) {
 
     int nc;
     if (a.phase <= 1) {
-        // ---- candidates (database.py:133-138 / seqscore.cpp:49-60)
-        for (int i = tid; i < P; i += NT) {
-            unsigned long long key = SENT;
-            if (i < ntot) {
-                const int t = i / a.k;
-                const int64_t lab = a.labels[(q0 + t) * a.k + (i - t * a.k)];
-                if (lab >= 0) {
-                    // largest s with song_pos[s] <= lab  (searchsorted side='right' - 1)
-                    int lo = 0, hi = a.n_songs;   // song_pos has n_songs+1 entries; search [0, n_songs)
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        if (a.song_pos[mid] <= lab) lo = mid + 1; else hi = mid;
-                    }
-                    const int song = lo - 1;
-                    const int tim = t / a.fsm, shift = t - tim * a.fsm;
-                    const int off = (int)(lab - a.song_pos[song] - tim);
-                    const bool owned = song >= a.song_lo && song < a.song_hi;
-                    if (song >= 0 && (owned || !a.only_owned)) key = pack_cand(a.mode, song, off, shift);
-                }
-            }
-            sk[i] = key;
-        }
+        make_candidate_keys<NT>(a, q0, ntot, P, sk, s_cpos, tid);
         __syncthreads();
         // ---- sort ascending (== lexicographic candidate order of the reference)
         bitonic_sort_keys<NT>(sk, P, tid);
@@ -243,6 +331,17 @@ __global__ __launch_bounds__(NT) void match_kernel(RerankArgs a) {
     }
     if (a.phase == 2) return;
     __syncthreads();
+    int n_unique = nc;
+    if (a.phase == 3) {                  // the rank-sorted list of the phased launch keeps its duplicates: count the distinct keys
+        if (tid == 0) s_nc = 0;
+        __syncthreads();
+        int u = 0;
+        for (int c = tid; c < nc; c += NT) u += (c == 0 || sk[c] != sk[c - 1]) ? 1 : 0;
+        u = (int)wave_sum((float)u);
+        if (lane == 0 && u) atomicAdd(&s_nc, u);
+        __syncthreads();
+        n_unique = s_nc;
+    }
 
     // ---- argmax, first-wins in candidate order (database.py:158-163 / seqscore.cpp:115-124)
     if (tid < 64) {
@@ -267,7 +366,7 @@ __global__ __launch_bounds__(NT) void match_kernel(RerankArgs a) {
         }
         if (lane == 0) {
             pfann_match_result r;
-            r.n_cand = nc;
+            r.n_cand = n_unique;
             if (nc > 0 && besti != 0x7FFFFFFF) {
                 const Cand cd = unpack_cand(a.mode, sk[besti]);
                 r.song = cd.song; r.offset = cd.off; r.shift = cd.shift; r.score = best;
@@ -373,7 +472,9 @@ int launch_match_pick(const unsigned long long *keys, int G, int64_t nQ, pfann_m
     return 0;
 }
 
-int launch_match(const RerankArgs &a, hipStream_t s) {
+int launch_match(const RerankArgs &a_in, hipStream_t s) {
+    RerankArgs a = a_in;
+    a.dbg = 0;
     if (a.nQ <= 0) return 0;
     if (a.fsm < 1 || a.fsm > 32) { set_error("match: frame_shift_mul=%d outside 1..32", a.fsm); return -1; }
     if (a.n_songs >= (1 << 30)) { set_error("match: too many songs"); return -1; }
@@ -382,10 +483,31 @@ int launch_match(const RerankArgs &a, hipStream_t s) {
         set_error("match: max_qlen*top_k needs %d candidate slots > %d and no scratch was given", a.pmax, MAXC);
         return -1;
     }
+    static const bool per_phase = getenv("PFANN_PROF_LAYERS") != nullptr;
+    static const bool no_rank = getenv("PFANN_NO_RANK_SORT") != nullptr;
+    // rank-sorted phase 1 (match_rank_kernel): 32 workgroups per query, slices of pmax / 32 <= 128 keys
+    const bool rank_p1 = a.phase == 1 && !no_rank && a.pmax >= 1024 && a.pmax <= 4096;
+    if (a.phase == 1 && per_phase) {     // tuning aid: one profiling tag per phase
+        RerankArgs b = a;
+        { ProfScope p1("seq_match p1 candidates", s);
+          if (rank_p1) PF_LAUNCH(match_rank_kernel<1024>, dim3((unsigned)a.nQ, 32), dim3(1024), (size_t)a.pmax * 8, s, b);
+          else PF_LAUNCH(match_kernel<1024>, dim3((unsigned)a.nQ), dim3(1024), a.pmax <= MAXC ? (size_t)a.pmax * 12 : 64, s, b); }
+        b.phase = 2;
+        const unsigned chunks = (unsigned)std::min<int64_t>((a.pmax + 15) / 16, std::max<int64_t>(1, 2048 / a.nQ));
+        { ProfScope p2("seq_match p2 scores", s);
+          PF_LAUNCH(match_kernel<1024>, dim3((unsigned)a.nQ, chunks), dim3(1024), 64, s, b); }
+        b.phase = 3;
+        { ProfScope p3("seq_match p3 argmax", s);
+          PF_LAUNCH(match_kernel<1024>, dim3((unsigned)a.nQ), dim3(1024), 64, s, b); }
+        PF_HIP(hipGetLastError());
+        return 0;
+    }
     ProfScope ps("seq_match", s);
     if (a.phase == 1) {
         // few queries: candidates (one workgroup per query) -> scores (all CUs) -> argmax
         RerankArgs b = a;
+        if (rank_p1) PF_LAUNCH(match_rank_kernel<1024>, dim3((unsigned)a.nQ, 32), dim3(1024), (size_t)a.pmax * 8, s, b);
+        else
         PF_LAUNCH(match_kernel<1024>, dim3((unsigned)a.nQ), dim3(1024), a.pmax <= MAXC ? (size_t)a.pmax * 12 : 64, s, b);
         b.phase = 2;
         const unsigned chunks = (unsigned)std::min<int64_t>((a.pmax + 15) / 16, std::max<int64_t>(1, 2048 / a.nQ));

