@@ -44,6 +44,8 @@ class DeviceIndex:
         self.ntotal = 0
         self.label_base = 0
         self.n_songs = 0
+        self._small_args = {}
+        self._host_res = None
 
     def __del__(self):
         h, self.handle = getattr(self, "handle", None), None
@@ -164,12 +166,34 @@ class DeviceIndex:
         tensor of results --, song_scores or None)."""
         q = q.to(self.device, torch.float32).contiguous()
         labels = labels.to(self.device, torch.int64).contiguous()
-        qs = _l.upload_async(qstart, self.device, np.int64)
-        ql_np = np.asarray(qlen, dtype=np.int32)
-        ql = _l.upload_async(ql_np, self.device, np.int32)
+        qs_np = np.ascontiguousarray(qstart, dtype=np.int64)
+        ql_np = np.ascontiguousarray(qlen, dtype=np.int32)
         nQ = int(ql_np.shape[0])
+        if nQ <= 4:
+            # the one-query regime calls with the same tiny (qstart, qlen) over and over: keep their device copies
+            key = (qs_np.tobytes(), ql_np.tobytes())
+            hit = self._small_args.get(key)
+            if hit is None:
+                if len(self._small_args) > 64:
+                    self._small_args.clear()
+                hit = (_l.upload_async(qs_np, self.device, np.int64), _l.upload_async(ql_np, self.device, np.int32))
+                self._small_args[key] = hit
+            qs, ql = hit
+        else:
+            qs = _l.upload_async(qs_np, self.device, np.int64)
+            ql = _l.upload_async(ql_np, self.device, np.int32)
         k = labels.shape[1]
-        res = torch.empty((nQ, ctypes.sizeof(_l.MatchResult)), device=self.device, dtype=torch.uint8)
+        rsz = ctypes.sizeof(_l.MatchResult)
+        host_res = None
+        if to_host and 0 < nQ <= 64:
+            # few queries: the kernel writes its 24-byte results straight into pinned (device-mapped) host memory, so the
+            # answer is on the host when the stream has drained -- no device-to-host copy call on the latency path
+            if self._host_res is None:
+                self._host_res = torch.empty((64, rsz), dtype=torch.uint8).pin_memory()
+            host_res = self._host_res[:nQ]
+            res = host_res
+        else:
+            res = torch.empty((nQ, rsz), device=self.device, dtype=torch.uint8)
         ss = None
         if want_song_scores:
             ss = torch.zeros((nQ, self.n_songs, 2), device=self.device, dtype=torch.float32)
@@ -181,6 +205,12 @@ class DeviceIndex:
                      "pfann_match")
         if not to_host:
             return res, ss
+        if host_res is not None:
+            torch.cuda.current_stream(self.device).synchronize()
+            out = np.frombuffer(host_res.numpy().tobytes(), dtype=self.RESULT_DTYPE)
+            if (out["song"] == -2).any():
+                raise _l.PfannError("matcher refused a query (candidate buffer sizing error)")
+            return out, ss
         return self.results_to_host(res), ss
 
 
