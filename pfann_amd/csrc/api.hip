@@ -196,6 +196,7 @@ void pfann_destroy(pfann_ctx *c) {
     for (int i = 0; i < 16; ++i) {
         if (c->sub[i].w) (void)hipFree(c->sub[i].w);
         if (c->sub[i].w_hi) { (void)hipFree(c->sub[i].w_hi); (void)hipFree(c->sub[i].w_lo); }
+        if (c->sub[i].w22) (void)hipFree(c->sub[i].w22);
         if (c->sub[i].bias) (void)hipFree(c->sub[i].bias);
         if (c->sub[i].ln_w) (void)hipFree(c->sub[i].ln_w);
         if (c->sub[i].ln_b) (void)hipFree(c->sub[i].ln_b);
@@ -273,6 +274,18 @@ int pfann_load_weight(pfann_ctx *c, const char *name, const float *host, int64_t
                 }
                 if (upload(&L.w, w.data(), numel)) return -1;
                 if (blk == 0 && !second) { c->w1_host = w; c->gram_ready = false; }
+                if (ci > 1) {
+                    // {W1, W0, -W2, W0 + W2} per output channel for the five-block kernel (encoder_fused.hip)
+                    std::vector<float> w4((size_t)L.co * 4 * ci);
+                    for (int o = 0; o < L.co; ++o)
+                        for (int i = 0; i < ci; ++i) {
+                            const float w0 = w[((size_t)o * 3 + 0) * ci + i], w1 = w[((size_t)o * 3 + 1) * ci + i],
+                                        w2 = w[((size_t)o * 3 + 2) * ci + i];
+                            float *d4 = &w4[(size_t)o * 4 * ci + i];
+                            d4[0] = w1; d4[ci] = w0; d4[2 * (size_t)ci] = -w2; d4[3 * (size_t)ci] = w0 + w2;
+                        }
+                    if (upload(&L.w22, w4.data(), (int64_t)w4.size())) return -1;
+                }
                 if (ci > 1) {
                     // 2-term fp16 split of w * 2^e (largest magnitude in [2^14, 2^15)): hi = fl16(ws),
                     // lo = fl16(ws - hi) exactly representable residual -> 2^-22 relative, both in the normal range

@@ -151,6 +151,9 @@ struct SubLayer {          // one conv (+LN+act) sub-layer, channels-last activa
     // w * w_scale = hi + lo to 2^-22 relative (encoder_fused.hip, SPLIT kernels)
     void *w_hi, *w_lo;
     float w_inv_scale;
+    // [co][4][ci] = {W1, W0, -W2, W0 + W2}: the weights of conv_gemm_ln_w22_kernel (stride-2 convs computed with five
+    // channel blocks per output pair instead of six)
+    float *w22;
 };
 
 }  // namespace pfann

@@ -591,6 +591,326 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The stride-2 three-tap convolutions with FIVE channel blocks per pair of outputs instead of six (Winograd F(2,2) on
+// the even input samples; measured on a stripped clone, tools/ubench/gemm_w22.hip: 1.52 ms vs 1.76 ms for the same
+// skeleton doing the plain convolution, 0.865 of the fp32 MFMA peak counted in the convolution's own flops).
+// Two neighbouring outputs along the convolved axis (input positions 2o .. 2o+4 = e0 o0 e1 o1 e2, right/bottom zero pad):
+//     y0 = W0 e0 + W1 o0 + W2 e1          y1 = W0 e1 + W1 o1 + W2 e2
+//     A0 = (e0 - e1) W0 + o0 W1           A1 = e1 (W0 + W2)           A2 = (e1 - e2) (-W2) + o1 W1
+//     y0 = A0 + A1                        y1 = A1 + A2
+// e, o = the LayerNorm + activation of the previous sub-layer applied on load, as in conv_gemm_ln_kernel; the
+// differences are taken AFTER it, in the loader.  p.w = the layer's [N][4][Ci] table {W1, W0, -W2, W0 + W2}.
+// A workgroup = 128 output rows (64 pairs) x 128 channels, 8 waves of 32 pairs x 32 channels with three accumulator
+// blocks (48 VGPRs); a channel chunk of 32 takes four sub-steps through the double-buffered LDS:
+//     [o0; o1] x W1 (128 rows: A0, A2)    (e0 - e1) x W0 (A0)    (e1 - e2) x -W2 (A2)    e1 x (W0 + W2) (A1)
+// = 80 MFMAs per wave and chunk instead of 96.  Results differ from the plain kernel's by fp32 rounding (the sums are
+// associated differently); every summation order is fixed, so they are bit-reproducible run to run.
+// Used for full convs with stride 2, pad_lo 0, all three taps live, an even output length along the convolved axis and
+// Ci % 32 == 0 (launch_conv_gemm_ln); everything else keeps conv_gemm_ln_kernel.
+// FIRST: sub-layer 1 with the C_in = 1 conv folded into the loader as in conv_gemm_ln_kernel<.., FIRST>: p.x is the log-mel
+// batch; the 5 x 3 log-mel values a pair needs do not depend on the channel, so they are loaded ONCE per tile and the
+// activation operand costs no memory traffic in the loop at all.
+template <bool RELU_BN, bool FIRST>
+__global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParams p) {
+    constexpr int BM = 128, BN = 128, BK = 32, LDK = BK + 4, NT = 512, WAVES_N = 4, NP = 64;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDK + 2 * BN * LDK];
+    __shared__ __attribute__((aligned(16))) float s_w1[FIRST ? 4 * 256 : 4];   // FIRST: w1[3][Ci], b1[Ci]; Ci <= 256
+    __shared__ float s_ml[FIRST ? NP * 16 : 1];          // FIRST: the 5 x 3 log-mel values of every pair of the tile
+    float *const As = smem, *const Bs = smem + 2 * BM * LDK;
+    asm volatile("" :: "s"(p.x), "s"(p.w), "s"(p.in_stats), "s"(p.ln_w), "s"(p.ln_b), "s"(p.in_elems), "s"(p.tap_stride),
+                 "s"(p.M), "s"(p.N), "s"(p.Ci), "s"(p.rows_per_sample), "s"(p.To), "s"(p.F), "s"(p.T));
+    asm volatile("" :: "s"(p.rps_shift), "s"(p.To_shift), "s"(p.axis), "s"(p.in_len), "s"(p.n_tiles_n), "s"(p.n_samples),
+                 "s"(p.dv_group.mul), "s"(p.dv_group.shift), "s"(p.dv_tile.mul), "s"(p.dv_tile.shift), "s"(p.dv_n.mul), "s"(p.dv_n.shift));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int rps = p.rows_per_sample;
+    int mt, nt;
+    if (rps >= 2 * BM) {             // same tile order as conv_gemm_ln_kernel: tile ti of 64 neighbouring samples back to back
+        constexpr int GS = 64;
+        const int tps = rps / BM;
+        const int per_group = GS * tps * p.n_tiles_n;
+        const int g = fastdiv(L, p.dv_group);
+        const int left = p.n_samples - g * GS;
+        const int gs = left < GS ? left : GS;
+        const int r = L - g * per_group;
+        const int ti = gs == GS ? fastdiv(r, p.dv_tile) : r / (gs * p.n_tiles_n);
+        const int r2 = r - ti * (gs * p.n_tiles_n);
+        const int bi = fastdiv(r2, p.dv_n);
+        nt = r2 - bi * p.n_tiles_n;
+        mt = (g * GS + bi) * tps + ti;
+    } else {
+        mt = fastdiv(L, p.dv_n);
+        nt = L - mt * p.n_tiles_n;
+    }
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int b_first = m0 >> p.rps_shift;
+    if (FIRST) {     // first-conv weights and bias -> LDS (visible after the barrier below)
+        for (int i = tid; i < 4 * p.Ci; i += NT) s_w1[i] = i < 3 * p.Ci ? p.w1[i] : p.b1[i - 3 * p.Ci];
+    }
+    const int col4 = tid & 7, rowq = tid >> 3;           // loader thread = pair rowq, channels 4*col4 .. +3 of the chunk
+    // tile-relative output rows of pair q: along T (axis 0) the pair is two consecutive rows; along F (axis 1) the rows
+    // [fo][to] and [fo + 1][to], To apart (m0 is a multiple of 2*To: 128 % (2*To) == 0 is checked by the launcher)
+    auto pair_row0 = [&](int q) { return p.axis == 0 ? 2 * q : ((q >> p.To_shift) << (p.To_shift + 1)) + (q & (p.To - 1)); };
+    const int prow_stride = p.axis == 0 ? 1 : p.To;
+    const int64_t x_elems = FIRST ? (int64_t)p.F * p.T0 : p.in_elems;       // per-sample size of p.x
+    const __amdgpu_buffer_rsrc_t srd_a =
+        make_srd(p.x + (int64_t)b_first * x_elems, (unsigned long long)(p.n_samples - b_first) * x_elems * 4ull);
+    const __amdgpu_buffer_rsrc_t srd_w = make_srd(p.ln_w, (unsigned long long)p.in_elems * 4ull);
+    const __amdgpu_buffer_rsrc_t srd_lb = make_srd(p.ln_b, (unsigned long long)p.in_elems * 4ull);
+    const __amdgpu_buffer_rsrc_t srd_b = make_srd(p.w, (unsigned long long)p.N * 4ull * p.Ci * 4ull);
+    const __amdgpu_buffer_rsrc_t srd_st = make_srd(p.in_stats, (unsigned long long)p.n_samples * 8ull);
+    // the five input positions of this thread's pair: byte offsets of the activation (relative to sample b_first) and of
+    // the LayerNorm affine rows (sample-relative); out-of-range positions (zero padding, rows >= M) read 0 everywhere
+    unsigned va[FIRST ? 1 : 5], vr[5];
+    float amu, ars;
+    {
+        const int m = m0 + pair_row0(rowq);
+        const bool mok = m < p.M;
+        const int b = m >> p.rps_shift;
+        amu = buf_load1(srd_st, mok ? (unsigned)b * 8u : BUF_OOB);
+        ars = buf_load1(srd_st, mok ? (unsigned)b * 8u + 4u : BUF_OOB);
+        const int r = m & (rps - 1);
+        const int fo = r >> p.To_shift, to = r & (p.To - 1);
+        int rel, a0;
+        if (p.axis == 0) { a0 = 2 * to; rel = (fo * p.T + a0) * p.Ci; }
+        else { a0 = 2 * fo; rel = (a0 * p.T + to) * p.Ci; }
+        const int aoff = (b - b_first) * (int)p.in_elems + rel;
+        const int ts = (int)p.tap_stride;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const bool ok = mok && (a0 + j) < p.in_len;
+            if (!FIRST) va[j] = ok ? (unsigned)(aoff + j * ts + col4 * 4) * 4u : BUF_OOB;
+            vr[j] = ok ? (unsigned)(rel + j * ts + col4 * 4) * 4u : BUF_OOB;
+        }
+        if (FIRST) {
+            va[0] = 0;
+            // the pair's 5 x 3 log-mel values (they do not depend on the channel) -> LDS, two per loader thread:
+            // mel element ((b - b_first) * F + a0 + j) * T0 + to * s1 - pad1 + t1   (axis 1: a0 = 2 fo)
+            const int tq = to * p.s1 - p.pad1;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int e = col4 * 2 + h;              // 0 .. 15; 15 is padding
+                const int j = e / 3, t1 = e - j * 3;
+                const bool ok = e < 15 && mok && (a0 + j) < p.in_len && (unsigned)(tq + t1) < (unsigned)p.T0;
+                s_ml[rowq * 16 + e] = buf_load1(srd_a, ok ? (unsigned)(((b - b_first) * p.F + a0 + j) * p.T0 + tq + t1) * 4u : BUF_OOB);
+            }
+        }
+    }
+    if (FIRST) __syncthreads();
+    unsigned vb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + rowq + 64 * j;
+        vb[j] = n < p.N ? (unsigned)n * (unsigned)(4 * p.Ci) * 4u + (unsigned)col4 * 16u : BUF_OOB;
+    }
+    f32x4 px[2], pw[2], pb[2], rb[2], fe1;
+    const f32x2 mu2 = {amu, amu}, rs2 = {ars, ars};
+    // v = POST((z - mean) * rstd * W + B); out-of-range positions: W = B = 0 -> +-0 -> 0 (as in conv_gemm_ln_kernel)
+    auto fx = [&](const f32x4 &z4, const f32x4 &w4, const f32x4 &b4) {
+        f32x4 v;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x2 z = {z4[2 * h], z4[2 * h + 1]}, w2 = {w4[2 * h], w4[2 * h + 1]}, b2 = {b4[2 * h], b4[2 * h + 1]};
+            f32x2 t = __builtin_elementwise_fma((z - mu2) * rs2, w2, b2);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (RELU_BN) t[e] = fmaxf(t[e], 0.f);
+                else t[e] = p.after_bn ? act_fn(t[e], p.act) : t[e];
+                v[2 * h + e] = t[e];
+            }
+        }
+        return v;
+    };
+    int cc_st = 0;                                       // channel chunk of the sub-step whose operands sit in the registers
+    // positions of sub-step KIND's operands: {o0, o1}, {e0, e1}, {e2}
+    auto issue = [&](auto kindc, int cc) {               // global loads of sub-step (kind, channel chunk cc)
+        constexpr int KIND = decltype(kindc)::value;
+        constexpr int J0 = KIND == 0 ? 1 : (KIND == 1 ? 0 : 4), J1 = KIND == 0 ? 3 : 2;
+        const int so = cc * 4;
+        cc_st = cc;
+        if (KIND <= 2) {
+            if (!FIRST) px[0] = buf_load4(srd_a, va[FIRST ? 0 : J0], so);
+            pw[0] = buf_load4(srd_w, vr[J0], so); pb[0] = buf_load4(srd_lb, vr[J0], so);
+        }
+        if (KIND <= 1) {
+            if (!FIRST) px[1] = buf_load4(srd_a, va[FIRST ? 0 : J1], so);
+            pw[1] = buf_load4(srd_w, vr[J1], so); pb[1] = buf_load4(srd_lb, vr[J1], so);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) rb[j] = buf_load4(srd_b, vb[j], (KIND * p.Ci + cc) * 4);
+    };
+    // FIRST: z = b1 + sum_t1 w1[t1] * mel[t1] for this thread's four channels of input row J (same FMA order as
+    // conv_first_stats_kernel: bias, then taps 0, 1, 2)
+    auto first_z = [&](int J) {
+        const int c0 = cc_st + col4 * 4;
+        f32x4 z = *reinterpret_cast<const f32x4 *>(&s_w1[3 * p.Ci + c0]);
+#pragma unroll
+        for (int t1 = 0; t1 < 3; ++t1) {
+            const f32x4 w = *reinterpret_cast<const f32x4 *>(&s_w1[t1 * p.Ci + c0]);
+            const float m = s_ml[rowq * 16 + J * 3 + t1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[e] = fmaf(m, w[e], z[e]);
+        }
+        if (!RELU_BN && !p.after_bn) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[e] = act_fn(z[e], p.act);      // PRE of sub-layer 0
+        }
+        return z;
+    };
+    auto stash = [&](auto kindc, float *Ad, float *Bd) {  // transform + LDS refill of that sub-step
+        constexpr int KIND = decltype(kindc)::value;
+        if (FIRST) {
+            if (KIND == 0) { px[0] = first_z(1); px[1] = first_z(3); }
+            else if (KIND == 1) { px[0] = first_z(0); px[1] = first_z(2); }
+            else if (KIND == 2) px[0] = first_z(4);
+        }
+        if (KIND == 0) {
+            *reinterpret_cast<f32x4 *>(&Ad[rowq * LDK + col4 * 4]) = fx(px[0], pw[0], pb[0]);
+            *reinterpret_cast<f32x4 *>(&Ad[(NP + rowq) * LDK + col4 * 4]) = fx(px[1], pw[1], pb[1]);
+        } else if (KIND == 1) {
+            const f32x4 f0 = fx(px[0], pw[0], pb[0]);
+            fe1 = fx(px[1], pw[1], pb[1]);
+            *reinterpret_cast<f32x4 *>(&Ad[rowq * LDK + col4 * 4]) = f0 - fe1;
+        } else if (KIND == 2) {
+            *reinterpret_cast<f32x4 *>(&Ad[rowq * LDK + col4 * 4]) = fe1 - fx(px[0], pw[0], pb[0]);
+        } else {
+            *reinterpret_cast<f32x4 *>(&Ad[rowq * LDK + col4 * 4]) = fe1;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4 *>(&Bd[(rowq + 64 * j) * LDK + col4 * 4]) = rb[j];
+    };
+    f32x16 acc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
+    const int nch = p.Ci / BK;
+    const int l31 = lane & 31, lhalf = lane >> 5;
+    issue(K0{}, 0);
+    stash(K0{}, As, Bs);
+    __syncthreads();
+    // one sub-step: MFMAs on LDS buffer PB while the next sub-step goes global -> registers -> buffer PB ^ 1
+    auto substep = [&](int ch, auto kindc, auto nextc) {
+        constexpr int KIND = decltype(kindc)::value, PB = KIND & 1;
+        const float *Ac = As + PB * (BM * LDK), *Bc = Bs + PB * (BN * LDK);
+        float *An = As + (PB ^ 1) * (BM * LDK), *Bn = Bs + (PB ^ 1) * (BN * LDK);
+        const bool more = KIND < 3 || ch + 1 < nch;
+        const int cc_next = (KIND < 3 ? ch : ch + 1) * BK;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(&Ac[(wm * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
+            f32x4 a1 = a0;
+            if (KIND == 0) a1 = *reinterpret_cast<const f32x4 *>(&Ac[(NP + wm * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(&Bc[(wn * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
+            if (kk == 0) {
+                if (more) issue(nextc, cc_next);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (kk == BK / 8 - 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) stash(nextc, An, Bn);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (KIND == 0) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[s], a0[s], acc[0], 0, 0, 0);   // C^T: rows = n
+                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[s], a1[s], acc[2], 0, 0, 0);
+                } else if (KIND == 1) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[s], a0[s], acc[0], 0, 0, 0);
+                else if (KIND == 2) acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[s], a0[s], acc[2], 0, 0, 0);
+                else acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[s], a0[s], acc[1], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    };
+    for (int ch = 0; ch < nch; ++ch) {
+        substep(ch, K0{}, K1{});
+        substep(ch, K1{}, K2{});
+        substep(ch, K2{}, K3{});
+        substep(ch, K3{}, K0{});
+    }
+
+    // ---- epilogue: y0 = A0 + A1 + bias, y1 = A1 + A2 + bias -> LDS -> whole rows; per-sample partial statistics
+    // (same scheme as conv_gemm_ln_kernel: a lane holds ONE pair (lane & 31) and four consecutive channels per register quad)
+    const __amdgpu_buffer_rsrc_t srd_y = make_srd(p.y + (int64_t)m0 * p.N, (unsigned long long)(p.M - m0) * p.N * 4ull);
+    const __amdgpu_buffer_rsrc_t srd_bias = make_srd(p.bias, (unsigned long long)p.N * 4ull);
+    constexpr int LDC = BN + 4;
+    float *Cs = smem;                                   // [BM][LDC]
+    float *red1 = smem + BM * LDC;                      // [BM][WAVES_N]
+    float *red2 = red1 + BM * WAVES_N;
+    const int G = rps >= BM ? BM : rps;
+    const unsigned rowbytes = (unsigned)p.N * 4u;
+    f32x4 bias4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * 32 + 8 * g + 4 * lhalf;
+        bias4[g] = buf_load4(srd_bias, n < p.N ? (unsigned)n * 4u : BUF_OOB);
+    }
+    const int prow = pair_row0(wm * 32 + l31);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float a1 = 0.f, a2 = 0.f;
+        const int row = prow + i * prow_stride;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 z4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float z = (acc[i][4 * g + e] + acc[i + 1][4 * g + e]) + bias4[g][e];
+                if (!RELU_BN && !p.after_bn) z = act_fn(z, p.act);
+                a1 += z;
+                a2 = fmaf(z, z, a2);
+                z4[e] = z;
+            }
+            *reinterpret_cast<f32x4 *>(&Cs[row * LDC + wn * 32 + 8 * g + 4 * lhalf]) = z4;
+        }
+        a1 += __shfl_xor(a1, 32, 64);
+        a2 += __shfl_xor(a2, 32, 64);
+        if (lhalf == 0) {
+            red1[row * WAVES_N + wn] = a1;
+            red2[row * WAVES_N + wn] = a2;
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int LPR = BN / 4, RPP = NT / LPR;
+        const int cl = tid % LPR, rr = tid / LPR;
+        const int n = n0 + cl * 4;
+        const unsigned nb = n < p.N ? (unsigned)n * 4u : BUF_OOB;
+#pragma unroll
+        for (int it = 0; it < BM / RPP; ++it) {
+            const int row = it * RPP + rr;
+            buf_store4(srd_y, nb + (unsigned)row * rowbytes, *reinterpret_cast<const f32x4 *>(&Cs[row * LDC + cl * 4]));
+        }
+    }
+    float t1 = 0.f, t2 = 0.f;
+    if (tid < BM) {
+#pragma unroll
+        for (int w = 0; w < WAVES_N; ++w) { t1 += red1[tid * WAVES_N + w]; t2 += red2[tid * WAVES_N + w]; }
+        for (int o = (G < 64 ? G : 64) >> 1; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o, 64); t2 += __shfl_xor(t2, o, 64); }
+    }
+    if (G > 64) {
+        float *x2 = red2 + BM * WAVES_N;
+        if (tid < BM && lane == 0) { x2[2 * wave] = t1; x2[2 * wave + 1] = t2; }
+        __syncthreads();
+        t1 = x2[0] + x2[2];
+        t2 = x2[1] + x2[3];
+    }
+    if (tid < BM && (tid & (G - 1)) == 0) {
+        const int mg = m0 + tid;
+        if (mg < p.M) {
+            const int b = mg >> p.rps_shift;
+            const int slot = ((mg & (rps - 1)) / G) * p.n_tiles_n + nt;
+            float *o = p.out_part + ((int64_t)b * p.out_P + slot) * 2;
+            o[0] = t1;
+            o[1] = t2;
+        }
+    }
+}
+
 // (mean, rstd) of every sample from its P partial (sum, sum of squares) pairs: one wave per sample,
 // fp64, fixed order.  Done once here rather than by every GEMM block that touches the sample.
 __global__ __launch_bounds__(256) void ln_finalize_kernel(const float *__restrict__ part, int P, double inv_n,
@@ -755,6 +1075,22 @@ int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, 
         p.dv_n = make_fastdiv(p.n_tiles_n); p.dv_tile = make_fastdiv(64 * p.n_tiles_n);
         p.dv_group = make_fastdiv(64 * (p.rows_per_sample >= 128 ? p.rows_per_sample / 128 : 1) * p.n_tiles_n);
         const int64_t blocks = (int64_t)cdiv(p.M, 128) * p.n_tiles_n;
+        // five channel blocks per output pair instead of six (conv_gemm_ln_w22_kernel) where the layer allows it
+        static const bool no_w22 = getenv("PFANN_NO_W22") != nullptr;
+        const int out_len = L.axis == 0 ? L.To : L.Fo;
+        if (!no_w22 && (!first || (L.axis == 1 && L.ci <= 256 && getenv("PFANN_NO_W22_FIRST") == nullptr)) && precision == 0 && L.w22 != nullptr && L.stride == 2 && L.pad_lo == 0 && p.k_begin == 0 &&
+            p.k_end == 3 * L.ci && out_len % 2 == 0 && p.M % 2 == 0 && (L.axis == 0 || (L.To <= 64 && 128 % (2 * L.To) == 0)) &&
+            (int64_t)p.N * 4 * p.Ci * 4 < 0x7FFF0000ll) {
+            p.w = L.w22;
+            ProfScope ps(layer_tag(per_layer ? "conv_gemm_ln_128 w22" : "conv_gemm_ln_128"), s, flops);
+            const dim3 g((unsigned)blocks), t(512);
+            if (first && relu_bn) PF_LAUNCH((conv_gemm_ln_w22_kernel<true, true>), g, t, 0, s, p);
+            else if (first) PF_LAUNCH((conv_gemm_ln_w22_kernel<false, true>), g, t, 0, s, p);
+            else if (relu_bn) PF_LAUNCH((conv_gemm_ln_w22_kernel<true, false>), g, t, 0, s, p);
+            else PF_LAUNCH((conv_gemm_ln_w22_kernel<false, false>), g, t, 0, s, p);
+            PF_HIP(hipGetLastError());
+            return 0;
+        }
         ProfScope ps(layer_tag("conv_gemm_ln_128"), s, flops);
         // 8 waves (512 threads), each a 64x32 tile: half the prefetch registers per thread and four
         // waves per SIMD with two resident blocks

@@ -243,6 +243,40 @@ def test_encoder_large_batch_128_tiles_vs_oracle(torch_cuda):
     assert np.abs(e1 - ref).max() < 1e-4
 
 
+def test_encoder_five_block_kernel_vs_oracle(torch_cuda):
+    """A batch large enough (130 segments) for the stride-2 layers with 1024 / 512 / 256 rows per sample to run on
+    conv_gemm_ln_w22_kernel (five channel blocks per output pair instead of six: conv along T and along F, N = 128 and
+    256, a last tile with rows >= M): every sub-layer activation and the embeddings against the CPU oracle.  The sums are
+    associated differently from the plain kernel's, so this is an fp32-rounding-level comparison, same bars as the
+    golden tests (2e-4 relative on activations, 1e-4 on embeddings)."""
+    from oracle import encoder as oe
+    from pfann_amd.engine import Engine
+    params = cfg("default")
+    _, _, _, F, T = synth.model_dims(params)
+    sd = synth.make_state_dict(params, seed=123)
+    B = 130
+    x = (synth.normal(79, "t/w22", B * F * T).reshape(B, F, T) * 3.0 - 6.0).astype(np.float32)
+    taps_ref = []
+    ref = oe.encode(x, sd, params, norm=True, taps=taps_ref)
+    eng = Engine(params, 0, max_batch=160)
+    eng.load_state_dict(sd)
+    eng.debug_keep(True)
+    e1 = eng.encode(torch_cuda.as_tensor(x).cuda(), norm=True).cpu().numpy()
+    worst = 0.0
+    for i, tr in enumerate(taps_ref):
+        tg = eng.debug_activation(i, 8)
+        e = np.abs(tg - tr[:8]).max() / max(1.0, np.abs(tr[:8]).max())
+        worst = max(worst, e)
+        assert e < 2e-4, "sub-layer %d: rel err %g" % (i, e)
+    print("five-block kernels vs oracle: emb %.3e, worst tap rel %.3e" % (np.abs(e1 - ref).max(), worst))
+    assert np.abs(e1 - ref).max() < 1e-4
+    eng.debug_keep(False)
+    e2 = eng.encode(torch_cuda.as_tensor(x).cuda(), norm=True).cpu().numpy()
+    assert np.abs(e2 - ref).max() < 1e-4
+    # run to run bit-reproducible
+    assert np.array_equal(e2, eng.encode(torch_cuda.as_tensor(x).cuda(), norm=True).cpu().numpy())
+
+
 def test_encoder_split_precision_matches_fp32(torch_cuda):
     """Opt-in encoder arithmetic (pfann_set_encoder_precision = 1): conv products as three fp16 MFMA
     terms of two-term operand splits, fp32 accumulation.  Must stay fp32-grade: embeddings within 2e-5

@@ -17,7 +17,7 @@ def main(path):
     B = js["config"]["segments_per_step"] // js["n_gpus"]
     rows = []
     for tag, kv in js["kernels"].items():
-        m = re.match(r"(conv_gemm_ln_\d+) rows=(\d+) K=(\d+) N=(\d+)( first)?", tag)
+        m = re.match(r"(conv_gemm_ln_\d+(?: w22)?) rows=(\d+) K=(\d+) N=(\d+)( first)?", tag)
         if not m:
             continue
         rps, K, N = int(m.group(2)), int(m.group(3)), int(m.group(4))
