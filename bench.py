@@ -85,7 +85,9 @@ def cpu_baseline_leg(args, params, sd, shard, song_pos, q_pcm_mine, res, k, n_ro
         return st, dec
 
     sweep = {}
-    for nt in sorted({min(16, ncpu), min(64, ncpu), default_threads, ncpu}):
+    # all logical cores only up to 128: on this pool's 256-thread hosts the oracle runs at ~1 segment/s with 256
+    # threads (oversubscribed BLAS + OpenMP), a 76 s probe for a number nobody would pick (profiles/r3/bench.json)
+    for nt in sorted({min(8, ncpu), min(16, ncpu), min(32, ncpu), min(64, ncpu), min(default_threads, 128), min(ncpu, 128)}):
         run([0], nt)                                                       # warm this setting
         stp, _ = run(list(range(min(4, nq_cpu))), nt)
         sweep[nt] = round(min(4, nq_cpu) * QUERY_SEGS / sum(stp.values()), 1)
@@ -537,9 +539,10 @@ def main():
             kernels[tag] = {"ms_per_step": ms / args.steps, "launches_per_step": cnt.value / args.steps,
                             "avg_us": 1e3 * ms / max(cnt.value, 1), "work_per_launch": work / max(cnt.value, 1)}
     # roofline of the dominant kernel (most time in the timed region)
-    ROOF = {"conv_gemm_ln_128": ("pfann::conv_gemm_ln_kernel<128,128,64,32,...> (implicit-GEMM conv with LayerNorm+ReLU "
-                                 "of its input fused into the A-loader and LN statistics of its output in the epilogue; "
-                                 "all instantiations, incl. the one with the first conv folded in)", "mfma"),
+    ROOF = {"conv_gemm_ln_128": ("pfann::conv_gemm_ln_w22_kernel / conv_gemm_ln_kernel<128,128,64,32,...> (the 15 implicit-GEMM "
+                                 "convs, 128x128 tiles, LayerNorm+ReLU of the input fused into the A-loader, LN statistics of the "
+                                 "output in the epilogue; the stride-2 layers -- 96 % of the time -- on the five-blocks-per-output-"
+                                 "pair kernel, incl. the one with the first conv folded in)", "mfma"),
             "conv_gemm_ln_64": ("pfann::conv_gemm_ln_kernel<64,64,32,32>", "mfma"),
             "conv_first_stats": ("pfann::conv_first_stats_kernel", "hbm"),
             "conv_gemm_128": ("pfann::conv_gemm_kernel<128,128,64,64>", "mfma"),
@@ -571,6 +574,8 @@ def main():
                     "unit": "TFLOP/s" if mf else "GB/s", "frac": round(ach / peak, 4), "traffic": None,
                     "avg_launch_us": round(kv["avg_us"], 1), "launches_per_step": kv["launches_per_step"],
                     "algorithmic_work_per_launch": kv["work_per_launch"],
+                    "flops_counted": "ALGORITHMIC: 2*M*N*K_live of the convolutions (SURVEY 8d); the five-block kernel executes "
+                                     "5/6 of them on its layers, so the MFMA pipe itself is used at about 5/6 of `frac` there",
                     "share_of_step_time": round(kv["ms_per_step"] / (1e3 * elapsed / args.steps), 3)}
     # HBM-side traffic per launch of the dominant kernel, from the committed PMC passes of this
     # same command (tools/profile_bench.sh -> tools/make_traffic_json.py -> profiles/traffic.json)
