@@ -584,6 +584,11 @@ def main():
             tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
             key = ROOF[dom][0].split("<")[0].split(" ")[0]
             tmpl = ROOF[dom][0].split(" ")[0].replace(",...>", "").replace(",", ", ")
+            if "tag:" + dom in tj:
+                roofline["traffic"] = tj["tag:" + dom]["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = "%s PMC FETCH_SIZE x2 + WRITE_SIZE, launch-weighted over the kernels of tag %s" % (
+                    tj["tag:" + dom]["source"], dom)
+                raise KeyError("done")
             names = sorted(tj, key=lambda nm: "all instantiations" not in nm)     # prefer the combined record
             for name in names:
                 rec = tj[name]

@@ -43,6 +43,18 @@ def main(d):
                 "write_size_kb_per_launch": sum(r["write_size_kb_per_launch"] * r["dispatches"] for r in rs) / nd,
                 "hbm_bytes_per_launch": sum(r["hbm_bytes_per_launch"] * r["dispatches"] for r in rs) / nd,
                 "correction": "FETCH_SIZE x2 (gfx950, 16 B/lane loads), WRITE_SIZE x1; launch-weighted over instantiations"}
+    # bench.py's profiling tag "conv_gemm_ln_128" = every 128x128-tile conv GEMM launch: the five-block kernel
+    # (conv_gemm_ln_w22_kernel, both variants) and what is left on conv_gemm_ln_kernel<128, ...>
+    rs = [r for k, r in res.items() if re.match(r"(?:void )?pfann::conv_gemm_ln_(w22_kernel|kernel<128)", k) and "all instantiations" not in k]
+    if rs:
+        nd = sum(r["dispatches"] for r in rs)
+        res["tag:conv_gemm_ln_128"] = {
+            "dispatches": nd, "source": d,
+            "fetch_size_kb_per_launch": sum(r["fetch_size_kb_per_launch"] * r["dispatches"] for r in rs) / nd,
+            "write_size_kb_per_launch": sum(r["write_size_kb_per_launch"] * r["dispatches"] for r in rs) / nd,
+            "hbm_bytes_per_launch": sum(r["hbm_bytes_per_launch"] * r["dispatches"] for r in rs) / nd,
+            "correction": "FETCH_SIZE x2 (gfx950, 16 B/lane loads), WRITE_SIZE x1; launch-weighted over "
+                          "conv_gemm_ln_w22_kernel<*> and conv_gemm_ln_kernel<128,*>"}
     json.dump(res, open("profiles/traffic.json", "w"), indent=1, sort_keys=True)
     print(json.dumps(res, indent=1)[:1500])
 
