@@ -243,15 +243,20 @@ def test_encoder_large_batch_128_tiles_vs_oracle(torch_cuda):
     assert np.abs(e1 - ref).max() < 1e-4
 
 
-def test_encoder_five_block_kernel_vs_oracle(torch_cuda):
+@pytest.mark.parametrize("variant", ["default", "elu_pre_ln"])
+def test_encoder_five_block_kernel_vs_oracle(torch_cuda, variant):
     """A batch large enough (130 segments) for the stride-2 layers with 1024 / 512 / 256 rows per sample to run on
     conv_gemm_ln_w22_kernel (five channel blocks per output pair instead of six: conv along T and along F, N = 128 and
-    256, a last tile with rows >= M): every sub-layer activation and the embeddings against the CPU oracle.  The sums are
+    256, a last tile with rows >= M): every sub-layer activation and the embeddings against the CPU oracle.  "elu_pre_ln":
+    the same model with ELU applied BEFORE LayerNorm (model.py:58-72 with relu_after_bn=False), i.e. the kernel's generic
+    <false, *> instantiations incl. the folded first conv with its pre-activation.  The sums are
     associated differently from the plain kernel's, so this is an fp32-rounding-level comparison, same bars as the
     golden tests (2e-4 relative on activations, 1e-4 on embeddings)."""
     from oracle import encoder as oe
     from pfann_amd.engine import Engine
     params = cfg("default")
+    if variant == "elu_pre_ln":
+        params["model"].update(conv_activation="ELU", relu_after_bn=False)
     _, _, _, F, T = synth.model_dims(params)
     sd = synth.make_state_dict(params, seed=123)
     B = 130
