@@ -152,13 +152,14 @@ class DeviceIndex:
         _l.check(self.lib.pfann_match_pack(self.handle, res_dev.data_ptr(), nQ, keys.data_ptr(), self._stream()), "pfann_match_pack")
         return keys
 
-    def pick_winner(self, all_keys):
-        """all_keys int64 [G, nQ, 2] (all-gathered) -> structured array of the winners (one D2H)."""
+    def pick_winner(self, all_keys, to_host=True):
+        """all_keys int64 [G, nQ, 2] (all-gathered) -> structured array of the winners (one D2H), or with to_host=False
+        the device tensor of results (results_to_host turns it into the array later)."""
         all_keys = all_keys.to(self.device).contiguous()
         G, nQ = all_keys.shape[0], all_keys.shape[1]
         out = torch.empty((nQ, ctypes.sizeof(_l.MatchResult)), device=self.device, dtype=torch.uint8)
         _l.check(self.lib.pfann_match_pick(self.handle, all_keys.data_ptr(), G, nQ, out.data_ptr(), self._stream()), "pfann_match_pick")
-        return self.results_to_host(out)
+        return self.results_to_host(out) if to_host else out
 
     def match(self, q, labels, qstart, qlen, fsm=1, alpha=0.0, mode=0, only_owned=False, want_song_scores=False,
               to_host=True):

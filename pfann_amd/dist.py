@@ -135,7 +135,7 @@ class ShardedIndex:
         gI = all_gather_rows(Im, self.group).reshape(G * Qs, k)[:Q]
         return gD.contiguous(), gI.contiguous()
 
-    def query_batch(self, q, qstart, qlen):
+    def query_batch(self, q, qstart, qlen, to_host=True):
         """-> structured array (song, offset, shift, score) per query, identical on all ranks.
         Everything between the search and the final result stays on the device: the owner-side results are packed
         into one 128-bit orderable key per query (pfann_match_pack), all-gathered (16 bytes per query and rank) and
@@ -144,4 +144,4 @@ class ShardedIndex:
         res, _ = self.b.match(q, I, qstart, qlen, self.fsm, self.alpha, 0, True, False, to_host=False)
         keys = self.b.pack_winner_keys(res)                          # int64 [nQ, 2]
         allk = all_gather_rows(keys, self.group)                     # [G, nQ, 2]
-        return self.b.pick_winner(allk)
+        return self.b.pick_winner(allk, to_host=to_host)      # to_host=False: the device tensor (results_to_host later)

@@ -83,7 +83,7 @@ class OracleIndex:
         lo = np.where(refused, np.uint64(0), lo)
         return torch.from_numpy(np.stack([hi, lo], 1).view(np.int64).copy())
 
-    def pick_winner(self, all_keys):
+    def pick_winner(self, all_keys, to_host=True):
         k = all_keys.cpu().numpy().view(np.uint64)                  # [G, nQ, 2]
         G, nQ = k.shape[0], k.shape[1]
         out = np.zeros(nQ, dtype=[("song", "<i4"), ("offset", "<i4"), ("shift", "<i4"), ("n_cand", "<i4"), ("score", "<f8")])
