@@ -521,6 +521,29 @@ def main():
             "value": round(n_seg / el, 1), "unit": "segments/s", "ms_per_step": round(1e3 * el, 3),
             "decisions_identical_to_fp32_db": "%d/%d" % (same, Q), "top1_hit_rate": round(hit16 / Q, 4)}}
         del idx16
+        # ---- encoder-only rates of the other model families and of the unfused fallback (the rates DESIGN.md quotes):
+        # this step's windows (PCM resident in HBM) -> fingerprints, 3 passes each; never `value`
+        enc_alt = {}
+        wav_alt = eng.pcm16_to_mono(pcm_dev)
+        for name, cfg_file, fused in (("seg.json (depthwise conv2, 116 MMAC/segment)", "seg.json", True),
+                                      ("n640d64.json (d = 64, depthwise, 36 MMAC/segment)", "n640d64.json", True),
+                                      ("default.json, LayerNorm NOT fused (pfann_set_fused_layernorm(0): conv_gemm_kernel + ln_act_kernel)",
+                                       "default.json", False)):
+            pa = read_config(os.path.join(REPO, "configs", cfg_file))
+            ea = Engine(pa, local_rank, max_batch=4864)
+            ea.load_state_dict(synth.make_state_dict(pa, seed=123))
+            if not fused:
+                assert ea.set_fused_layernorm(False) is False
+            ea.embed_windows(wav_alt, starts_dev)
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            for _ in range(3):
+                ea.embed_windows(wav_alt, starts_dev)
+            torch.cuda.synchronize()
+            enc_alt[name] = {"segments_per_s": round(3 * starts_dev.shape[0] / (time.perf_counter() - ta), 1),
+                             "windows_per_pass": int(starts_dev.shape[0]), "max_batch": 4864}
+            del ea
+        alt["encoder_only"] = enc_alt
     if seam_before is not None:
         seam_after = seam_leg()
 

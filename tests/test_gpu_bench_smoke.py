@@ -42,6 +42,7 @@ def test_bench_json_contract_small():
     assert cli["matcher"]["top1_hit_rate"] >= 0.5
     assert out["ranks_seen"] == 1 and out["devices"] == [0]
     assert out["alt_modes"]["fp16_db"]["decisions_identical_to_fp32_db"].endswith("/16")
+    assert len(out["alt_modes"]["encoder_only"]) == 3 and all(v["segments_per_s"] > 0 for v in out["alt_modes"]["encoder_only"].values())
     assert out["seq_score_seam"]["same_best_song"] is True and out["seq_score_seam"]["calls"] == 200
     assert out["seq_score_seam"]["gpu_call_us_median"] <= out["seq_score_seam"]["gpu_call_us_p95"]
 

@@ -25,7 +25,7 @@ from pfann_amd import synth
 
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(REPO, "gpurun_out", "r2")
+OUT = os.path.join(REPO, "gpurun_out", "r3")
 SEG, QSEG, HOP = 59, 19, 4000
 
 

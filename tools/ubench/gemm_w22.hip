@@ -40,13 +40,14 @@ __global__ void fill(float *p, size_t n, float scale, float bias) {
 template <int MODE>
 __global__ __launch_bounds__(512, 4) void kw(const float *__restrict__ x, const float *__restrict__ lw, const float *__restrict__ lb,
                                              const float *__restrict__ w, const float *__restrict__ stats, float *__restrict__ y,
-                                             float *__restrict__ part, int rps_out) {
+                                             float *__restrict__ part, int rps_out, unsigned long long *ts) {
     constexpr int LDK = 36, BM = 128, BN = 128, C = 128;
     constexpr int NSUB = MODE == 0 ? 4 : 3;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem, *Bs = smem + 2 * BM * LDK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
     const int l31 = lane & 31, lhalf = lane >> 5, col4 = tid & 7, rowq = tid >> 3;
+    const unsigned long long t_start = __builtin_readcyclecounter();
     const int m0 = blockIdx.x * BM;
     const int b = m0 / rps_out, r0 = m0 % rps_out;
     const int rps_in = 2 * rps_out;
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(512, 4) void kw(const float *__restrict__ x, const 
         }
         __syncthreads();
     };
+    const unsigned long long t_loop0 = __builtin_readcyclecounter();
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
     if (MODE == 0) {
@@ -163,6 +165,7 @@ __global__ __launch_bounds__(512, 4) void kw(const float *__restrict__ x, const 
             substep(ch * 3 + 3, I0{}, I1{}); substep(ch * 3 + 4, I1{}, I0{}); substep(ch * 3 + 5, I2{}, I1{});
         }
     }
+    const unsigned long long t_loop1 = __builtin_readcyclecounter();
     // ---- epilogue: rows through LDS as whole 512 B rows + statistics (as gemm_tile's EPI = 2, STATS)
     const __amdgpu_buffer_rsrc_t sy = srd(y + (int64_t)m0 * BN, (uint64_t)BM * BN * 4);
     constexpr int LDC = 132;
@@ -200,6 +203,11 @@ __global__ __launch_bounds__(512, 4) void kw(const float *__restrict__ x, const 
         for (int o = 32; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o, 64); t2 += __shfl_xor(t2, o, 64); }
         if (lane == 0) { part[(blockIdx.x * 2 + wave) * 2] = t1; part[(blockIdx.x * 2 + wave) * 2 + 1] = t2; }
     }
+    if (ts != nullptr && tid == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        unsigned long long *o = ts + (size_t)blockIdx.x * 4;
+        o[0] = t_start; o[1] = t_loop0; o[2] = t_loop1; o[3] = __builtin_readcyclecounter();
+    }
 }
 
 int main(int argc, char **argv) {
@@ -221,13 +229,24 @@ int main(int argc, char **argv) {
             auto kp = mode == 0 ? kw<0> : kw<1>;
             (void)hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-            hipLaunchKernelGGL(kp, dim3(ntiles), dim3(512), lds, 0, x, lw, lb, w, stats, y, part, rps_out); (void)hipDeviceSynchronize();
+            hipLaunchKernelGGL(kp, dim3(ntiles), dim3(512), lds, 0, x, lw, lb, w, stats, y, part, rps_out, nullptr); (void)hipDeviceSynchronize();
             (void)hipEventRecord(e0);
-            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kp, dim3(ntiles), dim3(512), lds, 0, x, lw, lb, w, stats, y, part, rps_out);
+            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kp, dim3(ntiles), dim3(512), lds, 0, x, lw, lb, w, stats, y, part, rps_out, nullptr);
             (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 3;
             printf("%-64s %8.3f ms  %6.1f TFLOP/s (algorithmic)  %.3f  %s\n",
                    mode == 0 ? "F(2,2): 5 blocks per output pair, 4 sub-steps per chunk" : "plain: 6 blocks per output pair, 3 sub-steps per chunk",
                    ms, flop / ms / 1e9, flop / ms / 1e9 / 157.3, hipGetErrorString(hipGetLastError()));
         }
+    // per-tile phase stamps (shader clock cycles; two workgroups resident per CU)
+    unsigned long long *ts; (void)hipMalloc(&ts, (size_t)ntiles * 32);
+    unsigned long long *h = (unsigned long long *)malloc((size_t)ntiles * 32);
+    for (int mode = 1; mode >= 0; --mode) {
+        auto kp = mode == 0 ? kw<0> : kw<1>;
+        hipLaunchKernelGGL(kp, dim3(ntiles), dim3(512), lds, 0, x, lw, lb, w, stats, y, part, rps_out, ts); (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h, ts, (size_t)ntiles * 32, hipMemcpyDeviceToHost);
+        double a = 0, b2 = 0, c2 = 0; int n = 0;
+        for (int i = ntiles / 4; i < ntiles * 3 / 4; ++i) { a += h[4 * i + 1] - h[4 * i]; b2 += h[4 * i + 2] - h[4 * i + 1]; c2 += h[4 * i + 3] - h[4 * i + 2]; ++n; }
+        printf("%s per tile (cycles): prologue %.0f, loop %.0f, epilogue %.0f, total %.0f\n", mode == 0 ? "F(2,2)" : "plain ", a / n, b2 / n, c2 / n, (a + b2 + c2) / n);
+    }
     return 0;
 }
