@@ -268,13 +268,17 @@ __global__ __launch_bounds__(256, 2) void scan_f16_kernel(ScanParams p) {
 // k-th best of a row's 64*S group maxima is the score of a real row, hence (minus the rounding margin) a lower bound of its
 // k-th best overall.  One such pass over every 4th row + a radix select of the group maxima replace the dense and 1/16
 // levels with their two survivor selects.  Groups are interleaved on purpose (see gmx in the kernel).
-template <int KS, bool GMAX = false>
-__global__ __launch_bounds__(256, 2) void scan_f16_qres_kernel(ScanParams p) {
-    constexpr int BM = 128, WM = 64, WN = 64, TM = 2, TN = 2;
+// DBR = db rows per tile: 128 (two workgroups per CU), or 64 for the full pass: half the LDS and fewer accumulators per
+// workgroup, THREE workgroups (12 waves) per CU -- more independent barrier domains to cover a workgroup's epilogue and
+// barrier waits with the others' MFMAs, at twice the barriers per MFMA.
+template <int KS, bool GMAX = false, int DBR = 128>
+__global__ __launch_bounds__(256, DBR == 64 ? 3 : 2) void scan_f16_qres_kernel(ScanParams p) {
+    constexpr int BM = 128, WM = 64, WN = DBR / 2, TM = 2, TN = WN / 32;
     constexpr int ROWB = KS * 32;                 // bytes of one fp16 row
     constexpr int CPR = ROWB / 16;                // 16-byte chunks per row
-    constexpr int NLD = 128 * CPR / 256;          // direct-to-LDS loads per thread per db tile
-    __shared__ __attribute__((aligned(1024))) float Bs[2][128 * ROWB / 4];
+    constexpr int NLD = DBR * CPR / 256;          // direct-to-LDS loads per thread per db tile
+    static_assert(!GMAX || DBR == 128, "the group-maximum pass assumes 64 groups per slice");
+    __shared__ __attribute__((aligned(1024))) float Bs[2][DBR * ROWB / 4];
     __shared__ int s_cnt[BM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void scan_f16_qres_kernel(ScanParams p) {
     const int64_t m0 = (int64_t)mt * BM;
     // db tiles seg, seg + S, seg + 2S, ...: interleaved, so a run of similar rows (one song) is spread
     // over the sub-lists instead of overflowing one
-    const int64_t t_lo = seg, t_hi = (p.nrows + 127) / 128;
+    const int64_t t_lo = seg, t_hi = (p.nrows + DBR - 1) / DBR;
     if (tid < BM) s_cnt[tid] = 0;
     // this workgroup's sub-lists: row ml, slot pos -> keys[(m0 + ml) * CAP + seg * subcap + pos]
     const __amdgpu_buffer_rsrc_t srd_k = make_srd(p.keys + m0 * CAP + (int64_t)seg * subcap, (unsigned long long)BM * CAP * 8ull);
@@ -344,9 +348,9 @@ __global__ __launch_bounds__(256, 2) void scan_f16_qres_kernel(ScanParams p) {
         goff[u] = (unsigned long long)r * p.row_stride * ROWB + (unsigned)((cs ^ key(r)) * 16);
     }
     auto load_tile = [&](int64_t t, int bb) {
-        const int64_t r0 = t * 128 * p.row_stride;
+        const int64_t r0 = t * DBR * p.row_stride;
         const char *base = dbb + r0 * ROWB;
-        if ((t + 1) * 128 <= p.nrows) {      // whole tile in range (uniform): one 64-bit add per load
+        if ((t + 1) * DBR <= p.nrows) {      // whole tile in range (uniform): one 64-bit add per load
 #pragma unroll
             for (int u = 0; u < NLD; ++u)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + goff[u]),
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void scan_f16_qres_kernel(ScanParams p) {
 #pragma unroll
             for (int u = 0; u < NLD; ++u) {
                 // rows past the end: fetch the last row instead (their columns are masked by `nok`)
-                const bool ok = t * 128 + lrow[u] < p.nrows;
+                const bool ok = t * DBR + lrow[u] < p.nrows;
                 const char *src = ok ? base + goff[u] : dbb + last_row * ROWB + (goff[u] & (ROWB - 1));
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)&Bs[bb][(wave * NLD + u) * 256],
@@ -395,8 +399,8 @@ __global__ __launch_bounds__(256, 2) void scan_f16_qres_kernel(ScanParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b8[kk & 1][j], afr[i][kk], kk == 0 ? zero16 : acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        const int nvalid = (int)(p.nrows - t * 128 < 128 ? p.nrows - t * 128 : 128);
-        if (nvalid < 128) {              // last tile (uniform): db rows past the end never count
+        const int nvalid = (int)(p.nrows - t * DBR < DBR ? p.nrows - t * DBR : DBR);
+        if (nvalid < DBR) {              // last tile (uniform): db rows past the end never count
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void scan_f16_qres_kernel(ScanParams p) {
                     }
                     int pos = 0;
                     if (c > 0) pos = atomicAdd(&s_cnt[ml], c);       // one reservation for all of the lane's survivors
-                    const unsigned row0 = (unsigned)((t * 128 + wn * WN + j * 32 + 4 * lhalf) * p.row_stride);
+                    const unsigned row0 = (unsigned)((t * DBR + wn * WN + j * 32 + 4 * lhalf) * p.row_stride);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         if (anyg[g]) {
@@ -551,6 +555,11 @@ int launch_scan_f16(const void *dbh, int64_t n, int d, int64_t stride, const voi
         p.nsub = S;
         PF_HIP(hipMemsetAsync(ws.cnt, 0, sizeof(int) * nq * S, s));
         const dim3 grid((unsigned)(p.n_tiles_m * S));
+        // 64-row db tiles, three workgroups per CU (168 VGPRs) for the full pass: 2.97 -> 2.86 ms on the bench's 9728 x 1 M
+        // pass, back to back on one box (four per CU would need <= 128 VGPRs: 35 spilled); PFANN_SCAN_DBR128=1: the old tiles
+        static const bool dbr64 = getenv("PFANN_SCAN_DBR128") == nullptr;
+        if (d == 128 && dbr64 && stride == 1) PF_LAUNCH((scan_f16_qres_kernel<8, false, 64>), grid, dim3(256), 0, s, p);
+        else
         if (d == 128) PF_LAUNCH((scan_f16_qres_kernel<8>), grid, dim3(256), 0, s, p);
         else PF_LAUNCH((scan_f16_qres_kernel<4>), grid, dim3(256), 0, s, p);
     } else if (db_tiles * cdiv(p.n_tiles_m, 4) >= 4096)
