@@ -324,6 +324,11 @@ def embed_file_batches(engine, dataset, hop, batch_windows=4096, timer=None, nor
         in_flight.append((ev, release))
         while in_flight and in_flight[0][0].query():
             pool.put(in_flight.popleft()[1])
+        # back-pressure: this thread only enqueues work, so without a bound it would run the whole file list ahead of the
+        # GPU and pin every group's PCM at once (4.8 GB for 10 k songs); three groups in flight keep the GPU fed
+        while len(in_flight) > 3:
+            in_flight[0][0].synchronize()
+            pool.put(in_flight.popleft()[1])
         timer.resolve()
         yield out
     timer.resolve(wait=True)
