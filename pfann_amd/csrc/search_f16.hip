@@ -551,6 +551,8 @@ int launch_scan_f16(const void *dbh, int64_t n, int d, int64_t stride, const voi
         // S interleaved db slices: about four rounds of the 512 resident workgroups, sub-lists of >= 256
         int S = (int)(2048 / p.n_tiles_m);
         S = S < 1 ? 1 : (S > 32 ? 32 : S);
+        static const int s_env = getenv("PFANN_SCAN_S") ? atoi(getenv("PFANN_SCAN_S")) : 0;
+        if (s_env > 0) S = s_env;
         if (S > db_tiles) S = (int)db_tiles;
         p.nsub = S;
         PF_HIP(hipMemsetAsync(ws.cnt, 0, sizeof(int) * nq * S, s));
