@@ -108,7 +108,6 @@ struct RerankArgs {
     int *ncand;             // [nQ] scratch of the phased launch (few queries: scoring spread over the whole GPU)
     int phase;              // 0: whole query in one workgroup; 1: candidates; 2: scores; 3: argmax (1-3 need gkeys)
     pfann_match_result *results; float *song_scores;
-    int dbg;                // PFANN_MATCH_ABLATE bits (timing experiments only; results are garbage): 1 no sort, 2 no lookup, 4 no dedup
 };
 int launch_match(const RerankArgs &a, hipStream_t s);
 int launch_match_pack(const pfann_match_result *res, int64_t nQ, unsigned long long *keys, hipStream_t s);

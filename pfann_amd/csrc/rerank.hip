@@ -472,9 +472,7 @@ int launch_match_pick(const unsigned long long *keys, int G, int64_t nQ, pfann_m
     return 0;
 }
 
-int launch_match(const RerankArgs &a_in, hipStream_t s) {
-    RerankArgs a = a_in;
-    a.dbg = 0;
+int launch_match(const RerankArgs &a, hipStream_t s) {
     if (a.nQ <= 0) return 0;
     if (a.fsm < 1 || a.fsm > 32) { set_error("match: frame_shift_mul=%d outside 1..32", a.fsm); return -1; }
     if (a.n_songs >= (1 << 30)) { set_error("match: too many songs"); return -1; }
