@@ -564,7 +564,7 @@ def main():
     # roofline of the dominant kernel (most time in the timed region)
     ROOF = {"conv_gemm_ln_128": ("pfann::conv_gemm_ln_w22_kernel / conv_gemm_ln_kernel<128,128,64,32,...> (the 15 implicit-GEMM "
                                  "convs, 128x128 tiles, LayerNorm+ReLU of the input fused into the A-loader, LN statistics of the "
-                                 "output in the epilogue; the stride-2 layers -- 96 % of the time -- on the five-blocks-per-output-"
+                                 "output in the epilogue; the stride-2 layers -- 95 % of the flops -- on the five-blocks-per-output-"
                                  "pair kernel, incl. the one with the first conv folded in)", "mfma"),
             "conv_gemm_ln_64": ("pfann::conv_gemm_ln_kernel<64,64,32,32>", "mfma"),
             "conv_first_stats": ("pfann::conv_first_stats_kernel", "hbm"),
@@ -600,6 +600,12 @@ def main():
                     "flops_counted": "ALGORITHMIC: 2*M*N*K_live of the convolutions (SURVEY 8d); the five-block kernel executes "
                                      "5/6 of them on its layers, so the MFMA pipe itself is used at about 5/6 of `frac` there",
                     "share_of_step_time": round(kv["ms_per_step"] / (1e3 * elapsed / args.steps), 3)}
+        if dom == "conv_gemm_ln_128":
+            # the same launches priced two other ways: in MFMA work actually EXECUTED (the five-block kernel runs 5/6 of its
+            # layers' multiplies: 10 of the 15 launches, 95.4 % of the flops at the default model's shapes), and the
+            # whole step against SURVEY 8(d)'s whole-encoder count (0.58204 GFLOP per segment, dead taps included)
+            roofline["frac_in_executed_flops"] = round(ach / peak * (5.0 / 6.0 * 0.954 + 0.046), 4)
+            roofline["end_to_end_mfma_frac_survey_8d"] = round(value * ENC_FLOP_PER_SEG / (world * PEAK_F32_MFMA * 1e12), 4)
     # HBM-side traffic per launch of the dominant kernel, from the committed PMC passes of this
     # same command (tools/profile_bench.sh -> tools/make_traffic_json.py -> profiles/traffic.json)
     if roofline is not None:
