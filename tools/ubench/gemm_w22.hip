@@ -111,7 +111,9 @@ __global__ __launch_bounds__(512, 4) void kw(const float *__restrict__ x, const 
     for (int i = 0; i < 3; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     constexpr int NST = NSUB * (C / 32);
     issue(0, 0);
+    const unsigned long long t_p1 = __builtin_readcyclecounter();
     stash(0, As, Bs);
+    const unsigned long long t_p2 = __builtin_readcyclecounter();
     __syncthreads();
     // one sub-step: MFMAs on LDS buffer PB while sub-step st+1 goes global -> registers -> buffer PB^1
     auto substep = [&](int st, auto kindc, auto pbc) {
@@ -184,11 +186,13 @@ __global__ __launch_bounds__(512, 4) void kw(const float *__restrict__ x, const 
         }
     }
     __syncthreads();
+    const unsigned long long t_e1 = __builtin_readcyclecounter();
     for (int it = 0; it < 8; ++it) {
         const int row = it * 16 + wave * 2 + lhalf;
         const f32x4 v = *reinterpret_cast<const f32x4 *>(&Cs[row * LDC + l31 * 4]);
         st4(sy, (unsigned)row * (BN * 4u) + l31 * 16u, v);
     }
+    const unsigned long long t_e2 = __builtin_readcyclecounter();
     __syncthreads();
     float *red = smem + 128 * 132;
     for (int i = 0; i < 2; ++i) {
@@ -204,9 +208,11 @@ __global__ __launch_bounds__(512, 4) void kw(const float *__restrict__ x, const 
         if (lane == 0) { part[(blockIdx.x * 2 + wave) * 2] = t1; part[(blockIdx.x * 2 + wave) * 2 + 1] = t2; }
     }
     if (ts != nullptr && tid == 0) {
+        const unsigned long long t_e3 = __builtin_readcyclecounter();
         __builtin_amdgcn_s_waitcnt(0);
-        unsigned long long *o = ts + (size_t)blockIdx.x * 4;
+        unsigned long long *o = ts + (size_t)blockIdx.x * 10;
         o[0] = t_start; o[1] = t_loop0; o[2] = t_loop1; o[3] = __builtin_readcyclecounter();
+        o[4] = t_p1; o[5] = t_p2; o[6] = t_e1; o[7] = t_e2; o[8] = t_e3;
     }
 }
 
@@ -238,15 +244,22 @@ int main(int argc, char **argv) {
                    ms, flop / ms / 1e9, flop / ms / 1e9 / 157.3, hipGetErrorString(hipGetLastError()));
         }
     // per-tile phase stamps (shader clock cycles; two workgroups resident per CU)
-    unsigned long long *ts; (void)hipMalloc(&ts, (size_t)ntiles * 32);
-    unsigned long long *h = (unsigned long long *)malloc((size_t)ntiles * 32);
+    unsigned long long *ts; (void)hipMalloc(&ts, (size_t)ntiles * 80);
+    unsigned long long *h = (unsigned long long *)malloc((size_t)ntiles * 80);
     for (int mode = 1; mode >= 0; --mode) {
         auto kp = mode == 0 ? kw<0> : kw<1>;
         hipLaunchKernelGGL(kp, dim3(ntiles), dim3(512), lds, 0, x, lw, lb, w, stats, y, part, rps_out, ts); (void)hipDeviceSynchronize();
-        (void)hipMemcpy(h, ts, (size_t)ntiles * 32, hipMemcpyDeviceToHost);
-        double a = 0, b2 = 0, c2 = 0; int n = 0;
-        for (int i = ntiles / 4; i < ntiles * 3 / 4; ++i) { a += h[4 * i + 1] - h[4 * i]; b2 += h[4 * i + 2] - h[4 * i + 1]; c2 += h[4 * i + 3] - h[4 * i + 2]; ++n; }
+        (void)hipMemcpy(h, ts, (size_t)ntiles * 80, hipMemcpyDeviceToHost);
+        double a = 0, b2 = 0, c2 = 0, d[6] = {0, 0, 0, 0, 0, 0}; int n = 0;
+        for (int i = ntiles / 4; i < ntiles * 3 / 4; ++i) {
+            const unsigned long long *o = h + 10 * (size_t)i;
+            a += o[1] - o[0]; b2 += o[2] - o[1]; c2 += o[3] - o[2]; ++n;
+            d[0] += o[4] - o[0]; d[1] += o[5] - o[4]; d[2] += o[1] - o[5]; d[3] += o[6] - o[2]; d[4] += o[7] - o[6]; d[5] += o[8] - o[7];
+        }
         printf("%s per tile (cycles): prologue %.0f, loop %.0f, epilogue %.0f, total %.0f\n", mode == 0 ? "F(2,2)" : "plain ", a / n, b2 / n, c2 / n, (a + b2 + c2) / n);
+        printf("   prologue: set-up + first loads issued %.0f, loads arrive + transform + LDS refill %.0f, barrier %.0f\n", d[0] / n, d[1] / n, d[2] / n);
+        printf("   epilogue: C tile to LDS + barrier %.0f, row stores issued %.0f, barrier + statistics %.0f, wait for the stores %.0f\n",
+               d[3] / n, d[4] / n, d[5] / n, c2 / n - (d[3] + d[4] + d[5]) / n);
     }
     return 0;
 }
