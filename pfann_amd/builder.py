@@ -263,7 +263,9 @@ def embed_file_batches(engine, dataset, hop, batch_windows=4096, timer=None, nor
     ahead = max(4 * workers, 16) if ahead is None else ahead
     pool = _PinnedPool()
     in_flight = collections.deque()
-    if isinstance(dataset, MusicDataset) and workers > 0 and os.environ.get("PFANN_NATIVE_WAV", "1") != "0":
+    # the native reader only stands in for MusicDataset's OWN file reader: a subclass that decodes differently keeps its say
+    if isinstance(dataset, MusicDataset) and type(dataset).load_pcm_sr is MusicDataset.load_pcm_sr and workers > 0 and \
+            os.environ.get("PFANN_NATIVE_WAV", "1") != "0":
         source = _native_groups(engine, dataset, hop, batch_windows, pool, workers)
     else:
         source = _threaded_groups(engine, dataset, hop, batch_windows, pool, workers, ahead)
