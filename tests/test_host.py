@@ -396,3 +396,30 @@ def test_native_wav_loader_groups_and_slabs(tmp_path):
             assert not any(i in (20, 21) for i in ids)
     assert seen == list(range(23))
     assert calls == [(want[20].shape[0], 2)]
+
+
+def test_cli_bench_helpers(tmp_path):
+    """tools/cli_bench.py host pieces: its WAV writer produces files the `wave` module (the reference's reader,
+    audio.py:130-149) and the library's native reader agree on; the stage-line parser reads what the CLIs print."""
+    import ctypes
+    import wave
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import cli_bench
+    from pfann_amd import lib as L
+    pcm = (np.arange(3 * 12345, dtype=np.int64) * 7919 % 60000 - 30000).astype(np.int16).reshape(3, 12345)
+    paths = [str(tmp_path / ("c%d.wav" % i)) for i in range(3)]
+    cli_bench.write_wavs(paths, pcm)
+    for i, p in enumerate(paths):
+        with wave.open(p) as w:
+            assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (1, 2, 8000, 12345)
+            assert np.array_equal(np.frombuffer(w.readframes(12345), np.int16), pcm[i])
+    lib = L.load()
+    info = (L.WavInfo * 3)()
+    arr = (ctypes.c_char_p * 3)(*[os.fsencode(p) for p in paths])
+    assert lib.pfann_wav_probe(arr, 3, 2, info) == 0
+    assert [(i.status, i.n_frames, i.n_ch, i.sample_rate, i.data_pos) for i in info] == [(0, 12345, 1, 8000, 44)] * 3
+    out = "loading model...\nload 0.270000s\nstereo to mono 0.027600s\ncompute embedding 2.423200s\ntotal build time 2.870s\n"
+    stages, total = cli_bench.parse_stdout(out)
+    assert total == 2.87 and stages == {"load": 0.27, "stereo to mono": 0.0276, "compute embedding": 2.4232}
+    stages, total = cli_bench.parse_stdout("search 0.019200s\nrerank 0.003900s\noutput answer 0.029600s\ntotal query time 0.390000s\n")
+    assert total == 0.39 and set(stages) == {"search", "rerank", "output answer"}
