@@ -40,7 +40,7 @@ __global__ void fill(float *p, size_t n, float scale, float bias) {
 template <int MODE>
 __global__ __launch_bounds__(512, 4) void kw(const float *__restrict__ x, const float *__restrict__ lw, const float *__restrict__ lb,
                                              const float *__restrict__ w, const float *__restrict__ stats, float *__restrict__ y,
-                                             float *__restrict__ part, int rps_out, unsigned long long *ts) {
+                                             float *__restrict__ part, int rps_out, unsigned long long *ts, int hot) {
     constexpr int LDK = 36, BM = 128, BN = 128, C = 128;
     constexpr int NSUB = MODE == 0 ? 4 : 3;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -52,7 +52,9 @@ __global__ __launch_bounds__(512, 4) void kw(const float *__restrict__ x, const 
     const int b = m0 / rps_out, r0 = m0 % rps_out;
     const int rps_in = 2 * rps_out;
     const float mu = stats[2 * b], rs = stats[2 * b + 1];
-    const __amdgpu_buffer_rsrc_t sx = srd(x + (int64_t)b * rps_in * C, (uint64_t)rps_in * C * 4);
+    // hot != 0: every tile reads the activations of sample (b % hot) -- an L2-resident operand, to see how much of the
+    // tile time is HBM latency of the activation loads
+    const __amdgpu_buffer_rsrc_t sx = srd(x + (int64_t)(hot ? b % hot : b) * rps_in * C, (uint64_t)rps_in * C * 4);
     const __amdgpu_buffer_rsrc_t slw = srd(lw, (uint64_t)rps_in * C * 4), slb = srd(lb, (uint64_t)rps_in * C * 4);
     const __amdgpu_buffer_rsrc_t sw = srd(w, (uint64_t)BN * 4 * C * 4);
     auto off = [&](int inrow) { return (unsigned)inrow < (unsigned)rps_in ? (unsigned)((inrow * C + col4 * 4) * 4) : 0x80000000u; };
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(512, 4) void kw(const float *__restrict__ x, const 
 }
 
 int main(int argc, char **argv) {
-    const int rps_out = 1024, B = argc > 1 ? atoi(argv[1]) : 2048;
+    const int rps_out = 1024, B = argc > 1 ? atoi(argv[1]) : 2048, hot = argc > 2 ? atoi(argv[2]) : 0;
     const int64_t M = (int64_t)B * rps_out;
     const int ntiles = (int)(M / 128);
     float *x, *lw, *lb, *w, *stats, *y, *part;
@@ -235,9 +237,9 @@ int main(int argc, char **argv) {
             auto kp = mode == 0 ? kw<0> : kw<1>;
             (void)hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-            hipLaunchKernelGGL(kp, dim3(ntiles), dim3(512), lds, 0, x, lw, lb, w, stats, y, part, rps_out, nullptr); (void)hipDeviceSynchronize();
+            hipLaunchKernelGGL(kp, dim3(ntiles), dim3(512), lds, 0, x, lw, lb, w, stats, y, part, rps_out, nullptr, hot); (void)hipDeviceSynchronize();
             (void)hipEventRecord(e0);
-            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kp, dim3(ntiles), dim3(512), lds, 0, x, lw, lb, w, stats, y, part, rps_out, nullptr);
+            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kp, dim3(ntiles), dim3(512), lds, 0, x, lw, lb, w, stats, y, part, rps_out, nullptr, hot);
             (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 3;
             printf("%-64s %8.3f ms  %6.1f TFLOP/s (algorithmic)  %.3f  %s\n",
                    mode == 0 ? "F(2,2): 5 blocks per output pair, 4 sub-steps per chunk" : "plain: 6 blocks per output pair, 3 sub-steps per chunk",
@@ -248,7 +250,7 @@ int main(int argc, char **argv) {
     unsigned long long *h = (unsigned long long *)malloc((size_t)ntiles * 80);
     for (int mode = 1; mode >= 0; --mode) {
         auto kp = mode == 0 ? kw<0> : kw<1>;
-        hipLaunchKernelGGL(kp, dim3(ntiles), dim3(512), lds, 0, x, lw, lb, w, stats, y, part, rps_out, ts); (void)hipDeviceSynchronize();
+        hipLaunchKernelGGL(kp, dim3(ntiles), dim3(512), lds, 0, x, lw, lb, w, stats, y, part, rps_out, ts, hot); (void)hipDeviceSynchronize();
         (void)hipMemcpy(h, ts, (size_t)ntiles * 80, hipMemcpyDeviceToHost);
         double a = 0, b2 = 0, c2 = 0, d[6] = {0, 0, 0, 0, 0, 0}; int n = 0;
         for (int i = ntiles / 4; i < ntiles * 3 / 4; ++i) {
