@@ -286,10 +286,41 @@ __global__ __launch_bounds__(256, 2) void scan_small_kernel(ScanParams p) {
         __syncthreads();
     }
     f32x4 qa[NP];
+    if (MODE == 1 && ELT == 2 && p.q32 != nullptr) {
+        // query preparation folded in (q_prep_kernel's job, one launch less): fp16 image of the fp32 query rows -- this lane's
+        // fragment is elements 16 j + 8 lhalf .. + 7 of row l31 --, the row's error bound eps and the out-of-range flag
+        float ss = 0.f;
+        f32x4 lo[NP], hi[NP];
 #pragma unroll
-    for (int j = 0; j < NP; ++j)
-        qa[j] = l31 < p.nq ? *reinterpret_cast<const f32x4 *>(qb + (int64_t)l31 * RB + j * 32 + lhalf * 16)
-                           : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NP; ++j) {
+            const float *src = p.q32 + (int64_t)l31 * D + j * 16 + lhalf * 8;
+            lo[j] = l31 < p.nq ? *reinterpret_cast<const f32x4 *>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+            hi[j] = l31 < p.nq ? *reinterpret_cast<const f32x4 *>(src + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ss = fmaf(lo[j][e], lo[j][e], ss); ss = fmaf(hi[j][e], hi[j][e], ss); }
+        }
+        ss += __shfl_xor(ss, 32, 64);
+        const bool bad = !(ss < 3.6e9f);                   // ||q|| >= 6e4 or NaN: outside fp16's range
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            f16x8 h8;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { h8[e] = bad ? (_Float16)0.f : (_Float16)lo[j][e]; h8[4 + e] = bad ? (_Float16)0.f : (_Float16)hi[j][e]; }
+            qa[j] = __builtin_bit_cast(f32x4, h8);
+            if (gw == 0 && l31 < p.nq)
+                *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(p.qh_out) + (int64_t)l31 * RB + j * 32 + lhalf * 16) = qa[j];
+        }
+        if (gw == 0 && lhalf == 0 && l31 < p.nq) {
+            const float nq2 = sqrtf(ss);
+            p.eps[l31] = 1.05e-3f * nq2 * p.xnorm_max + 3.1e-8f * sqrtf((float)D) * (nq2 + p.xnorm_max);
+            if (bad) p.row_ovf[l31] = 1;                   // recomputed exactly by the fallback
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+            qa[j] = l31 < p.nq ? *reinterpret_cast<const f32x4 *>(qb + (int64_t)l31 * RB + j * 32 + lhalf * 16)
+                               : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     for (int64_t pi = 0; pi < n_pieces; ++pi) {
         const int64_t r0 = piece_lo(pi), r_hi = piece_hi(pi);
         // registers -> wave-private LDS tile (the previous tile's fragment reads are complete: their
@@ -399,13 +430,15 @@ __global__ __launch_bounds__(256, 2) void scan_small_kernel(ScanParams p) {
 __global__ __launch_bounds__(256) void group_max_select_kernel(const float *__restrict__ gmax, int G, int k,
                                                                float *__restrict__ thr, int *__restrict__ cnt, int ncnt,
                                                                const float *__restrict__ eps, float *__restrict__ thr_adj,
-                                                               float margin, float *__restrict__ topm, int mtop, float margin_out) {
+                                                               float margin, float *__restrict__ topm, int mtop, float margin_out,
+                                                               int *zero_me) {
     constexpr int GMAX = 4096;
     __shared__ unsigned sv[GMAX];
     __shared__ int hist[256];
     __shared__ int s_bin, s_kk, s_n;
     const int64_t m = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (zero_me != nullptr && m == 0 && tid == 0) *zero_me = 0;      // the select's overflow counter (one memset less)
     for (int i = tid; i < ncnt; i += 256) cnt[m * ncnt + i] = 0;
     for (int i = tid; i < G; i += 256) sv[i] = ~f2ord(gmax[m * G + i]);          // ascending = descending score
     __syncthreads();
@@ -474,10 +507,10 @@ __global__ __launch_bounds__(256) void group_max_select_kernel(const float *__re
 }
 
 int launch_group_max_select(SearchWorkspace &ws, int64_t nq, int G, int k, int ncnt, bool with_eps, float margin, hipStream_t s,
-                            float *topm = nullptr, int mtop = 0, float margin_out = 0.f) {
+                            float *topm = nullptr, int mtop = 0, float margin_out = 0.f, int *zero_me = nullptr) {
     ProfScope ps("topk_group_select", s);
     PF_LAUNCH(group_max_select_kernel, dim3((unsigned)nq), dim3(256), 0, s, reinterpret_cast<const float *>(ws.cl), G, k, ws.thr,
-              ws.cnt, ncnt, with_eps ? ws.eps : nullptr, ws.thr_adj, margin, topm, mtop, margin_out);
+              ws.cnt, ncnt, with_eps ? ws.eps : nullptr, ws.thr_adj, margin, topm, mtop, margin_out, zero_me);
     PF_HIP(hipGetLastError());
     return 0;
 }
@@ -496,71 +529,9 @@ __global__ __launch_bounds__(256) void topk_fallback_kernel(int *__restrict__ ro
                                                             const void *__restrict__ dbv, int64_t n, int d, int k,
                                                             float *__restrict__ D, int64_t *__restrict__ I,
                                                             int64_t label_base) {
-    constexpr int FB = 2048, RPP = 128;           // buffer slots; rows per pass (32 row groups x 4)
-    __shared__ unsigned long long buf[FB];
-    __shared__ float qs[1024];
-    __shared__ int s_cnt;
-    __shared__ unsigned long long s_T;
-    const int64_t m = blockIdx.x;
-    if (row_ovf[m] == 0) return;
-    const int tid = threadIdx.x, sub = tid & 7, grp = tid >> 3;
-    for (int e = tid; e < d; e += 256) qs[e] = ELT == 4 ? q[m * d + e] : (float)(_Float16)q[m * d + e];
-    if (tid == 0) { s_cnt = 0; s_T = ~0ull; }
-    __syncthreads();
-    for (int64_t base = 0; base < n; base += RPP) {
-        const unsigned long long T = s_T;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t row = base + u * 32 + grp;
-            float part = 0.f;
-            if (row < n) {
-                for (int e = sub * 4; e < d; e += 32) {
-                    float x0, x1, x2, x3;
-                    if (ELT == 4) {
-                        const float4 x4 = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(dbv) + row * d + e);
-                        x0 = x4.x; x1 = x4.y; x2 = x4.z; x3 = x4.w;
-                    } else {
-                        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-                        const f16x4 h4 = *reinterpret_cast<const f16x4 *>(reinterpret_cast<const _Float16 *>(dbv) + row * d + e);
-                        x0 = (float)h4[0]; x1 = (float)h4[1]; x2 = (float)h4[2]; x3 = (float)h4[3];
-                    }
-                    part = fmaf(x0, qs[e], part); part = fmaf(x1, qs[e + 1], part);
-                    part = fmaf(x2, qs[e + 2], part); part = fmaf(x3, qs[e + 3], part);
-                }
-            }
-            part += __shfl_xor(part, 1, 64);
-            part += __shfl_xor(part, 2, 64);
-            part += __shfl_xor(part, 4, 64);
-            if (sub == 0 && row < n) {
-                const unsigned long long key = pack_key(part, (unsigned)row);
-                if (key < T) buf[atomicAdd(&s_cnt, 1)] = key;       // s_cnt <= FB - RPP before the pass
-            }
-        }
-        __syncthreads();
-        if (s_cnt > FB - RPP || base + RPP >= n) {                    // block-uniform
-            const int c = s_cnt;
-            for (int i = c + tid; i < FB; i += 256) buf[i] = ~0ull;
-            __syncthreads();
-            bitonic_sort_u64(buf, FB, tid, 256);
-            if (tid == 0) {
-                s_cnt = c < k ? c : k;
-                s_T = c >= k ? buf[k - 1] : ~0ull;
-            }
-            __syncthreads();
-        }
-    }
-    const int c = s_cnt;
-    for (int i = tid; i < k; i += 256) {
-        if (i < c) {
-            D[m * k + i] = ord2f(~(unsigned)(buf[i] >> 32));
-            I[m * k + i] = (int64_t)(unsigned)(buf[i] & 0xFFFFFFFFu) + label_base;
-        } else {
-            D[m * k + i] = -3.4028234663852886e38f;
-            I[m * k + i] = -1;
-        }
-    }
-    if (tid == 0) row_ovf[m] = 0;
+    topk_fallback_body<ELT, 256>(blockIdx.x, row_ovf, q, dbv, n, d, k, D, I, label_base);
 }
+
 
 int launch_topk_fallback(SearchWorkspace &ws, const float *q, const float *db, const void *dbh, int64_t n, int d,
                          int64_t nq, int k, float *D, int64_t *I, int64_t label_base, hipStream_t s) {
@@ -729,9 +700,19 @@ __global__ void fill_empty_kernel(float *D, int64_t *I, int64_t total) {
 // Four short launches around the one pass that reads the shard; no host synchronisation.
 // db32 != nullptr with ELT == 2: `rows` is the fp16 copy of an fp32 shard -- the scan is a pre-filter with the rigorous
 // margin of q_prep_kernel (half the bytes of the fp32 pass), the select re-scores in exact fp32 like the batched path.
+// d = 128 and n > CAP: five launches instead of eight -- query preparation at the head of the group-maximum pass, the
+// select's counter zeroed by the group select, big select + exact fallback (both normally idle) in one launch.
+// PFANN_NO_FOLDED_SMALL=1: one launch per stage, as for d = 64.  (Going further -- the group select / the select as the
+// tail of the pass before it, run by workgroups 0 .. nq-1 once every workgroup has arrived -- was built and measured:
+// the in-kernel hand-over costs what the launch it replaces costs, 85.7 vs 82.6 us per call; profiles/r3/NOTES.md.)
+static bool folded_small_path(int d) {
+    static const bool off = getenv("PFANN_NO_FOLDED_SMALL") != nullptr;
+    return d == 128 && !off;
+}
+
 template <int ELT>
 static int search_small(const void *rows, int64_t n, int d, const void *qrows, int64_t nq, int k, float *D, int64_t *I,
-                        int64_t label_base, const float *q32, const float *db32, SearchWorkspace &ws, hipStream_t s) {
+                        int64_t label_base, const float *q32, const float *db32, float xnorm_max, SearchWorkspace &ws, hipStream_t s) {
     const bool prefilter = ELT == 2 && db32 != nullptr;
     ScanParams p;
     p.q = reinterpret_cast<const float *>(qrows); p.db = reinterpret_cast<const float *>(rows);
@@ -758,18 +739,25 @@ static int search_small(const void *rows, int64_t n, int d, const void *qrows, i
     if (R > n / W) R = n / W;                          // at least one sampled row per group (n > CAP = 4 W)
     p.row_stride = R; p.nrows = (n + R - 1) / R; p.nsub = 1;
     p.gmax = reinterpret_cast<float *>(ws.cl);         // [nq][W] floats; the keys are written after tau is known
+    const bool folded = folded_small_path(d);
+    if (folded && ELT == 2) { p.q32 = q32; p.xnorm_max = xnorm_max; p.qh_out = ws.qh; p.eps = ws.eps; p.row_ovf = ws.row_ovf; }
     {
         ProfScope ps("scan_topk_sample", s, p.nrows * bytes_per_row);
         PF_SMALL(1, GRID);
     }
-    if (launch_group_max_select(ws, nq, W, k, 32, prefilter, prefilter ? 2.f : 0.f, s)) return -1;
-    p.row_stride = 1; p.nrows = n; p.nsub = 32; p.thr = prefilter ? ws.thr_adj : ws.thr; p.gmax = nullptr;
+    if (launch_group_max_select(ws, nq, W, k, 32, prefilter, prefilter ? 2.f : 0.f, s, nullptr, 0, 0.f,
+                                folded ? ws.overflow + 1 : nullptr)) return -1;
+    p.row_stride = 1; p.nrows = n; p.nsub = 32; p.thr = prefilter ? ws.thr_adj : ws.thr; p.gmax = nullptr; p.q32 = nullptr;
     {
         ProfScope ps("scan_topk", s, n * bytes_per_row);
         PF_SMALL(0, GRID);
     }
 #undef PF_SMALL
-    return launch_select_rescore(ws, nq, k, 1, D, I, label_base, q32, db32, d, 32, prefilter ? 1 : 0, s);
+    if (!folded) return launch_select_rescore(ws, nq, k, 1, D, I, label_base, q32, db32, d, 32, prefilter ? 1 : 0, s);
+    if (launch_select_rescore_small(ws, nq, k, D, I, label_base, q32, db32, d, 32, prefilter ? 1 : 0, s)) return -1;
+    // the fallback streams the exact rows: fp32 where the shard has them
+    return launch_select_tail(ws, nq, k, D, I, label_base, q32, db32, ELT == 4 ? rows : (db32 ? (const void *)db32 : rows),
+                              db32 != nullptr || ELT == 4 ? 4 : 2, n, d, 32, prefilter ? 1 : 0, s);
 }
 
 // phase 1 on a path without a sampled threshold: no information
@@ -820,15 +808,18 @@ int search_topk(const float *db, const void *dbh, float xnorm_max, int64_t n, in
             PF_HIP(hipMalloc(&ws.qh, (size_t)nq * d * 2));
             ws.qh_elems = nq * d;
         }
-        if (!resume && launch_q_prep(q, nq, d, xnorm_max, ws.qh, ws.eps, ws.row_ovf, s)) return -1;
+        // (the folded small path prepares the query rows at the head of its group-maximum pass)
+        const bool prep_in_scan = small && phase != 1 && n > CAP && folded_small_path(d);
+        if (!resume && !prep_in_scan && launch_q_prep(q, nq, d, xnorm_max, ws.qh, ws.eps, ws.row_ovf, s)) return -1;
     }
     if (small) {
         if (phase == 1) return no_bound();
         int rc;
-        if (half_only) rc = search_small<2>(dbh, n, d, ws.qh, nq, k, D, I, label_base, q, nullptr, ws, s);
-        else if (small_pre) rc = search_small<2>(dbh, n, d, ws.qh, nq, k, D, I, label_base, q, db, ws, s);
-        else rc = search_small<4>(db, n, d, q, nq, k, D, I, label_base, q, nullptr, ws, s);
+        if (half_only) rc = search_small<2>(dbh, n, d, ws.qh, nq, k, D, I, label_base, q, nullptr, xnorm_max, ws, s);
+        else if (small_pre) rc = search_small<2>(dbh, n, d, ws.qh, nq, k, D, I, label_base, q, db, xnorm_max, ws, s);
+        else rc = search_small<4>(db, n, d, q, nq, k, D, I, label_base, q, nullptr, xnorm_max, ws, s);
         if (rc) return rc;
+        if (n > CAP && folded_small_path(d)) return 0;         // the fallback ran inside search_small's last launch
         return launch_topk_fallback(ws, q, db, dbh, n, d, nq, k, D, I, label_base, s);
     }
     // ---- generic ladder: the shard is scanned at strides R^L .. R, 1; the coarsest level keeps everything

@@ -689,27 +689,40 @@ __global__ __launch_bounds__(256) void select_rescore_small_kernel(const unsigne
         __syncthreads();
     }
     const int n2 = s_n2;
-    // exact fp32 scores: 4 threads per candidate, 64 candidates in flight per pass
+    // exact fp32 scores: 4 threads per candidate (fixed reduction order), 4 x 64 candidates in flight per pass.  A
+    // candidate's four lanes sit in one wave, so its key is read before it is replaced in program order: no barrier
     const float *qv = q32 + m * d;
     if (rescore)
-    for (int c0 = 0; c0 < n2; c0 += NT / 4) {
-        const int c = c0 + (tid >> 2), sub = tid & 3;
-        float part = 0.f;
-        unsigned row = 0;
-        if (c < n2) {
-            row = (unsigned)(skeys[c] & 0xFFFFFFFFull);
-            const float *xv = db32 + (int64_t)row * d;
-            for (int e = sub * 4; e < d; e += 16) {
-                const float4 x4 = *reinterpret_cast<const float4 *>(xv + e);
-                const float4 q4 = *reinterpret_cast<const float4 *>(qv + e);
-                part = fmaf(x4.x, q4.x, part); part = fmaf(x4.y, q4.y, part);
-                part = fmaf(x4.z, q4.z, part); part = fmaf(x4.w, q4.w, part);
+    for (int c0 = 0; c0 < n2; c0 += NT) {
+        float part[4];
+        unsigned row[4];
+        const int sub = tid & 3;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * (NT / 4) + (tid >> 2);
+            row[u] = c < n2 ? (unsigned)(skeys[c] & 0xFFFFFFFFull) : 0u;
+            part[u] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * (NT / 4) + (tid >> 2);
+            if (c < n2) {
+                const float *xv = db32 + (int64_t)row[u] * d;
+                for (int e = sub * 4; e < d; e += 16) {
+                    const float4 x4 = *reinterpret_cast<const float4 *>(xv + e);
+                    const float4 q4 = *reinterpret_cast<const float4 *>(qv + e);
+                    part[u] = fmaf(x4.x, q4.x, part[u]); part[u] = fmaf(x4.y, q4.y, part[u]);
+                    part[u] = fmaf(x4.z, q4.z, part[u]); part[u] = fmaf(x4.w, q4.w, part[u]);
+                }
             }
         }
-        part += __shfl_xor(part, 1, 64);
-        part += __shfl_xor(part, 2, 64);
-        __syncthreads();                              // every lane has read its key before it is replaced
-        if (c < n2 && sub == 0) skeys[c] = pack_key(part, row);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * (NT / 4) + (tid >> 2);
+            part[u] += __shfl_xor(part[u], 1, 64);
+            part[u] += __shfl_xor(part[u], 2, 64);
+            if (c < n2 && sub == 0) skeys[c] = pack_key(part[u], row[u]);
+        }
     }
     __syncthreads();
     // rank sort (keys are unique: they contain the row)
@@ -757,15 +770,15 @@ __global__ __launch_bounds__(256) void select_rescore_small_kernel(const unsigne
 //   mode 0: thr[m] = exact k-th best (or -inf), thr_adj[m] = thr[m] - eps[m]
 //   mode 1: D, I = exact top-k;  list overflow -> overflow flag (+ raised thresholds)
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void select_rescore_kernel(const unsigned long long *__restrict__ keys,
-                                                              const int *__restrict__ cnt, int k, int mode,
-                                                              float *__restrict__ thr, float *__restrict__ thr_adj,
-                                                              const float *__restrict__ eps, float *__restrict__ D,
-                                                              int64_t *__restrict__ I, int64_t label_base,
-                                                              int *overflow, int *__restrict__ row_ovf,
-                                                              const float *__restrict__ q32,
-                                                              const float *__restrict__ db32, int d, int nsub,
-                                                              int skip_small, int rescore) {
+__device__ inline void select_rescore_body(const unsigned long long *__restrict__ keys,
+                                           const int *__restrict__ cnt, int k, int mode,
+                                           float *__restrict__ thr, float *__restrict__ thr_adj,
+                                           const float *__restrict__ eps, float *__restrict__ D,
+                                           int64_t *__restrict__ I, int64_t label_base,
+                                           int *overflow, int *row_ovf,
+                                           const float *__restrict__ q32,
+                                           const float *__restrict__ db32, int d, int nsub,
+                                           int skip_small, int rescore) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
     __shared__ int s_n2;
     __shared__ int s_off[66];
@@ -934,6 +947,60 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(const unsigned lon
             }
         }
     }
+}
+
+__global__ __launch_bounds__(1024) void select_rescore_kernel(const unsigned long long *__restrict__ keys,
+                                                              const int *__restrict__ cnt, int k, int mode,
+                                                              float *__restrict__ thr, float *__restrict__ thr_adj,
+                                                              const float *__restrict__ eps, float *__restrict__ D,
+                                                              int64_t *__restrict__ I, int64_t label_base,
+                                                              int *overflow, int *__restrict__ row_ovf,
+                                                              const float *__restrict__ q32,
+                                                              const float *__restrict__ db32, int d, int nsub,
+                                                              int skip_small, int rescore) {
+    select_rescore_body(keys, cnt, k, mode, thr, thr_adj, eps, D, I, label_base, overflow, row_ovf, q32, db32, d, nsub, skip_small, rescore);
+}
+
+// Last launch of the small-batch search (search.hip, search_small): the rows select_rescore_small_kernel left (more than
+// SMALL_N survivors; normally none: returns after one 4-byte read) and, behind it, the exact fallback for flagged rows
+// (normally none either) -- two launches' worth of "nothing to do" in one.  FB_ELT: element size of the fallback's rows.
+template <int FB_ELT>
+__global__ __launch_bounds__(1024) void select_tail_kernel(const unsigned long long *__restrict__ keys, const int *__restrict__ cnt, int k,
+                                                           float *__restrict__ thr, float *__restrict__ thr_adj,
+                                                           const float *__restrict__ eps, float *D, int64_t *I, int64_t label_base,
+                                                           int *overflow, int *row_ovf, const float *__restrict__ q32,
+                                                           const float *__restrict__ db32, int d, int nsub, int rescore,
+                                                           const void *__restrict__ fb_rows, int64_t n) {
+    select_rescore_body(keys, cnt, k, 1, thr, thr_adj, eps, D, I, label_base, overflow, row_ovf, q32, db32, d, nsub, 1, rescore);
+    __syncthreads();
+    topk_fallback_body<FB_ELT, 1024>(blockIdx.x, row_ovf, q32, fb_rows, n, d, k, D, I, label_base);
+}
+
+int launch_select_tail(SearchWorkspace &ws, int64_t nq, int k, float *D, int64_t *I, int64_t label_base, const float *q32,
+                       const float *db32, const void *fb_rows, int fb_elt, int64_t n, int d, int nsub, int rescore, hipStream_t s) {
+    if (d > 1024) { set_error("search_topk: d=%d > 1024", d); return -1; }
+    const void *fn = fb_elt == 4 ? (const void *)select_tail_kernel<4> : (const void *)select_tail_kernel<2>;
+    if (ensure_dyn_lds(fn, CAP * 8)) return -1;
+    ProfScope ps("topk_select_tail", s);
+    if (fb_elt == 4)
+        PF_LAUNCH(select_tail_kernel<4>, dim3((unsigned)nq), dim3(1024), CAP * 8, s, reinterpret_cast<const unsigned long long *>(ws.cl),
+                  ws.cnt, k, ws.thr, ws.thr_adj, ws.eps, D, I, label_base, ws.overflow, ws.row_ovf, q32, db32, d, nsub, rescore, fb_rows, n);
+    else
+        PF_LAUNCH(select_tail_kernel<2>, dim3((unsigned)nq), dim3(1024), CAP * 8, s, reinterpret_cast<const unsigned long long *>(ws.cl),
+                  ws.cnt, k, ws.thr, ws.thr_adj, ws.eps, D, I, label_base, ws.overflow, ws.row_ovf, q32, db32, d, nsub, rescore, fb_rows, n);
+    PF_HIP(hipGetLastError());
+    return 0;
+}
+
+// small-batch path: ws.overflow[1] was zeroed by the group select; the rows this kernel leaves go to launch_select_tail
+int launch_select_rescore_small(SearchWorkspace &ws, int64_t nq, int k, float *D, int64_t *I, int64_t label_base,
+                                const float *q32, const float *db32, int d, int nsub, int rescore, hipStream_t s) {
+    ProfScope ps(rescore ? "topk_select_rescore" : "topk_select_radix", s);
+    PF_LAUNCH(select_rescore_small_kernel, dim3((unsigned)nq), dim3(256), 0, s,
+              reinterpret_cast<const unsigned long long *>(ws.cl), ws.cnt, k, 1, ws.thr, ws.thr_adj, ws.eps, D,
+              I, label_base, ws.overflow, ws.row_ovf, q32, db32, d, nsub, rescore);
+    PF_HIP(hipGetLastError());
+    return 0;
 }
 
 int launch_select_rescore(SearchWorkspace &ws, int64_t nq, int k, int mode, float *D, int64_t *I, int64_t label_base,
