@@ -180,6 +180,7 @@ def main():
                     help="0: exact fp32 MFMA (default, the headline); 1: opt-in 3-term fp16 split (pfann_set_encoder_precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the informational fp16-storage run")
+    ap.add_argument("--serial", action="store_true", help="time the K batches strictly one at a time instead of two deep")
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--launch-check", action="store_true",
                     help="only start the ranks, meet in the process group, print who is there (n_gpus, ranks_seen, backend, "
@@ -397,6 +398,52 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- the timed loop, two batches deep, as a serving loop (and the matcher CLI, pfann_amd/matcher.py) runs the
+    # path: the H2D of batch i+1 goes on a side stream under the kernels of batch i, and the decisions of batch i are read
+    # on the host after batch i+1 has been launched.  Every batch still does everything (H2D of its PCM, all kernels, D2H
+    # of its decisions) inside the timed region; only the host's waits are overlapped.  --serial: one batch at a time.
+    class TwoDeep:
+        def __init__(self, w):
+            self.w = w
+            self.cs = torch.cuda.Stream(device=dev)
+            self.bufs = [torch.empty_like(w["pcm_dev"]) for _ in range(2)]
+            self.up = [torch.cuda.Event() for _ in range(2)]         # upload of the buffer complete
+            self.used = [torch.cuda.Event() for _ in range(2)]       # buffer consumed (mono conversion issued behind it)
+
+        def upload(self, i):
+            with torch.cuda.stream(self.cs):
+                self.bufs[i & 1].copy_(self.w["pcm_host"], non_blocking=True)
+                self.up[i & 1].record(self.cs)
+
+        def launch(self, i):
+            w = self.w
+            torch.cuda.current_stream().wait_event(self.up[i & 1])
+            wav = eng.pcm16_to_mono(self.bufs[i & 1])
+            self.used[i & 1].record()
+            e = eng.embed_windows(wav, w["starts"])
+            if use_sharded:
+                e = all_gather_ragged(e, w["q_counts"])
+                return sharded.query_batch(e, w["qstart"], w["qlen"], to_host=False), e
+            D, I = cur_index[0].search(e, k)
+            r, _ = cur_index[0].match(e, I, w["qstart"], w["qlen"], to_host=False)
+            return r, e
+
+        def run(self, n):
+            self.upload(0)
+            pend = res = e = None
+            for i in range(n):
+                r, e = self.launch(i)
+                if i + 1 < n:
+                    if i >= 1:
+                        self.cs.wait_event(self.used[(i + 1) & 1])   # batch i-1 has consumed the buffer batch i+1 lands in
+                    self.upload(i + 1)
+                if pend is not None:
+                    res = index.results_to_host(pend)
+                pend = r
+            if pend is not None:
+                res = index.results_to_host(pend)
+            return res, e
+
     def max_over_ranks(sec):
         if not in_group:
             return sec
@@ -411,11 +458,17 @@ def main():
     if prof:
         lib.pfann_prof_reset()
         lib.pfann_prof_enable(1)
+    two_deep = None if (args.serial or emu > 1) else TwoDeep(main_w)
+    if two_deep is not None:
+        two_deep.run(2)
     fence()
     lib.pfann_prof_marker(None)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res, emb = step()
+    if two_deep is not None:
+        res, emb = two_deep.run(args.steps)
+    else:
+        for _ in range(args.steps):
+            res, emb = step()
     fence()
     elapsed = time.perf_counter() - t0
     lib.pfann_prof_marker(None)
@@ -424,6 +477,20 @@ def main():
     elapsed = max_over_ranks(elapsed)
     n_seg = Q * QUERY_SEGS
     value = n_seg * args.steps / elapsed
+
+    # ---- the same K batches one at a time (H2D, kernels, D2H, host wait; then the next): what `value` was through round 3's
+    # first half, kept for comparison
+    serial = None
+    if two_deep is not None:
+        fence()
+        tp = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        el = max_over_ranks(time.perf_counter() - tp)
+        serial = {"value": round(n_seg * args.steps / el, 1), "unit": "segments/s", "ms_per_step": round(1e3 * el / args.steps, 3),
+                  "what": "the same batches strictly one at a time: the host waits for batch i's decisions before it starts "
+                          "the H2D of batch i+1"}
 
     # ---- the same step with the query PCM already resident in HBM (reported beside `value`)
     pcie = None
@@ -776,6 +843,11 @@ def main():
                         "windows -> log-mel -> encoder -> unit-norm fingerprints in HBM (builder.py:75-103's loop), "
                         "%d windows per launch group" % args.max_batch},
             "value_includes": "H2D of the query PCM from pinned host memory (SURVEY 8d: PCM-in-host-memory to decisions)",
+            "step_overlap": ("none: one batch at a time" if two_deep is None else
+                             "two batches deep: the H2D of batch i+1 runs on a side stream under the kernels of batch i and the "
+                             "host reads batch i's decisions after launching batch i+1; all K batches' H2D, kernels and D2H lie "
+                             "inside the timed region"),
+            "serial": serial,
             "hbm_resident": pcie, "seq_score_seam": seam_info, "cli": cli,
             "alt_modes": alt, "other_scaling_mode": other_mode,
             "kernels": {t: {kk: (float("%.4g" % vv) if isinstance(vv, float) else vv) for kk, vv in v.items()}

@@ -33,6 +33,8 @@ def test_bench_json_contract_small():
     assert par["identical_song_and_offset"] == par["queries"]
     assert out["top1_hit_rate"] > 0.5
     assert out["builder"]["value"] > 0 and out["hbm_resident"]["value"] > 0 and "H2D" in out["value_includes"]
+    # the timed loop runs two batches deep (stated in the line); the one-at-a-time figure is kept beside it
+    assert out["step_overlap"].startswith("two batches deep") and out["serial"]["value"] > 0
     assert set(cb["stages_s"]) == {"compute embedding", "search", "rerank"} and cb["python_rerank"]["queries"] >= 1
     assert cb["python_rerank"]["same_decision_as_c_path"].split("/")[0] == cb["python_rerank"]["same_decision_as_c_path"].split("/")[1]
     cli = out["cli"]
