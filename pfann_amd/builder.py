@@ -37,12 +37,17 @@ class _PinnedPool:
         self.lock = threading.Lock()
 
     def get(self, n):
-        cap = 1 << max(12, int(n - 1).bit_length())
+        # per-file buffers: powers of two; a launch group's slab (tens of MB): the next multiple of 8 M samples -- a
+        # 41 M-sample group took a 67 M-sample slab, and a slab's price is its size
+        cap = 1 << max(12, int(n - 1).bit_length()) if n <= (1 << 22) else -(-n // (1 << 23)) * (1 << 23)
         with self.lock:
             lst = self.free.get(cap)
             if lst:
                 return lst.pop()
-        return torch.empty(cap, dtype=torch.int16).pin_memory()
+        # allocated pinned (torch.empty(...).pin_memory() allocates pageable memory, pins a second block and copies the
+        # garbage over: 60 ms per 134 MB slab on the loader thread -- with a fresh slab per group until the first one comes
+        # back, a 2000-query matcher run was fed one group per 83 ms for a GPU that needs 41)
+        return torch.empty(cap, dtype=torch.int16, pin_memory=True)
 
     def put(self, bufs):
         with self.lock:
