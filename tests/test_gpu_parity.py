@@ -508,6 +508,33 @@ def test_search_small_batch_sublist_overflow_device_fallback(torch_cuda):
     _check_topk(torch_cuda, db, q[2:].astype(np.float32), 100)
 
 
+@pytest.mark.parametrize("prefilter", [True, False])
+def test_search_small_batch_d128_tail_launch(torch_cuda, prefilter):
+    """d = 128, nq <= 32: the five-launch small-batch path (query preparation inside the group-maximum pass, select,
+    then ONE launch for the big select and the exact fallback).  Query row 0: 5000 near-identical rows (more than 4096
+    survivors: the big-select half of the tail launch); row 1: 9000 rows tying exactly at the top (every sub-list
+    overflows: the fallback half, exact ties -> ascending row ids); row 2: 900 near-identical rows 32 tiles apart (one
+    sub-list overflows); the rest ordinary rows through the 256-thread select."""
+    d, n = 128, 600000
+    rng = np.random.default_rng(71)
+    db = rng.standard_normal((n, d)).astype(np.float32)
+    c = rng.standard_normal((3, d)).astype(np.float32)
+    db[20000:25000] = c[0] + 0.003 * db[20000:25000]
+    db[50000:59000] = c[1]
+    for u in range(900):
+        lo = 70001 + u * 32 * 32
+        if lo < n:
+            db[lo] = c[2] + 0.01 * db[lo]
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    q = np.concatenate([c, rng.standard_normal((16, d)).astype(np.float32)])
+    q[0] = c[0] + 0.05 * q[3]
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    D, I = _check_topk(torch_cuda, db, q.astype(np.float32), 300, prefilter)
+    assert np.array_equal(I[1, :300], np.arange(50000, 50300))
+    # the flags the tail launch cleared: the same handle again, ordinary rows only
+    _check_topk(torch_cuda, db, q[3:].astype(np.float32), 100, prefilter)
+
+
 def test_search_all_scores_tie_zero_query(torch_cuda):
     """q = 0: every row scores 0, the survivor lists overflow at any threshold; exact answer = rows 0..k-1."""
     d, n = 128, 30000
