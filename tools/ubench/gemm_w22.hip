@@ -37,7 +37,7 @@ __global__ void fill(float *p, size_t n, float scale, float bias) {
 
 // MODE 0: the F(2,2) scheme.  MODE 1: the same kernel skeleton doing the plain 6-block convolution (3 full 128-row
 // sub-steps per chunk, two accumulator blocks) -- the like-for-like baseline inside this file.
-template <int MODE>
+template <int MODE, int EPI = 0>       // EPI 1: output rows stored straight from the accumulators (16 B per lane), no LDS staging
 __global__ __launch_bounds__(512, 4) void kw(const float *__restrict__ x, const float *__restrict__ lw, const float *__restrict__ lb,
                                              const float *__restrict__ w, const float *__restrict__ stats, float *__restrict__ y,
                                              float *__restrict__ part, int rps_out, unsigned long long *ts, int hot) {
@@ -184,18 +184,20 @@ __global__ __launch_bounds__(512, 4) void kw(const float *__restrict__ x, const 
                 const float z = (MODE == 0 ? acc[i][4 * g + e] + acc[i + 1][4 * g + e] : acc[i][4 * g + e]) + 0.5f;
                 a1s[i] += z; a2s[i] = fmaf(z, z, a2s[i]); z4[e] = z;
             }
-            *reinterpret_cast<f32x4 *>(&Cs[row * LDC + wn * 32 + 8 * g + 4 * lhalf]) = z4;
+            if (EPI == 1) st4(sy, (unsigned)row * (BN * 4u) + (unsigned)(wn * 32 + 8 * g + 4 * lhalf) * 4u, z4);
+            else *reinterpret_cast<f32x4 *>(&Cs[row * LDC + wn * 32 + 8 * g + 4 * lhalf]) = z4;
         }
     }
-    __syncthreads();
+    if (EPI == 0) __syncthreads();
     const unsigned long long t_e1 = __builtin_readcyclecounter();
+    if (EPI == 0)
     for (int it = 0; it < 8; ++it) {
         const int row = it * 16 + wave * 2 + lhalf;
         const f32x4 v = *reinterpret_cast<const f32x4 *>(&Cs[row * LDC + l31 * 4]);
         st4(sy, (unsigned)row * (BN * 4u) + l31 * 16u, v);
     }
     const unsigned long long t_e2 = __builtin_readcyclecounter();
-    __syncthreads();
+    if (EPI == 0) __syncthreads();
     float *red = smem + 128 * 132;
     for (int i = 0; i < 2; ++i) {
         const int row = MODE == 0 ? 2 * (wm * 32 + l31) + i : wm * 64 + i * 32 + l31;
@@ -233,8 +235,8 @@ int main(int argc, char **argv) {
     const double flop = 2.0 * M * 128 * 384;                  // ALGORITHMIC: the convolution's 3 taps
     printf("M = %lld rows, N = 128, K = 384 (algorithmic), %d tiles, LDS %zu B\n", (long long)M, ntiles, lds);
     for (int rep = 0; rep < 2; ++rep)
-        for (int mode = 1; mode >= 0; --mode) {
-            auto kp = mode == 0 ? kw<0> : kw<1>;
+        for (int mode = 2; mode >= 0; --mode) {
+            auto kp = mode == 0 ? kw<0> : (mode == 1 ? kw<1> : kw<0, 1>);
             (void)hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
             hipLaunchKernelGGL(kp, dim3(ntiles), dim3(512), lds, 0, x, lw, lb, w, stats, y, part, rps_out, nullptr, hot); (void)hipDeviceSynchronize();
@@ -242,7 +244,7 @@ int main(int argc, char **argv) {
             for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kp, dim3(ntiles), dim3(512), lds, 0, x, lw, lb, w, stats, y, part, rps_out, nullptr, hot);
             (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 3;
             printf("%-64s %8.3f ms  %6.1f TFLOP/s (algorithmic)  %.3f  %s\n",
-                   mode == 0 ? "F(2,2): 5 blocks per output pair, 4 sub-steps per chunk" : "plain: 6 blocks per output pair, 3 sub-steps per chunk",
+                   mode == 0 ? "F(2,2): 5 blocks per output pair, 4 sub-steps per chunk" : (mode == 1 ? "plain: 6 blocks per output pair, 3 sub-steps per chunk" : "F(2,2), rows stored straight from the accumulators (no LDS staging)"),
                    ms, flop / ms / 1e9, flop / ms / 1e9 / 157.3, hipGetErrorString(hipGetLastError()));
         }
     // per-tile phase stamps (shader clock cycles; two workgroups resident per CU)
