@@ -308,7 +308,9 @@ def main():
             x = x / x.norm(dim=1, keepdim=True)
             lo, hi = max(b0, r_lo), min(b1, r_hi)
             shard[lo - r_lo:hi - r_lo] = x[lo - b0:hi - b0]
-    CH = 256                             # songs per generated chunk (123 MB of PCM)
+    # songs per generated chunk: whole launch groups (164 songs = 9676 windows fit --max-batch 9728), four per chunk, so
+    # that the builder loop is timed on full groups and fills / drains its pipeline once per 656 songs (315 MB of PCM)
+    CH = 4 * max(1, args.max_batch // SEG_PER_SONG)
     real_ids = range(s_lo, s_hi) if not args.filler_db else \
         [int(v) for v in np.unique(np.linspace(0, n_songs - 1, 48).astype(np.int64)) if s_lo <= v < s_hi]
     host_buf = torch.empty((CH, SEG_PER_SONG * 4000 + 4000), dtype=torch.int16).pin_memory()

@@ -190,7 +190,7 @@ class DeviceIndex:
             # few queries: the kernel writes its 24-byte results straight into pinned (device-mapped) host memory, so the
             # answer is on the host when the stream has drained -- no device-to-host copy call on the latency path
             if self._host_res is None:
-                self._host_res = torch.empty((64, rsz), dtype=torch.uint8).pin_memory()
+                self._host_res = torch.empty((64, rsz), dtype=torch.uint8, pin_memory=True)
             host_res = self._host_res[:nQ]
             res = host_res
         else:
@@ -296,7 +296,7 @@ class Database:
         key = str(dtype)
         buf = self._pin.get(key)
         if buf is None or buf.numel() < n:
-            buf = torch.empty(max(n, 1), dtype=dtype).pin_memory()
+            buf = torch.empty(max(n, 1), dtype=dtype, pin_memory=True)
             self._pin[key] = buf
         return buf[:n].view(shape)
 
