@@ -585,6 +585,68 @@ static void run3(const char *what, P p, int slots_per_cu) {
            flop / ms / 1e9 / 2500.0, sv / p.nq, hipGetErrorString(hipGetLastError()));
 }
 
+// The fp16 MFMA stream by itself: NACC independent 32x32x16 accumulator chains per wave, nothing else in the loop.
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_peak(float *out, int iters) {
+    f16x8 a, b;
+    for (int e = 0; e < 8; ++e) { a[e] = (_Float16)(0.001f * (threadIdx.x + e)); b[e] = (_Float16)(0.002f * (threadIdx.x ^ e)); }
+    f32x16 acc[NACC];
+    for (int j = 0; j < NACC; ++j)
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < NACC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[j], 0, 0, 0);
+    }
+    float t = 0.f;
+    for (int j = 0; j < NACC; ++j) t += acc[j][0] + acc[j][15];
+    if (t == 12345.f) out[threadIdx.x] = t;
+}
+template <int NACC>
+static void run_peak(int wgs_per_cu) {
+    float *out; (void)hipMalloc(&out, 4096);
+    const int iters = 20000;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL((mfma_peak<NACC>), dim3(256 * wgs_per_cu), dim3(256), 0, 0, out, 100); (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL((mfma_peak<NACC>), dim3(256 * wgs_per_cu), dim3(256), 0, 0, out, iters);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    const double flop = 256.0 * wgs_per_cu * 4 * (double)iters * NACC * 32768.0;
+    printf("fp16 MFMA 32x32x16 alone: %d chains per wave, %d waves per SIMD: %7.3f ms  %6.0f TF = %.3f of 2500\n", NACC, wgs_per_cu, ms,
+           flop / ms / 1e9, flop / ms / 1e9 / 2500.0);
+    (void)hipFree(out);
+}
+
+// ... and the fp32 MFMA stream (32x32x2, the conv GEMMs' instruction) for comparison
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma32_peak(float *out, int iters) {
+    float a = 0.001f * threadIdx.x, b = 0.002f * (threadIdx.x ^ 5);
+    f32x16 acc[NACC];
+    for (int j = 0; j < NACC; ++j)
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < NACC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+    }
+    float t = 0.f;
+    for (int j = 0; j < NACC; ++j) t += acc[j][0] + acc[j][15];
+    if (t == 12345.f) out[threadIdx.x] = t;
+}
+template <int NACC>
+static void run_peak32(int wgs_per_cu, int iters) {
+    float *out; (void)hipMalloc(&out, 4096);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL((mfma32_peak<NACC>), dim3(256 * wgs_per_cu), dim3(256), 0, 0, out, 100); (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL((mfma32_peak<NACC>), dim3(256 * wgs_per_cu), dim3(256), 0, 0, out, iters);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    const double flop = 256.0 * wgs_per_cu * 4 * (double)iters * NACC * 4096.0;
+    printf("fp32 MFMA 32x32x2 alone: %d chains per wave, %d waves per SIMD: %7.3f ms  %6.1f TF = %.3f of 157.3\n", NACC, wgs_per_cu, ms,
+           flop / ms / 1e9, flop / ms / 1e9 / 157.3);
+    (void)hipFree(out);
+}
+
 int main(int argc, char **argv) {
     const int64_t nq = 9728, n = 1000064;
     const float thr = argc > 1 ? (float)atof(argv[1]) : 0.27f;
@@ -596,6 +658,8 @@ int main(int argc, char **argv) {
     float *hth = (float *)malloc(nq * 4); for (int64_t i = 0; i < nq; ++i) hth[i] = thr;
     (void)hipMemcpy(th, hth, nq * 4, hipMemcpyHostToDevice);
     P p; p.q = (const char *)q; p.db = (const char *)db; p.nq = nq; p.nrows = n; p.thr = th; p.cnt = cnt; p.keys = keys;
+    run_peak32<3>(2, 5000); run_peak32<3>(4, 5000); run_peak32<3>(4, 40000); run_peak32<2>(4, 40000);
+    run_peak<1>(1); run_peak<2>(1); run_peak<4>(1); run_peak<2>(2); run_peak<2>(3); run_peak<4>(2); run_peak<4>(4);
     for (int rep = 0; rep < 2; ++rep) {
         run<2, 64, 3, 0, false>("product form: ONE LDS array indexed [b] (s_waitcnt vmcnt(0) before the first fragment read)", p, 3);
         run<2, 64, 3, 2, false>("  ... no epilogue", p, 3);
