@@ -49,6 +49,26 @@ def test_bench_json_contract_small():
     assert out["seq_score_seam"]["gpu_call_us_median"] <= out["seq_score_seam"]["gpu_call_us_p95"]
 
 
+def test_two_deep_and_serial_loops_decide_alike(tmp_path):
+    """bench.py times its batches two deep (H2D of batch i+1 under batch i's kernels, decisions read one batch late);
+    --serial runs them one at a time.  Same decisions either way, and the JSON says which loop ran."""
+    import numpy as np
+    common = ["--steps", "3", "--warmup", "1", "--db-songs", "600", "--queries", "24", "--no-cpu-baseline", "--no-cli",
+              "--no-alt", "--max-batch", "512"]
+    outs, lines = [], []
+    for extra, name in ((["--serial"], "serial.npy"), ([], "deep.npy")):
+        p = str(tmp_path / name)
+        r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + common + extra + ["--dump-decisions", p],
+                           capture_output=True, text=True, timeout=900, cwd=REPO)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(np.load(p))
+        lines.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0]))
+    assert np.array_equal(outs[0], outs[1])
+    assert lines[0]["step_overlap"].startswith("none") and lines[0]["serial"] is None
+    assert lines[1]["step_overlap"].startswith("two batches deep") and lines[1]["serial"]["value"] > 0
+    assert lines[0]["steps"] == lines[1]["steps"] == 3
+
+
 @pytest.mark.parametrize("scaling", ["strong", "weak"])
 def test_two_rank_sharded_path_matches_single_gpu(tmp_path, scaling):
     """N>1 on the real kernels: 2 ranks sharing this box's GPU (gloo-staged collectives, debugging
