@@ -535,6 +535,30 @@ def test_search_small_batch_d128_tail_launch(torch_cuda, prefilter):
     _check_topk(torch_cuda, db, q[3:].astype(np.float32), 100, prefilter)
 
 
+def test_search_small_batch_fp16_storage_fallback_d128(torch_cuda):
+    """fp16-only storage, d = 128, nq <= 32: 9000 rows tying exactly at the top overflow every sub-list of query row 0; the
+    fallback half of the combined tail launch streams the fp16 rows (its ELT = 2 form) and returns the lowest row ids."""
+    from oracle import search as osr
+    from pfann_amd.database import DeviceIndex
+    d, n, k = 128, 300000, 300
+    rng = np.random.default_rng(91)
+    db = rng.standard_normal((n, d)).astype(np.float32)
+    c = rng.standard_normal((1, d)).astype(np.float32)
+    db[50000:59000] = c[0]
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    q = np.concatenate([c, rng.standard_normal((6, d)).astype(np.float32)])
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    idx = DeviceIndex(d, 0, storage="f16")
+    idx.load(db, np.array([0, n], np.int64), 0)
+    D, I = idx.search(torch_cuda.as_tensor(q).cuda(), k)
+    D, I = D.cpu().numpy(), I.cpu().numpy()
+    Dr, Ir = osr.flat_ip_topk_f16(q, db, k)
+    assert np.array_equal(I[0], np.arange(50000, 50000 + k))
+    assert np.abs(D - Dr).max() < 2e-5
+    for r in range(1, q.shape[0]):                       # ordinary rows: same label sets up to ties at the k-th score
+        assert len(set(I[r]) ^ set(Ir[r])) <= 4, r
+
+
 def test_search_all_scores_tie_zero_query(torch_cuda):
     """q = 0: every row scores 0, the survivor lists overflow at any threshold; exact answer = rows 0..k-1."""
     d, n = 128, 30000
