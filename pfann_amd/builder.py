@@ -369,7 +369,7 @@ def main(argv=None):
     engine = Engine(params, 0, max_batch=max_batch)
     model_pt = os.path.join(params["model_dir"], "model.pt")
     engine.load_state_dict(torch.load(model_pt, map_location="cpu"))
-    engine.warmup()
+    engine.warmup(windows=max_batch)
     print("model loaded")
 
     params["indexer"]["frame_shift_mul"] = 1                               # builder.py:64

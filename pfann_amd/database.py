@@ -259,14 +259,18 @@ class Database:
         self.index = DeviceIndex(self.d, device, storage)
         self.index.load(emb, self.song_pos, 0)
 
-    def warmup(self):
-        """one throw-away query through search + match: kernel code objects and scratch buffers exist afterwards"""
+    def warmup(self, rows=19 * 64):
+        """throw-away queries through search + match: kernel code objects and scratch buffers exist afterwards.  rows: the
+        largest number of query rows one launch group will bring (the matcher: PFANN_MAX_BATCH) -- the search workspace is
+        sized by it, and growing it later means a hipFree, which waits for everything in flight: the first full group of
+        a matcher run used to stall 30 ms behind its own encoder there (profiles/r3/NOTES.md)."""
         if self.index.ntotal:
             q = torch.zeros((19, self.d), device=self.index.device)
             q[:, 0] = 1.0
             self.query_finish(self.query_launch(q, [0], [19], want_song_scores=True))
-            n = min(2048, 19 * 64)
-            self.query_finish(self.query_launch(q.repeat(n // 19, 1), np.arange(n // 19) * 19, [19] * (n // 19)))
+            nq = max(1, int(rows) // 19)
+            big = torch.cat([q] * nq)                # (also loads torch's concatenation kernel, which the CLIs use per group)
+            self.query_finish(self.query_launch(big, np.arange(nq) * 19, [19] * nq, want_song_scores=True), reuse_buffers=True)
 
     # ---- batched form ------------------------------------------------------------------
     def query_launch(self, emb, qstart, qlen, want_song_scores=False, mode=0):

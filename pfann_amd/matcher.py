@@ -84,11 +84,11 @@ def main(argv=None):
     max_batch = int(os.environ.get("PFANN_MAX_BATCH", "9728"))
     engine = Engine(params, 0, max_batch=max_batch)
     engine.load_state_dict(torch.load(os.path.join(dir_for_db, "model.pt"), map_location="cpu"))
-    engine.warmup()
+    engine.warmup(windows=max_batch)
     print("model loaded")
     print("loading database...")
     db = Database(dir_for_db, params["indexer"], params["hop_size"], device=0, d=params["model"]["d"])
-    db.warmup()
+    db.warmup(rows=max_batch)
     print("database loaded")
 
     dataset = MusicDataset(file_list_for_query, params)
