@@ -378,28 +378,79 @@ def main(argv=None):
     timer = StageTimer()
     t0 = time.time()
     landmark_key = np.zeros(len(dataset), dtype=np.int32)
-    chunks = []
     total = 0
-    # the fingerprints stay in HBM until every file is through (1 M rows = 0.5 GB) and come back in one copy: no
-    # device-to-host wait inside the loop, so the next group's uploads and launches go out while this one computes
-    for idx, n_seg, emb in embed_files(engine, dataset, dataset.hop, batch_windows=max_batch, timer=timer):
-        landmark_key[idx] = n_seg
-        if n_seg:
-            chunks.append(emb)
-            total += n_seg
-    with timer.stage("download embeddings"):
-        embeddings = torch.cat(chunks).cpu().numpy() if chunks else np.zeros((0, d), np.float32)
-    embeddings.tofile(os.path.join(dir_for_db, "embeddings"))
-    print("total", total, "embeddings")
-    if total == 0:
-        print("The database is empty!")
-
     factory = params["indexer"].get("index_factory", "Flat")
     if factory not in ("Flat", "IDMap,Flat"):
         print("index_factory %r is approximate and out of scope: writing an exact flat "
               "inner-product index instead" % factory)
+    # Every launch group's fingerprints leave while the next group computes: one asynchronous copy into a pinned buffer on
+    # a side stream, and a writer thread appends them to `embeddings` and to the flat index `landmarkValue` (the
+    # reference adds to the index and writes both files after its loop, builder.py:105-136; the bytes are the same).  No
+    # device-to-host wait in the loop, and nothing left to copy or write when the last group is through.
+    f_emb = open(os.path.join(dir_for_db, "embeddings"), "wb")
+    f_idx = faissio.FlatIndexWriter(os.path.join(dir_for_db, "landmarkValue"), d)
+    wq = queue.Queue(maxsize=4)
+    werr = []
+
+    def writer():
+        try:
+            while True:
+                got = wq.get()
+                if got is None:
+                    return
+                ev, host, rows = got
+                ev.synchronize()
+                a = host[:rows * d].numpy().reshape(rows, d)
+                if rows:
+                    f_emb.write(memoryview(a).cast("B"))
+                f_idx.append(a)
+                free_bufs.put(host)
+        except BaseException as x:          # noqa: B902 -- reported by the main thread
+            werr.append(x)
+
+    free_bufs = queue.Queue()
+    wt = threading.Thread(target=writer, name="pfann-db-writer", daemon=True)
+    wt.start()
+    side = torch.cuda.Stream(device=engine.device)
+    for items in embed_file_batches(engine, dataset, dataset.hop, batch_windows=max_batch, timer=timer):
+        embs = []
+        for idx, n_seg, emb in items:
+            landmark_key[idx] = n_seg
+            if n_seg:
+                embs.append(emb)
+                total += n_seg
+        if not embs or werr:
+            continue
+        g = torch.cat(embs) if len(embs) > 1 else embs[0]
+        rows = int(g.shape[0])
+        try:
+            host = free_bufs.get_nowait()
+            if host.numel() < rows * d:
+                host = None
+        except queue.Empty:
+            host = None
+        if host is None:
+            host = torch.empty(max(rows, max_batch) * d, dtype=torch.float32, pin_memory=True)
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            host[:rows * d].copy_(g.reshape(-1), non_blocking=True)
+            g.record_stream(side)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        wq.put((ev, host, rows))
+    with timer.stage("download embeddings"):
+        wq.put(None)
+        wt.join()
+    f_emb.close()
+    f_idx.close()
+    if werr:
+        raise werr[0]
+    print("total", total, "embeddings")
+    if total == 0:
+        print("The database is empty!")
     print("writing database")
-    faissio.write_index_flat(os.path.join(dir_for_db, "landmarkValue"), embeddings)
     landmark_key.tofile(os.path.join(dir_for_db, "landmarkKey"))
     shutil.copyfile(file_list_for_db, os.path.join(dir_for_db, "songList.txt"))
     shutil.copyfile(configs, os.path.join(dir_for_db, "configs.json"))

@@ -14,14 +14,43 @@ METRIC_INNER_PRODUCT = 0
 METRIC_L2 = 1
 
 
+def _header(d, n, metric):
+    return ((b"IxFI" if metric == METRIC_INNER_PRODUCT else b"IxF2") + struct.pack("<iqqqBi", d, n, 1 << 20, 1 << 20, 1, metric) +
+            struct.pack("<Q", n * d))
+
+
+def _write_rows(f, xb):
+    if xb.size:                                   # (a memoryview of an empty array cannot be cast)
+        f.write(memoryview(xb).cast("B"))
+
+
 def write_index_flat(path, xb, metric=METRIC_INNER_PRODUCT):
     xb = np.ascontiguousarray(xb, dtype="<f4")
     n, d = xb.shape
     with open(path, "wb") as f:
-        f.write(b"IxFI" if metric == METRIC_INNER_PRODUCT else b"IxF2")
-        f.write(struct.pack("<iqqqBi", d, n, 1 << 20, 1 << 20, 1, metric))
-        f.write(struct.pack("<Q", n * d))
-        f.write(xb.tobytes())
+        f.write(_header(d, n, metric))
+        _write_rows(f, xb)
+
+
+class FlatIndexWriter:
+    """The same file written incrementally (the builder appends each launch group's rows while the next group computes):
+    header with n = 0 first, rows appended, the header rewritten with the final count on close."""
+
+    def __init__(self, path, d, metric=METRIC_INNER_PRODUCT):
+        self.d, self.n, self.metric = int(d), 0, metric
+        self.f = open(path, "wb")
+        self.f.write(_header(self.d, 0, metric))
+
+    def append(self, xb):
+        xb = np.ascontiguousarray(xb, dtype="<f4")
+        assert xb.ndim == 2 and xb.shape[1] == self.d
+        _write_rows(self.f, xb)
+        self.n += xb.shape[0]
+
+    def close(self):
+        self.f.seek(0)
+        self.f.write(_header(self.d, self.n, self.metric))
+        self.f.close()
 
 
 def read_index_flat(path):

@@ -121,6 +121,16 @@ def test_faiss_flat_index_roundtrip(tmp_path):
     faissio.write_index_flat(p, np.zeros((0, 16), np.float32))
     y, _ = faissio.read_index_flat(p)
     assert y.shape == (0, 16)
+    # the incremental writer the builder uses (rows appended group by group) leaves the same bytes
+    p2 = str(tmp_path / "landmarkValue2")
+    w = faissio.FlatIndexWriter(p2, 16)
+    for lo, hi in ((0, 5), (5, 5), (5, 30), (30, 37)):
+        w.append(x[lo:hi])
+    w.close()
+    assert open(p2, "rb").read() == raw
+    w = faissio.FlatIndexWriter(p2, 16)
+    w.close()
+    assert faissio.read_index_flat(p2)[0].shape == (0, 16)
     open(p, "wb").write(b"IwFl" + raw[4:])
     with pytest.raises(ValueError):
         faissio.read_index_flat(p)
