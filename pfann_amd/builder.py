@@ -165,6 +165,8 @@ def _native_groups(engine, dataset, hop, batch_windows, pool, workers):
     def produce():
         try:
             pos = 0
+            n_groups = 0
+            ramp = os.environ.get("PFANN_GROUP_RAMP", "1") != "0"
             info = np.zeros(0, _WAV_INFO)
             nseg = np.zeros(0, np.int64)
             base = 0                        # file index of info[0]
@@ -186,9 +188,19 @@ def _native_groups(engine, dataset, hop, batch_windows, pool, workers):
                         nseg = np.concatenate([nseg, more_seg])
                         pos += m
                         continue
-                # cut one group off the front: as many files as fit batch_windows (at least one)
+                # cut one group off the front: as many files as fit the group's window budget (at least one).  The run
+                # starts with a quarter and a half group and ends with a quarter group: the GPU starts after a quarter
+                # group's decode instead of a whole one's, and what is left to do when it stops (the last group's
+                # result copy and file writes) is a quarter group's (PFANN_GROUP_RAMP=0: whole groups throughout)
                 c = np.cumsum(nseg)
-                take = max(1, int(np.searchsorted(c, batch_windows, side="right")))       # files whose windows still fit
+                limit = batch_windows
+                if ramp:
+                    if n_groups < 2:
+                        limit = max(1, batch_windows >> (2 - n_groups))
+                    elif pos >= n and batch_windows // 2 < int(c[-1]) <= batch_windows:
+                        limit = int(c[-1]) - batch_windows // 4
+                n_groups += 1
+                take = max(1, int(np.searchsorted(c, limit, side="right")))       # files whose windows still fit
                 g_info, g_seg = info[:take].copy(), nseg[:take].copy()
                 info, nseg = info[take:], nseg[take:]
                 ok = g_info["status"] == 0
