@@ -110,12 +110,11 @@ def _threaded_groups(engine, dataset, hop, batch_windows, pool, workers, ahead):
             while ex is not None and nxt < n and nxt - i < ahead:
                 futs.append(ex.submit(_decode, dataset, nxt, pool, native))
                 nxt += 1
+            buf = None
             try:
                 t0 = time.perf_counter()                # "load": what the GPU-feeding thread waited for the decoders
                 pcm, sr, buf = futs.popleft().result() if ex is not None else _decode(dataset, i, pool, native)
                 t_load += time.perf_counter() - t0
-                if buf is not None:
-                    held.append(buf)
                 n_in = pcm.shape[0]
                 pinned_host = buf is not None or (isinstance(pcm, torch.Tensor) and pcm.device.type == "cpu" and
                                                   pcm.dtype == torch.int16 and pcm.is_contiguous() and pcm.is_pinned())
@@ -129,10 +128,15 @@ def _threaded_groups(engine, dataset, hop, batch_windows, pool, workers, ahead):
                 n_seg = (max(n_out, seg) - seg) // hop + 1
             except Exception as x:                                            # musicdata.py:95-101
                 print("load %s error! (%s)" % (dataset.files[i], x))
-                item, n_seg = None, 0
+                item, n_seg = None, 0            # (a buffer taken before the failure still goes back to the pool)
             if pending and n_win + n_seg > batch_windows:     # a group never exceeds the encoder's chunk (no small tail pass)
                 yield pending, None, held, t_load
                 pending, held, n_win, t_load = [], [], 0, 0.0
+            # file i's pinned buffer belongs to the group file i is uploaded with -- the one it is appended to HERE, after
+            # the overflow cut (it used to join `held` before the cut and was handed back to the pool with the previous
+            # group, while its own upload was still queued: a decode worker could overwrite it)
+            if buf is not None:
+                held.append(buf)
             pending.append((i, n_seg, item))
             n_win += n_seg
             if n_win >= batch_windows:

@@ -284,7 +284,6 @@ class Database:
         res, ss = self.index.match(emb, I, qstart, qlen, self.frame_shift_mul, self.score_alpha, mode,
                                    False, want_song_scores, to_host=False)
         ev[2].record()
-        ev[2].record()
         if ss is not None:
             # frames -> seconds where the block lives (database.py:148,193 do it on the host): (t - shift/fsm) * hop_size
             # with fine = t*fsm - shift, in double like the reference's Python floats, stored as float32

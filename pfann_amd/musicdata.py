@@ -9,6 +9,7 @@ Two ways to consume a file:
   * `MusicDataset.load_pcm_sr(i) -> (int16[n, ch], rate)`    -- raw PCM for the fused device
     path (Engine.pcm16_to_mono + Engine.embed_wav), which never materialises the unfold.
 """
+import os
 import struct
 import time
 import wave
@@ -52,6 +53,13 @@ def read_wav_pcm16(path, alloc=None):
                 if fmt is None:
                     raise wave.Error("data chunk before fmt chunk")
                 n_ch, sr = fmt
+                # streamed WAVs (ffmpeg pipe output) declare 0xFFFFFFFF or 0 bytes: never trust the header beyond what the
+                # file holds (csrc/wavio.hip clamps the same way), or alloc() would pin gigabytes for a few real samples
+                try:
+                    left = max(os.fstat(f.fileno()).st_size - f.tell(), 0)
+                    size = min(size, left)
+                except OSError:
+                    pass
                 n = size // (2 * n_ch) * n_ch                               # whole frames only
                 buf = alloc(n) if alloc is not None else np.empty(n, dtype=np.int16)
                 got = f.readinto(memoryview(buf).cast("B")[: n * 2]) if n else 0

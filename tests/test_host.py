@@ -408,6 +408,79 @@ def test_native_wav_loader_groups_and_slabs(tmp_path):
     assert calls == [(want[20].shape[0], 2)]
 
 
+def test_threaded_groups_release_list_owns_exactly_its_groups_buffers():
+    """builder._threaded_groups (the loader of non-MusicDataset inputs, PFANN_NATIVE_WAV=0, workers=0): the pinned
+    buffer of a file that does not fit the current launch group must travel with the NEXT group -- the one the file is
+    uploaded with.  It used to be handed back with the previous group's release list, i.e. it could be recycled by a
+    decode worker while its own upload was still queued.  Stub pool, no GPU."""
+    import types
+    import torch
+    from pfann_amd import builder
+
+    class Pool:
+        def __init__(self):
+            self.n = 0
+
+        def get(self, n):
+            self.n += 1
+            return torch.zeros(max(n, 1), dtype=torch.int16)
+
+    class DS:
+        files = ["f%d" % i for i in range(11)]
+
+        def load_pcm_sr(self, i, alloc):
+            n = 8000 + 4000 * (i % 4)                   # 1..4 segments each
+            a = alloc(n)
+            a[:] = i + 1
+            return a.reshape(-1, 1), 8000
+
+        def __len__(self):
+            return len(self.files)
+    params = {"sample_rate": 8000}
+    eng = types.SimpleNamespace(seg_len=8000, params=params)
+    for workers in (0, 2):
+        groups = list(builder._threaded_groups(eng, DS(), 4000, 5, Pool(), workers, 4))
+        seen_files = []
+        all_released = []
+        for items, slab, release, _ in groups:
+            rel_ptrs = {b.data_ptr() for b in release}
+            assert len(rel_ptrs) == len(release)
+            for idx, n_seg, item in items:
+                seen_files.append(idx)
+                assert item[0] == "host" and n_seg == 1 + idx % 4
+                assert item[1].data_ptr() in rel_ptrs, "file %d's buffer is not in its own group's release list" % idx
+                assert int(item[1][0]) == idx + 1
+            assert len(release) == len(items)            # ... and nothing else is
+            all_released += list(rel_ptrs)
+        assert seen_files == list(range(11)) and len(set(all_released)) == 11
+
+
+def test_wav_reader_clamps_a_streamed_header(tmp_path):
+    """A streamed WAV (ffmpeg pipe output) declares 0xFFFFFFFF data bytes: both readers return what the file holds and
+    neither sizes an allocation from the header (the Python reader used to ask alloc() for 2^31 samples)."""
+    from pfann_amd import lib as L
+    from pfann_amd.musicdata import read_wav_pcm16
+    pcm = (np.arange(5000) % 700 - 350).astype(np.int16)
+    p = str(tmp_path / "s.wav")
+    synth.write_wav(p, pcm)
+    raw = bytearray(open(p, "rb").read())
+    at = raw.index(b"data") + 4
+    raw[at:at + 4] = b"\xff\xff\xff\xff"
+    open(p, "wb").write(bytes(raw))
+    asked = []
+
+    def alloc(n):
+        asked.append(n)
+        return np.empty(n, np.int16)
+    got, sr = read_wav_pcm16(p, alloc)
+    assert sr == 8000 and np.array_equal(got[:, 0], pcm) and asked == [5000]
+    lib = L.load()
+    info = (L.WavInfo * 1)()
+    arr = (ctypes.c_char_p * 1)(os.fsencode(p))
+    lib.pfann_wav_probe(arr, 1, 1, info)
+    assert info[0].status == 0 and info[0].n_frames == 5000
+
+
 def test_cli_bench_helpers(tmp_path):
     """tools/cli_bench.py host pieces: its WAV writer produces files the `wave` module (the reference's reader,
     audio.py:130-149) and the library's native reader agree on; the stage-line parser reads what the CLIs print."""
