@@ -171,6 +171,16 @@ int pfann_set_fused_layernorm(pfann_ctx *ctx, int on);
  * effect.  New capability: the reference computes these convolutions in fp32 (model.py:54-73). */
 int pfann_set_encoder_precision(pfann_ctx *ctx, int mode);
 
+/* Kernel-variant plan of the encoder.  By default every call picks its GEMM tile size, the split-K path and the
+ * small-batch head from its OWN batch size, which makes the last bits of a fingerprint depend on the batch it was
+ * computed in (different summation orders; all within 5e-6 of the fp32 reference).  pfann_set_plan_batch(ctx, n) with
+ * n > 0 makes every later call pick the variants a batch of n segments would get (n < 65 is raised to 65), whatever
+ * its own size: a segment then has bit-identical fingerprints in every batch -- the drop-in CLIs set n = their launch
+ * group size, which is what makes their outputs byte-identical for any number of ranks and any grouping.  n = 0
+ * restores the default.  Returns the value in effect.  New capability (the reference's PyTorch kernels make no such
+ * promise either way; SURVEY 8a "batch independence"). */
+int64_t pfann_set_plan_batch(pfann_ctx *ctx, int64_t n);
+
 /* Number of internal HIP streams (1..8) a batch is split over inside pfann_encode /
  * pfann_segment_embed*: the MFMA-bound GEMMs of one sub-batch overlap the HBM-bound passes
  * of another.  Work is forked from and joined back into the caller's stream.  Returns n. */
@@ -255,7 +265,9 @@ typedef struct pfann_match_result {
  * fp32 divide, offsets t*fsm-shift, score_alpha honoured).
  * results_dev[nQ]; song_scores_dev[nQ][n_songs][2] may be NULL; when given it must be
  * zeroed by the caller and receives (score, offset-in-frames) of songs owned by the shard.
- * only_owned=1 restricts candidates to songs of this shard (multi-GPU rerank).
+ * only_owned: bit 0 restricts candidates to songs of this shard (multi-GPU rerank); bit 1 (PFANN_MATCH_OWNED_BLOCK,
+ * only together with bit 0) makes song_scores_dev a [nQ][owned songs][2] block (pfann_db_owned_songs) instead of
+ * [nQ][n_songs][2]: the shard's columns of the matcher's `.bin` matrix and nothing else.
  * max_qlen = largest qlen[j]: candidate lists of up to 8192 (qlen*k) entries are sorted in LDS,
  * longer ones (e.g. a 60 s query at k=100) in a per-query HBM slab the handle grows on demand;
  * a query longer than max_qlen gets song=-2. */
@@ -263,6 +275,18 @@ int pfann_match(pfann_db *db, const float *q_dev, const int64_t *labels_dev, int
                 const int64_t *qstart_dev, const int32_t *qlen_dev, int64_t nQ, int max_qlen,
                 int frame_shift_mul, float score_alpha, int mode, int only_owned,
                 pfann_match_result *results_dev, float *song_scores_dev, void *stream);
+
+#define PFANN_MATCH_ONLY_OWNED 1
+#define PFANN_MATCH_OWNED_BLOCK 2
+
+/* Songs whose rows all live in this shard: [*song_lo, *song_hi) (either pointer may be NULL); returns their number. */
+int pfann_db_owned_songs(pfann_db *db, int *song_lo, int *song_hi);
+
+/* In place, for n_pairs (score, alignment) pairs of a song_scores block written by pfann_match: the alignment slot
+ * goes from fine frames (t * frame_shift_mul - shift) to seconds, (t - shift / frame_shift_mul) * hop_size computed in
+ * double and stored as float32 -- what database.py:148,160 leaves in song_score[:, 1].  Asynchronous on `stream`. */
+int pfann_song_scores_to_seconds(pfann_db *db, float *song_scores_dev, int64_t n_pairs, int frame_shift_mul,
+                                 double hop_size, void *stream);
 
 /* Song-sharded multi-GPU retrieval, winner selection without the host (no reference counterpart):
  * pfann_match_pack turns this rank's results_dev[nQ] (from pfann_match with only_owned=1, python path) into one

@@ -149,12 +149,17 @@ def _threaded_groups(engine, dataset, hop, batch_windows, pool, workers, ahead):
             ex.shutdown(wait=True, cancel_futures=True)
 
 
-def _native_groups(engine, dataset, hop, batch_windows, pool, workers):
+def _native_groups(engine, dataset, hop, batch_windows, pool, workers, rank=0, world=1):
     """WAV files through the library's native reader (csrc/wavio.hip): a producer thread probes the headers, cuts the
     list into launch groups, and has `workers` native threads read each group's samples into ONE pinned slab, two
     groups ahead of the GPU.  Yields like _threaded_groups; slab = (pinned int16 tensor, samples used) when the group
     is uniform (every readable file mono, at the model's rate, at least one segment long: the slab IS the group's
-    concatenated PCM and goes up in one copy)."""
+    concatenated PCM and goes up in one copy).
+
+    world > 1 (one process per GPU): the list is cut into ROUNDS of `world` consecutive launch groups, every rank
+    probes all headers (so all ranks cut alike) but reads only the group with its own number; a fifth element is then
+    yielded, the round's layout [(first file, [predicted n_seg per file])] * world, and ranks without a group in the
+    last round yield empty items."""
     from . import resample
     lib = engine.lib
     seg = engine.seg_len
@@ -169,13 +174,13 @@ def _native_groups(engine, dataset, hop, batch_windows, pool, workers):
     def produce():
         try:
             pos = 0
-            n_groups = 0
+            n_rounds = 0
             ramp = os.environ.get("PFANN_GROUP_RAMP", "1") != "0"
             info = np.zeros(0, _WAV_INFO)
             nseg = np.zeros(0, np.int64)
             base = 0                        # file index of info[0]
             while (pos < n or info.shape[0]) and not stop.is_set():
-                if info.shape[0] == 0 or (pos < n and nseg.sum() < batch_windows):
+                if info.shape[0] == 0 or (pos < n and nseg.sum() < batch_windows * world):
                     m = min(PROBE, n - pos)
                     if m > 0:
                         more = np.zeros(m, _WAV_INFO)
@@ -192,34 +197,51 @@ def _native_groups(engine, dataset, hop, batch_windows, pool, workers):
                         nseg = np.concatenate([nseg, more_seg])
                         pos += m
                         continue
-                # cut one group off the front: as many files as fit the group's window budget (at least one).  The run
-                # starts with a quarter and a half group and ends with a quarter group: the GPU starts after a quarter
-                # group's decode instead of a whole one's, and what is left to do when it stops (the last group's
-                # result copy and file writes) is a quarter group's (PFANN_GROUP_RAMP=0: whole groups throughout)
-                c = np.cumsum(nseg)
-                limit = batch_windows
-                if ramp:
-                    if n_groups < 2:
-                        limit = max(1, batch_windows >> (2 - n_groups))
-                    elif pos >= n and batch_windows // 2 < int(c[-1]) <= batch_windows:
-                        limit = int(c[-1]) - batch_windows // 4
-                n_groups += 1
-                take = max(1, int(np.searchsorted(c, limit, side="right")))       # files whose windows still fit
-                g_info, g_seg = info[:take].copy(), nseg[:take].copy()
-                info, nseg = info[take:], nseg[take:]
-                ok = g_info["status"] == 0
-                sizes = np.where(ok, g_info["n_frames"] * g_info["n_ch"], 0)
-                offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
-                tot = int(sizes.sum())
-                slab = pool.get(max(tot, 1))
-                arr = (ctypes.c_char_p * take)(*paths[base:base + take])
-                rc = lib.pfann_wav_read(arr, take, workers, g_info.ctypes.data_as(ctypes.POINTER(_l.WavInfo)),
-                                        offs.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), slab.data_ptr(), slab.numel())
-                if rc != 0:
-                    raise _l.PfannError("pfann_wav_read failed (%d)" % rc)
-                g_seg = np.where(g_info["status"] == 0, g_seg, 0)          # a read error after a good probe
-                out_q.put((base, g_info, g_seg, offs, slab, tot))
-                base += take
+                # cut one ROUND of `world` groups off the front, each as many files as fit the group's window budget (at
+                # least one).  The run starts with a quarter and a half group and (one rank) ends with a quarter group:
+                # the GPU starts after a quarter group's decode instead of a whole one's, and what is left to do when it
+                # stops (the last group's result copy and file writes) is a quarter group's (PFANN_GROUP_RAMP=0: whole
+                # groups throughout).  Several ranks: the last round is cut into equal shares.
+                left = int(nseg.sum())
+                limit, tail = batch_windows, False
+                if ramp and n_rounds < 2:
+                    limit = max(1, batch_windows >> (2 - n_rounds))
+                elif ramp and world == 1 and pos >= n and batch_windows // 2 < left <= batch_windows:
+                    limit = left - batch_windows // 4
+                if world > 1 and pos >= n and left <= world * limit:
+                    limit, tail = max(1, -(-left // world)), True
+                n_rounds += 1
+                layout, mine = [], None
+                for r in range(world):
+                    if info.shape[0] == 0:
+                        layout.append((base, np.zeros(0, np.int64)))
+                        continue
+                    c = np.cumsum(nseg)
+                    if tail:        # the file that crosses the share still belongs to it (unless the encoder chunk overflows)
+                        take = int(np.searchsorted(c, limit, side="left")) + 1
+                        while take > 1 and c[min(take, c.shape[0]) - 1] > batch_windows:
+                            take -= 1
+                        take = min(take, c.shape[0])                    # (a remainder, if any, makes one more round)
+                    else:
+                        take = max(1, int(np.searchsorted(c, limit, side="right")))       # files whose windows still fit
+                    g_info, g_seg = info[:take].copy(), nseg[:take].copy()
+                    info, nseg = info[take:], nseg[take:]
+                    layout.append((base, g_seg.copy()))
+                    if r == rank:
+                        ok = g_info["status"] == 0
+                        sizes = np.where(ok, g_info["n_frames"] * g_info["n_ch"], 0)
+                        offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+                        tot = int(sizes.sum())
+                        slab = pool.get(max(tot, 1))
+                        arr = (ctypes.c_char_p * take)(*paths[base:base + take])
+                        rc = lib.pfann_wav_read(arr, take, workers, g_info.ctypes.data_as(ctypes.POINTER(_l.WavInfo)),
+                                                offs.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), slab.data_ptr(), slab.numel())
+                        if rc != 0:
+                            raise _l.PfannError("pfann_wav_read failed (%d)" % rc)
+                        g_seg = np.where(g_info["status"] == 0, g_seg, 0)          # a read error after a good probe
+                        mine = (base, g_info, g_seg, offs, slab, tot)
+                    base += take
+                out_q.put((mine, layout))
             out_q.put(None)
         except BaseException as x:          # hand the failure to the consumer instead of dying silently
             out_q.put(x)
@@ -235,7 +257,11 @@ def _native_groups(engine, dataset, hop, batch_windows, pool, workers):
                 break
             if isinstance(got, BaseException):
                 raise got
-            base, g_info, g_seg, offs, slab, tot = got
+            mine, layout = got
+            if mine is None:                       # fewer groups than ranks in the last round: nothing of ours
+                yield [], None, [], t_load, layout
+                continue
+            base, g_info, g_seg, offs, slab, tot = mine
             ok = g_info["status"] == 0
             for j in np.nonzero(~ok)[0]:
                 print("load %s error! (%s)" % (files[base + j], _WAV_ERR.get(int(g_info["status"][j]), "error")))
@@ -259,7 +285,10 @@ def _native_groups(engine, dataset, hop, batch_windows, pool, workers):
                     except Exception as x:
                         print("load %s error! (%s)" % (files[base + j], x))
                         items.append((base + j, 0, None))
-            yield items, ((slab, tot) if uniform else None), [slab], t_load
+            if world > 1:
+                yield items, ((slab, tot) if uniform else None), [slab], t_load, layout
+            else:
+                yield items, ((slab, tot) if uniform else None), [slab], t_load
     finally:
         stop.set()
         while th.is_alive():                # unblock a producer waiting on the full queue
@@ -269,9 +298,38 @@ def _native_groups(engine, dataset, hop, batch_windows, pool, workers):
                 th.join(0.05)
 
 
-def embed_file_batches(engine, dataset, hop, batch_windows=4096, timer=None, norm=True, workers=None, ahead=None):
+class Round(list):
+    """What embed_file_batches yields under several ranks: the list is THIS rank's launch group
+    [(index, n_seg, embeddings)], `files` = [(index, n_seg)] of every file of the round (all ranks' groups, list order,
+    actual segment counts exchanged over the ranks' gloo group) and `groups[r]` = (position in files, count) of rank
+    r's group."""
+    files = ()
+    groups = ()
+
+
+def gather_round(ranks, rnd, d, device):
+    """All ranks' fingerprints of one round on every rank: -> [(index, n_seg, embeddings [n_seg, d] or None)] for every
+    file of the round, in list order (one ragged all-gather of the groups' rows; 512 bytes per segment)."""
+    from .dist import all_gather_ragged
+    counts = [int(sum(n for _, n in rnd.files[p:p + c])) for p, c in rnd.groups]
+    rows = [e for _, n, e in rnd if n]
+    mine = torch.cat(rows) if len(rows) > 1 else (rows[0] if rows else torch.empty((0, d), device=device, dtype=torch.float32))
+    assert mine.shape[0] == counts[ranks.rank]
+    allrows = all_gather_ragged(mine, counts, ranks.group)
+    out, o = [], 0
+    for idx, n in rnd.files:
+        out.append((idx, n, allrows[o:o + n] if n else None))
+        o += n
+    return out
+
+
+def embed_file_batches(engine, dataset, hop, batch_windows=4096, timer=None, norm=True, workers=None, ahead=None, ranks=None):
     """Yields one list per launch group: [(index, n_seg, embeddings cuda tensor [n_seg, d] or None), ...] in list order;
     a file that fails to load has n_seg = 0 (the reference's 0-segment-song convention, builder.py:82-86).
+
+    ranks (pfann_amd.dist.Ranks, more than one rank): the list is cut into rounds of `world` consecutive launch groups
+    and this rank embeds the group with its own number; a `Round` is yielded (see there; gather_round gives every rank
+    the whole round).  Every rank runs the same number of rounds.
 
     Decode runs ahead of the GPU on `workers` host threads (the reference: DataLoader(num_workers=4), builder.py:66;
     PFANN_DECODE_WORKERS): for a MusicDataset the library's native WAV reader fills one pinned slab per group
@@ -287,11 +345,16 @@ def embed_file_batches(engine, dataset, hop, batch_windows=4096, timer=None, nor
     # the native reader only stands in for MusicDataset's OWN file reader: a subclass that decodes differently keeps its say
     if isinstance(dataset, MusicDataset) and type(dataset).load_pcm_sr is MusicDataset.load_pcm_sr and workers > 0 and \
             os.environ.get("PFANN_NATIVE_WAV", "1") != "0":
-        source = _native_groups(engine, dataset, hop, batch_windows, pool, workers)
+        source = _native_groups(engine, dataset, hop, batch_windows, pool, workers, *((ranks.rank, ranks.world) if ranks else ()))
+    elif ranks is not None and ranks.world > 1:
+        raise _l.PfannError("a multi-rank run reads its files through the native WAV reader (a MusicDataset, "
+                            "PFANN_DECODE_WORKERS > 0, PFANN_NATIVE_WAV not 0)")
     else:
         source = _threaded_groups(engine, dataset, hop, batch_windows, pool, workers, ahead)
+    multi = ranks is not None and ranks.world > 1
 
-    for pending, slab, release, t_load in source:
+    for got in source:
+        pending, slab, release, t_load = got[:4]
         t1 = time.perf_counter()
         out = [(idx, 0, None) for idx, _, _ in pending]
         wav_all = starts = None
@@ -353,7 +416,21 @@ def embed_file_batches(engine, dataset, hop, batch_windows=4096, timer=None, nor
             in_flight[0][0].synchronize()
             pool.put(in_flight.popleft()[1])
         timer.resolve()
-        yield out
+        if multi:
+            # the round's actual segment counts (a read error after a good probe turns a file into a 0-segment song on
+            # the rank that read it): summed over the ranks on the host-side gloo group, never behind GPU work
+            layout = got[4]
+            sizes = [len(pred) for _, pred in layout]
+            pos0 = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+            vec = np.zeros(int(pos0[-1]), np.int64)
+            vec[pos0[ranks.rank]:pos0[ranks.rank] + len(out)] = [n for _, n, _ in out]
+            vec = ranks.sum_host(vec)
+            rnd = Round(out)
+            rnd.files = [(int(layout[r][0]) + j, int(vec[pos0[r] + j])) for r in range(ranks.world) for j in range(sizes[r])]
+            rnd.groups = [(int(pos0[r]), sizes[r]) for r in range(ranks.world)]
+            yield rnd
+        else:
+            yield out
     timer.resolve(wait=True)
 
 
@@ -368,6 +445,14 @@ def main(argv=None):
     if len(argv) < 3:
         print("Usage: python %s <music list file> <db location>" % argv[0])
         return 1
+    from .dist import finish_ranks, init_ranks, self_launch_if_asked
+    rc = self_launch_if_asked(argv)         # PFANN_GPUS=N: N ranks of this command, one per GPU
+    if rc is not None:
+        return rc
+    ranks = init_ranks()                    # None: a plain single-process run
+    multi = ranks is not None and ranks.world > 1
+    rank0 = ranks is None or ranks.rank == 0
+    say = print if rank0 else (lambda *a, **k: None)
     file_list_for_db, dir_for_db = argv[1], argv[2]
     configs = argv[3] if len(argv) >= 4 else "configs/default.json"
     if os.path.isdir(configs):                                            # builder.py:38-44
@@ -378,102 +463,154 @@ def main(argv=None):
     else:
         params = read_config(configs)
     d = params["model"]["d"]
-    init_logger("builder")                                                 # builder.py:27-28
+    if rank0:
+        init_logger("builder")                                             # builder.py:27-28
 
-    print("loading model...")
+    say("loading model...")
     max_batch = int(os.environ.get("PFANN_MAX_BATCH", "9728"))
-    engine = Engine(params, 0, max_batch=max_batch)
+    engine = Engine(params, ranks.device if ranks is not None else 0, max_batch=max_batch)
+    # kernel variants of a full launch group for every call: a song's fingerprints -- every byte of `embeddings` -- do not
+    # depend on how the list is cut into groups or spread over ranks (include/pfann_amd.h: pfann_set_plan_batch)
+    engine.set_plan_batch(max_batch)
     model_pt = os.path.join(params["model_dir"], "model.pt")
     engine.load_state_dict(torch.load(model_pt, map_location="cpu"))
     engine.warmup(windows=max_batch)
-    print("model loaded")
+    say("model loaded")
 
     params["indexer"]["frame_shift_mul"] = 1                               # builder.py:64
     dataset = MusicDataset(file_list_for_db, params)
-    os.makedirs(dir_for_db, exist_ok=True)
     timer = StageTimer()
     t0 = time.time()
     landmark_key = np.zeros(len(dataset), dtype=np.int32)
     total = 0
     factory = params["indexer"].get("index_factory", "Flat")
     if factory not in ("Flat", "IDMap,Flat"):
-        print("index_factory %r is approximate and out of scope: writing an exact flat "
-              "inner-product index instead" % factory)
+        say("index_factory %r is approximate and out of scope: writing an exact flat "
+            "inner-product index instead" % factory)
     # Every launch group's fingerprints leave while the next group computes: one asynchronous copy into a pinned buffer on
-    # a side stream, and a writer thread appends them to `embeddings` and to the flat index `landmarkValue` (the
-    # reference adds to the index and writes both files after its loop, builder.py:105-136; the bytes are the same).  No
-    # device-to-host wait in the loop, and nothing left to copy or write when the last group is through.
-    f_emb = open(os.path.join(dir_for_db, "embeddings"), "wb")
-    f_idx = faissio.FlatIndexWriter(os.path.join(dir_for_db, "landmarkValue"), d)
+    # a side stream, and a writer thread puts them at their rows of `embeddings` and of the flat index `landmarkValue`
+    # (the reference adds to the index and writes both files after its loop, builder.py:105-136; the bytes are the same).
+    # No device-to-host wait in the loop, and nothing left to copy or write when the last group is through.  Several
+    # ranks: every rank writes the rows of the groups IT embedded, in place; nothing is funnelled through rank 0.
+    p_emb, p_idx = os.path.join(dir_for_db, "embeddings"), os.path.join(dir_for_db, "landmarkValue")
+    if rank0:
+        os.makedirs(dir_for_db, exist_ok=True)
+        open(p_emb, "wb").close()
+        with open(p_idx, "wb") as f:
+            faissio.write_header(f, d, 0)
+    if ranks is not None:
+        ranks.barrier()
+    fd_emb, fd_idx = os.open(p_emb, os.O_WRONLY), os.open(p_idx, os.O_WRONLY)
     wq = queue.Queue(maxsize=4)
     werr = []
 
+    def pwrite_all(fd, view, off):
+        done = 0
+        while done < len(view):
+            done += os.pwrite(fd, view[done:], off + done)
+
     def writer():
-        try:
-            while True:
-                got = wq.get()
-                if got is None:
-                    return
-                ev, host, rows = got
+        while True:
+            got = wq.get()
+            if got is None:
+                return
+            if werr:                            # after a failure: keep draining so that the producer never blocks
+                continue
+            try:
+                ev, host, rows, row0 = got
                 ev.synchronize()
-                a = host[:rows * d].numpy().reshape(rows, d)
                 if rows:
-                    f_emb.write(memoryview(a).cast("B"))
-                f_idx.append(a)
+                    view = memoryview(host[:rows * d].numpy()).cast("B")
+                    pwrite_all(fd_emb, view, row0 * d * 4)
+                    pwrite_all(fd_idx, view, faissio.HEADER_BYTES + row0 * d * 4)
                 free_bufs.put(host)
-        except BaseException as x:          # noqa: B902 -- reported by the main thread
-            werr.append(x)
+            except BaseException as x:          # noqa: B902 -- reported by the main thread
+                werr.append(x)
 
     free_bufs = queue.Queue()
     wt = threading.Thread(target=writer, name="pfann-db-writer", daemon=True)
     wt.start()
     side = torch.cuda.Stream(device=engine.device)
-    for items in embed_file_batches(engine, dataset, dataset.hop, batch_windows=max_batch, timer=timer):
-        embs = []
-        for idx, n_seg, emb in items:
-            landmark_key[idx] = n_seg
-            if n_seg:
-                embs.append(emb)
-                total += n_seg
-        if not embs or werr:
-            continue
-        g = torch.cat(embs) if len(embs) > 1 else embs[0]
-        rows = int(g.shape[0])
-        try:
-            host = free_bufs.get_nowait()
-            if host.numel() < rows * d:
+    ok = False
+    try:
+        for items in embed_file_batches(engine, dataset, dataset.hop, batch_windows=max_batch, timer=timer, ranks=ranks):
+            row0 = total                          # first row of THIS rank's group
+            if multi:
+                for r, (p, c) in enumerate(items.groups):
+                    n_r = sum(n for _, n in items.files[p:p + c])
+                    if r < ranks.rank:
+                        row0 += n_r
+                for idx, n_seg in items.files:    # every rank keeps the whole key: rank 0 writes it
+                    landmark_key[idx] = n_seg
+                    total += n_seg
+            embs = []
+            for idx, n_seg, emb in items:
+                if n_seg:
+                    embs.append(emb)
+                if not multi:
+                    landmark_key[idx] = n_seg
+                    total += n_seg
+            if werr:
+                break
+            if not embs:
+                continue
+            g = torch.cat(embs) if len(embs) > 1 else embs[0]
+            rows = int(g.shape[0])
+            try:
+                host = free_bufs.get_nowait()
+                if host.numel() < rows * d:
+                    host = None
+            except queue.Empty:
                 host = None
-        except queue.Empty:
-            host = None
-        if host is None:
-            host = torch.empty(max(rows, max_batch) * d, dtype=torch.float32, pin_memory=True)
-        ready = torch.cuda.Event()
-        ready.record()
-        with torch.cuda.stream(side):
-            side.wait_event(ready)
-            host[:rows * d].copy_(g.reshape(-1), non_blocking=True)
-            g.record_stream(side)
-            ev = torch.cuda.Event()
-            ev.record(side)
-        wq.put((ev, host, rows))
-    with timer.stage("download embeddings"):
-        wq.put(None)
-        wt.join()
-    f_emb.close()
-    f_idx.close()
-    if werr:
-        raise werr[0]
-    print("total", total, "embeddings")
+            if host is None:
+                host = torch.empty(max(rows, max_batch) * d, dtype=torch.float32, pin_memory=True)
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                host[:rows * d].copy_(g.reshape(-1), non_blocking=True)
+                g.record_stream(side)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            wq.put((ev, host, rows, row0))         # (the writer always drains: this cannot block for good)
+        with timer.stage("download embeddings"):
+            wq.put(None)
+            wt.join()
+        if werr:
+            raise werr[0]
+        ok = True
+    finally:
+        if not ok:                                 # stop the writer, leave no half-written database behind
+            if wt.is_alive():
+                werr.append(RuntimeError("build aborted"))
+                wq.put(None)
+                wt.join()
+        os.close(fd_emb)
+        os.close(fd_idx)
+        if not ok and rank0:
+            for pth in (p_emb, p_idx):
+                try:
+                    os.remove(pth)
+                except OSError:
+                    pass
+    if ranks is not None:
+        ranks.barrier()                            # every rank's rows are on disk
+    if rank0:
+        with open(p_idx, "r+b") as f:
+            faissio.write_header(f, d, total)
+    say("total", total, "embeddings")
     if total == 0:
-        print("The database is empty!")
-    print("writing database")
-    landmark_key.tofile(os.path.join(dir_for_db, "landmarkKey"))
-    shutil.copyfile(file_list_for_db, os.path.join(dir_for_db, "songList.txt"))
-    shutil.copyfile(configs, os.path.join(dir_for_db, "configs.json"))
-    shutil.copyfile(model_pt, os.path.join(dir_for_db, "model.pt"))
+        say("The database is empty!")
+    say("writing database")
+    if rank0:
+        landmark_key.tofile(os.path.join(dir_for_db, "landmarkKey"))
+        shutil.copyfile(file_list_for_db, os.path.join(dir_for_db, "songList.txt"))
+        shutil.copyfile(configs, os.path.join(dir_for_db, "configs.json"))
+        shutil.copyfile(model_pt, os.path.join(dir_for_db, "model.pt"))
     for name, secs in timer.t.items():                   # one stage per line, the format tools/stat.py:17 parses
-        print("%s %.6fs" % (name, secs))
-    print("total build time %.3fs" % (time.time() - t0))
+        say("%s %.6fs" % (name, secs))
+    say("total build time %.3fs" % (time.time() - t0))
+    finish_ranks(ranks)
     return 0
 
 

@@ -74,6 +74,7 @@ struct pfann_ctx {
     bool gram_ready = false;
     bool fused = false;             // LayerNorm fused into the GEMMs (encoder_fused.hip)
     int precision = 0;              // 0: fp32 MFMA (exact); 1: 3-term fp16 split on the fp16 MFMA (opt-in)
+    int64_t plan_batch = 0;         // pfann_set_plan_batch: kernel variants chosen for this batch size (0: each call's own)
     int n_streams = 1;              // sub-batches run on this many internal streams (MFMA-bound GEMMs of one
                                     // sub-batch overlap the HBM-bound LayerNorm passes of another)
     hipStream_t side[8] = {};
@@ -424,7 +425,8 @@ static int encode_chunk_fused(pfann_ctx *c, const float *mel, int64_t B, float *
     } else if (launch_conv_first_stats(c->sub[0], mel, fold_first ? nullptr : buf[0], part[0], B, g.activation, g.relu_after_bn, s)) {
         return -1;
     }
-    int P = fused_out_slots(c->sub[0], B);
+    const int64_t Bp = c->plan_batch > 0 ? c->plan_batch : B;
+    int P = fused_out_slots(c->sub[0], Bp);
     if (c->keep && keep_tap_fused(c, 0, buf[0], part[0], P, B, s)) return -1;
     int stats_final = 0;             // c->stats already holds (mean, rstd) of the next layer's input (split-K reduction)
     for (int i = 1; i < 16; ++i) {
@@ -435,12 +437,12 @@ static int encode_chunk_fused(pfann_ctx *c, const float *mel, int64_t B, float *
                                   buf[i & 1], part[i & 1], B, g.activation, g.relu_after_bn, first ? &c->sub[0] : nullptr, s)) return -1;
         } else if (launch_conv_gemm_ln(c->sub[i], c->sub[i - 1], first ? mel : buf[(i - 1) & 1], part[(i - 1) & 1], P, c->stats + slot0 * 2, buf[i & 1],
                                 part[i & 1], B, g.activation, g.relu_after_bn, first ? &c->sub[0] : nullptr, c->precision, s,
-                                c->n_streams == 1 || B < 128 ? c->splitk : nullptr, c->splitk_bytes, &stats_final)) return -1;
-        P = fused_out_slots(c->sub[i], B);
+                                c->n_streams == 1 || B < 128 ? c->splitk : nullptr, c->splitk_bytes, &stats_final, Bp)) return -1;
+        P = fused_out_slots(c->sub[i], Bp);
         if (c->keep && keep_tap_fused(c, i, buf[i & 1], part[i & 1], P, B, s)) return -1;
     }
     return launch_myg_ln(c->sub[15], buf[1], part[1], P, g.activation, g.relu_after_bn, c->g_w1, c->g_b1,
-                         c->g_w2, c->g_b2, g.d, g.u, g.h / g.d, B, emb, normalize, s);
+                         c->g_w2, c->g_b2, g.d, g.u, g.h / g.d, B, emb, normalize, s, Bp);
 }
 
 static int encode_chunk1(pfann_ctx *c, const float *mel, int64_t B, float *emb, int normalize, hipStream_t s,
@@ -554,6 +556,11 @@ int pfann_pcm16_files_to_mono(pfann_ctx *c, const void *const *host_pcm, const i
 }
 
 void pfann_debug_keep(pfann_ctx *c, int on) { c->keep = on != 0; }
+
+int64_t pfann_set_plan_batch(pfann_ctx *c, int64_t n) {
+    c->plan_batch = n <= 0 ? 0 : (n < 65 ? 65 : n);      // a plan below 65 would select the small-batch kernels, whose
+    return c->plan_batch;                                // scratch is sized for actual batches of at most 64
+}
 
 int pfann_set_streams(pfann_ctx *c, int n) {
     c->n_streams = n < 1 ? 1 : (n > 8 ? 8 : n);
@@ -782,7 +789,13 @@ int pfann_match(pfann_db *db, const float *q, const int64_t *labels, int k, cons
     a.db = db->emb; a.dbh = db->emb_h; a.n = db->n; a.d = db->d; a.label_base = db->label_base;
     a.song_pos = db->song_pos; a.n_songs = db->n_songs; a.song_lo = db->song_lo; a.song_hi = db->song_hi;
     a.q = q; a.labels = labels; a.k = k; a.qstart = qstart; a.qlen = qlen; a.nQ = nQ;
-    a.fsm = frame_shift_mul; a.alpha = score_alpha; a.mode = mode; a.only_owned = only_owned;
+    a.fsm = frame_shift_mul; a.alpha = score_alpha; a.mode = mode; a.only_owned = only_owned & 1;
+    // bit 1 of only_owned (PFANN_MATCH_OWNED_BLOCK): song_scores is [nQ][owned songs][2] instead of [nQ][n_songs][2]
+    a.ss_lo = 0; a.ss_n = db->n_songs;
+    if (only_owned & 2) {
+        if (!(only_owned & 1)) { set_error("match: the owned-songs score block needs only_owned candidates"); return -1; }
+        a.ss_lo = db->song_lo; a.ss_n = db->song_hi - db->song_lo;
+    }
     int P = 1;
     while (P < (int64_t)max_qlen * k) P <<= 1;
     a.pmax = P;
@@ -804,6 +817,18 @@ int pfann_match(pfann_db *db, const float *q, const int64_t *labels, int k, cons
     }
     a.results = results; a.song_scores = song_scores;
     return launch_match(a, (hipStream_t)stream);
+}
+
+int pfann_song_scores_to_seconds(pfann_db *db, float *song_scores_dev, int64_t n_pairs, int frame_shift_mul, double hop_size,
+                                 void *stream) {
+    PF_HIP(hipSetDevice(db->device));
+    return launch_song_scores_to_seconds(song_scores_dev, n_pairs, frame_shift_mul, hop_size, (hipStream_t)stream);
+}
+
+int pfann_db_owned_songs(pfann_db *db, int *song_lo, int *song_hi) {
+    if (song_lo) *song_lo = db->song_lo;
+    if (song_hi) *song_hi = db->song_hi;
+    return db->song_hi - db->song_lo;
 }
 
 int pfann_match_pack(pfann_db *db, const pfann_match_result *results_dev, int64_t nQ, uint64_t *keys_dev, void *stream) {

@@ -1016,7 +1016,8 @@ static int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
 int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, const float *in_part, int in_P,
                         float *in_stats, float *y, float *out_part, int64_t B, int act, int after_bn,
                         const SubLayer *Lfirst, int precision, hipStream_t s, float *splitk_scratch, size_t splitk_bytes,
-                        int *stats_final) {
+                        int *stats_final, int64_t Bplan) {
+    const int64_t Bp = Bplan > 0 ? Bplan : B;      // the batch the kernel variant is chosen for (kernels.h)
     // stats_final (in/out, may be null): in: in_stats already holds (mean, rstd) of the input (written by the previous
     // layer's split-K reduction) -> no ln_finalize launch; out: whether this layer left its OUTPUT statistics there.
     const bool in_final = stats_final != nullptr && *stats_final != 0;
@@ -1038,7 +1039,7 @@ int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, 
     p.in_stats = in_stats;
     p.ln_w = Lin.ln_w; p.ln_b = Lin.ln_b;
     p.in_elems = (int64_t)L.F * L.T * L.ci;
-    p.out_part = out_part; p.out_P = fused_out_slots(L, B);
+    p.out_part = out_part; p.out_P = fused_out_slots(L, Bp);
     p.act = act; p.after_bn = after_bn;
     p.n_samples = (int)B;
     p.w1 = nullptr; p.b1 = nullptr; p.T0 = 0; p.s1 = 1; p.pad1 = 0;
@@ -1070,7 +1071,7 @@ int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, 
         else if (relu_bn) PF_LAUNCH((conv_gemm_ln_kernel<BM, BN, WM, WN, true, false, UNI_>), g, t, 0, s, p);      \
         else PF_LAUNCH((conv_gemm_ln_kernel<BM, BN, WM, WN, false, false, UNI_>), g, t, 0, s, p);                  \
     } while (0)
-    if (gemm_tile(L, B) == 128) {
+    if (gemm_tile(L, Bp) == 128) {
         p.n_tiles_n = cdiv(p.N, 128);
         p.dv_n = make_fastdiv(p.n_tiles_n); p.dv_tile = make_fastdiv(64 * p.n_tiles_n);
         p.dv_group = make_fastdiv(64 * (p.rows_per_sample >= 128 ? p.rows_per_sample / 128 : 1) * p.n_tiles_n);
@@ -1113,7 +1114,7 @@ int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, 
         static const int chunk_kt = getenv("PFANN_SPLITK_CHUNK") ? atoi(getenv("PFANN_SPLITK_CHUNK")) : 8;
         const int n_splits = (nk + chunk_kt - 1) / chunk_kt;
         static const bool no_splitk = getenv("PFANN_NO_SPLITK") != nullptr;
-        if (uni && !first && !no_splitk && B <= 64 && blocks < 192 && nk >= 16 && chunk_kt > 0 && (p.k_end - p.k_begin) % 32 == 0 && n_splits > 1 &&
+        if (uni && !first && !no_splitk && B <= 64 && Bp <= 64 && blocks < 192 && nk >= 16 && chunk_kt > 0 && (p.k_end - p.k_begin) % 32 == 0 && n_splits > 1 &&
             splitk_scratch != nullptr && (size_t)n_splits * p.M * p.N * sizeof(float) <= splitk_bytes) {
             p.blocks_mn = (int)blocks;
             p.k_chunk = chunk_kt * 32;
@@ -1581,14 +1582,14 @@ __global__ __launch_bounds__(1024) void myg_ln_small_kernel(const float *__restr
 
 int launch_myg_ln(const SubLayer &Llast, const float *z, const float *part, int P, int act, int after_bn,
                   const float *w1, const float *b1, const float *w2, const float *b2, int d, int u, int v, int64_t B,
-                  float *emb, int normalize, hipStream_t s) {
+                  float *emb, int normalize, hipStream_t s, int64_t Bplan) {
     if (v > 32) { set_error("MyG: h/d = %d > 32 unsupported", v); return -1; }
     const int nt = ((d + 63) / 64) * 64;
     if (nt > 1024) { set_error("MyG: d = %d > 1024 unsupported", d); return -1; }
     ProfScope ps("myg_ln", s);
     static const bool no_small = getenv("PFANN_NO_SMALL_HEAD") != nullptr;
     const size_t small_lds = ((size_t)d * v + (size_t)d * u) * sizeof(float);
-    if (B <= 64 && !no_small && small_lds <= 60 * 1024) {
+    if (B <= 64 && (Bplan <= 0 || Bplan <= 64) && !no_small && small_lds <= 60 * 1024) {
         int thr = d * u < 1024 ? ((d * u + 63) / 64) * 64 : 1024;
         if (thr < nt) thr = nt;
         PF_LAUNCH(myg_ln_small_kernel, dim3((unsigned)B), dim3(thr), small_lds, s, z, part, P, Llast.ln_w, Llast.ln_b, act, after_bn,

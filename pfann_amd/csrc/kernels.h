@@ -44,14 +44,16 @@ int launch_conv_first_gram_stats(const SubLayer &L, const float *x, float *part,
 int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, const float *in_part, int in_P,
                         float *in_stats, float *y, float *out_part, int64_t B, int act, int after_bn,
                         const SubLayer *Lfirst, int precision, hipStream_t s, float *splitk_scratch = nullptr,
-                        size_t splitk_bytes = 0, int *stats_final = nullptr);
+                        size_t splitk_bytes = 0, int *stats_final = nullptr, int64_t Bplan = 0);
 int launch_conv_dw_ln(const SubLayer &L, const SubLayer &Lin, const float *x, const float *in_part, int in_P, float *in_stats,
                       float *y, float *out_part, int64_t B, int act, int after_bn, const SubLayer *Lfirst, hipStream_t s);
 int launch_ln_apply(const SubLayer &L, const float *z, const float *part, int P, float *out, int64_t B, int act,
                     int after_bn, hipStream_t s);
 int launch_myg_ln(const SubLayer &Llast, const float *z, const float *part, int P, int act, int after_bn,
                   const float *w1, const float *b1, const float *w2, const float *b2, int d, int u, int v, int64_t B,
-                  float *emb, int normalize, hipStream_t s);
+                  float *emb, int normalize, hipStream_t s, int64_t Bplan = 0);
+// Bplan (pfann_set_plan_batch): the batch size the kernel VARIANTS (tile size, split-K, small-batch head) are chosen for;
+// 0 = the launch's own B.  With a fixed plan a segment's fingerprint has the same bits in every batch it is part of.
 
 // ---- search.hip ----------------------------------------------------------------------
 struct SearchWorkspace {
@@ -108,10 +110,12 @@ struct RerankArgs {
     int *ncand;             // [nQ] scratch of the phased launch (few queries: scoring spread over the whole GPU)
     int phase;              // 0: whole query in one workgroup; 1: candidates; 2: scores; 3: argmax (1-3 need gkeys)
     pfann_match_result *results; float *song_scores;
+    int ss_lo, ss_n;        // the song_scores block of one query covers songs [ss_lo, ss_lo + ss_n): all, or the owned ones
 };
 int launch_match(const RerankArgs &a, hipStream_t s);
 int launch_match_pack(const pfann_match_result *res, int64_t nQ, unsigned long long *keys, hipStream_t s);
 int launch_match_pick(const unsigned long long *keys, int G, int64_t nQ, pfann_match_result *out, hipStream_t s);
+int launch_song_scores_to_seconds(float *ss, int64_t n_pairs, int fsm, double hop_size, hipStream_t s);
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): the attribute is per device
 int ensure_dyn_lds(const void *func, int bytes);
 

@@ -378,7 +378,7 @@ __global__ __launch_bounds__(NT) void match_kernel(RerankArgs a) {
     }
     // ---- per-song best (only recorded when > the zero-initialised slot)
     if (a.song_scores != nullptr) {
-        float *ss = a.song_scores + (int64_t)qi * a.n_songs * 2;
+        float *ss = a.song_scores + ((int64_t)qi * a.ss_n - a.ss_lo) * 2;       // indexed by GLOBAL song id below
         if (a.mode == 1 || a.fsm == 1) {
             // one song = one contiguous run of the sorted list: the run's first max wins
             for (int c = tid; c < nc; c += NT) {
@@ -459,6 +459,26 @@ __global__ void match_pick_kernel(const unsigned long long *__restrict__ keys, i
     }
     out[j] = r;
 }
+// per-song slot 1: alignment in fine frames (t * fsm - shift) -> seconds, (t - shift / fsm) * hop_size, computed in double
+// like the reference's Python floats (database.py:148,193) and stored as float32; slots never written hold 0 -> 0 s
+__global__ void song_scores_to_seconds_kernel(float *__restrict__ ss, int64_t n_pairs, int fsm, double hop_size) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs) return;
+    const long long fine = (long long)ss[2 * i + 1];
+    long long shift = (-fine) % fsm;
+    if (shift < 0) shift += fsm;
+    const long long t = (fine + shift) / fsm;
+    ss[2 * i + 1] = (float)(((double)t - (double)shift / (double)fsm) * hop_size);
+}
+int launch_song_scores_to_seconds(float *ss, int64_t n_pairs, int fsm, double hop_size, hipStream_t s) {
+    if (n_pairs <= 0) return 0;
+    if (fsm < 1) { set_error("song_scores_to_seconds: frame_shift_mul=%d", fsm); return -1; }
+    ProfScope ps("song_scores_to_seconds", s);
+    PF_LAUNCH(song_scores_to_seconds_kernel, dim3((unsigned)cdiv(n_pairs, 256)), dim3(256), 0, s, ss, n_pairs, fsm, hop_size);
+    PF_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_match_pack(const pfann_match_result *res, int64_t nQ, unsigned long long *keys, hipStream_t s) {
     if (nQ <= 0) return 0;
     PF_LAUNCH(match_pack_kernel, dim3((unsigned)cdiv(nQ, 256)), dim3(256), 0, s, res, nQ, keys);

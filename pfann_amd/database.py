@@ -161,10 +161,24 @@ class DeviceIndex:
         _l.check(self.lib.pfann_match_pick(self.handle, all_keys.data_ptr(), G, nQ, out.data_ptr(), self._stream()), "pfann_match_pick")
         return self.results_to_host(out) if to_host else out
 
+    def owned_songs(self):
+        """-> (song_lo, song_hi): the songs whose rows all live in this shard"""
+        lo, hi = ctypes.c_int(0), ctypes.c_int(0)
+        self.lib.pfann_db_owned_songs(self.handle, ctypes.byref(lo), ctypes.byref(hi))
+        return lo.value, hi.value
+
+    def song_scores_to_seconds(self, ss, fsm, hop_size):
+        """in place: the alignment slot of every (score, alignment) pair of a song_scores block, fine frames -> seconds"""
+        if ss is not None and ss.numel():
+            _l.check(self.lib.pfann_song_scores_to_seconds(self.handle, ss.data_ptr(), ss.numel() // 2, int(fsm), float(hop_size),
+                                                           self._stream()), "pfann_song_scores_to_seconds")
+        return ss
+
     def match(self, q, labels, qstart, qlen, fsm=1, alpha=0.0, mode=0, only_owned=False, want_song_scores=False,
-              to_host=True):
+              to_host=True, owned_block=False):
         """Sequence matcher for nQ queries.  Returns (results structured array -- or, with to_host=False, the device
-        tensor of results --, song_scores or None)."""
+        tensor of results --, song_scores or None).  owned_block (with only_owned): song_scores is [nQ, owned songs, 2],
+        this shard's columns of the score matrix, instead of [nQ, n_songs, 2]."""
         q = q.to(self.device, torch.float32).contiguous()
         labels = labels.to(self.device, torch.int64).contiguous()
         qs_np = np.ascontiguousarray(qstart, dtype=np.int64)
@@ -197,11 +211,12 @@ class DeviceIndex:
             res = torch.empty((nQ, rsz), device=self.device, dtype=torch.uint8)
         ss = None
         if want_song_scores:
-            ss = torch.zeros((nQ, self.n_songs, 2), device=self.device, dtype=torch.float32)
+            lo, hi = self.owned_songs() if owned_block else (0, self.n_songs)
+            ss = torch.zeros((nQ, hi - lo, 2), device=self.device, dtype=torch.float32)
         if nQ:
             _l.check(self.lib.pfann_match(self.handle, q.data_ptr(), labels.data_ptr(), k, qs.data_ptr(),
                                           ql.data_ptr(), nQ, int(ql_np.max()), fsm, float(alpha), mode,
-                                          1 if only_owned else 0, res.data_ptr(),
+                                          (1 if only_owned else 0) | (2 if owned_block else 0), res.data_ptr(),
                                           ss.data_ptr() if ss is not None else None, self._stream()),
                      "pfann_match")
         if not to_host:
@@ -224,7 +239,14 @@ def _fine_to_time(fine, fsm, hop_size):
 
 
 class Database:
-    def __init__(self, dir_for_db, indexer_params, hop_size, device=0, d=None, storage=None):
+    def __init__(self, dir_for_db, indexer_params, hop_size, device=0, d=None, storage=None, ranks=None):
+        """ranks: a pfann_amd.dist.Ranks (one process per GPU).  With more than one rank (or PFANN_FORCE_SHARDED=1) the
+        database is sharded by whole songs: this process reads and holds only its contiguous song range, every query
+        method is then COLLECTIVE (all ranks call it with the same arguments and get the same answers), and the
+        batched form hands back this shard's columns of the per-song score matrix (song_range)."""
+        self.ranks = ranks if (ranks is not None and ranks.sharded) else None
+        if ranks is not None:
+            device = ranks.device
         self.dir_for_db = dir_for_db
         self.params = indexer_params
         self.top_k = self.params["top_k"]
@@ -238,26 +260,45 @@ class Database:
         assert len(self.songList) == key.shape[0]
         self.song_pos = song_pos_from_key(key)
 
+        n_songs, n_rows = len(self.songList), int(self.song_pos[-1])
+        self.song_range = (0, n_songs)                           # songs whose score columns this process holds
+        r_lo, r_hi = 0, n_rows
+        if self.ranks is not None:
+            from .dist import shard_songs
+            self.song_range = shard_songs(self.song_pos, self.ranks.world)[self.ranks.rank]
+            r_lo, r_hi = int(self.song_pos[self.song_range[0]]), int(self.song_pos[self.song_range[1]])
         emb = None
         lv = os.path.join(dir_for_db, "landmarkValue")
         if os.path.exists(lv):
             try:
-                emb, _ = faissio.read_index_flat(lv)
+                emb, _, n_all = faissio.read_index_flat(lv, rows=(r_lo, r_hi))
+                assert n_all == n_rows, "landmarkValue rows != sum(landmarkKey)"
             except (ValueError, struct.error, OSError, IndexError) as x:   # not a flat index / truncated file
                 print("landmarkValue unusable (%s): falling back to the raw embeddings file" % x)
+                emb = None
         if emb is None:                                         # database.py:96-97 fallback
             if d is None:
                 cfg = os.path.join(dir_for_db, "configs.json")
                 d = json.load(open(cfg))["model"]["d"]
-            emb = np.fromfile(os.path.join(dir_for_db, "embeddings"), dtype=np.float32).reshape(-1, d)
+            path = os.path.join(dir_for_db, "embeddings")
+            assert os.path.getsize(path) == n_rows * d * 4, "embeddings rows != sum(landmarkKey)"
+            emb = np.fromfile(path, dtype=np.float32, count=(r_hi - r_lo) * d, offset=r_lo * d * 4).reshape(-1, d)
         self.d = emb.shape[1] if emb.ndim == 2 and emb.shape[0] else (d or emb.shape[-1])
-        assert emb.shape[0] == self.song_pos[-1], "embeddings rows != sum(landmarkKey)"
+        assert emb.shape[0] == r_hi - r_lo, "embeddings rows != sum(landmarkKey)"
         # "use_float16" in the indexer params (or PFANN_DB_STORAGE=f16) selects fp16-only storage: the knob the
         # reference hard-codes as co.useFloat16 = True for its GPU index (database.py:101-104)
         if storage is None:
             storage = os.environ.get("PFANN_DB_STORAGE") or ("f16" if self.params.get("use_float16", False) else "f32")
         self.index = DeviceIndex(self.d, device, storage)
-        self.index.load(emb, self.song_pos, 0)
+        self.index.load(emb, self.song_pos, r_lo)
+        self.sharded = None
+        if self.ranks is not None:
+            from .dist import ShardedIndex
+            self.sharded = ShardedIndex(self.index, self.song_pos, self.top_k, self.frame_shift_mul, self.score_alpha,
+                                        group=self.ranks.group, always_exchange=self.ranks.world == 1)
+        # per-song score blocks of one launch: at most this many (score, alignment) pairs in HBM (and as many in the
+        # pinned landing buffer); the CLIs split a launch group's queries accordingly (query_launch_chunks)
+        self.max_score_pairs = int(float(os.environ.get("PFANN_SCORE_BLOCK_MB", "1024")) * (1 << 20)) // 8
 
     def warmup(self, rows=19 * 64):
         """throw-away queries through search + match: kernel code objects and scratch buffers exist afterwards.  rows: the
@@ -279,19 +320,39 @@ class Database:
         dev = self.index.device
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         ev[0].record()
-        D, I = self.index.search(emb, self.top_k)
-        ev[1].record()
-        res, ss = self.index.match(emb, I, qstart, qlen, self.frame_shift_mul, self.score_alpha, mode,
-                                   False, want_song_scores, to_host=False)
+        if self.sharded is not None:
+            # song-sharded: two-phase shard search + all-to-all merge (`search`), owner-side match + 128-bit key
+            # all-gather + device pick (`rerank`); `res` are the winners over ALL shards, `ss` this shard's columns
+            D, I = self.sharded.search_global(emb)
+            ev[1].record()
+            res, ss = self.sharded.match_global(emb, I, qstart, qlen, want_song_scores, mode)
+        else:
+            D, I = self.index.search(emb, self.top_k)
+            ev[1].record()
+            res, ss = self.index.match(emb, I, qstart, qlen, self.frame_shift_mul, self.score_alpha, mode,
+                                       False, want_song_scores, to_host=False)
         ev[2].record()
-        if ss is not None:
-            # frames -> seconds where the block lives (database.py:148,193 do it on the host): (t - shift/fsm) * hop_size
-            # with fine = t*fsm - shift, in double like the reference's Python floats, stored as float32
-            fine = ss[:, :, 1].to(torch.int64)
-            shift = (-fine) % self.frame_shift_mul
-            t = (fine + shift) // self.frame_shift_mul
-            ss[:, :, 1] = ((t.double() - shift.double() / self.frame_shift_mul) * self.hop_size).float()
+        # frames -> seconds where the block lives (database.py:148,193 do it on the host): (t - shift/fsm) * hop_size
+        # with fine = t*fsm - shift, in double like the reference's Python floats, stored as float32
+        self.index.song_scores_to_seconds(ss, self.frame_shift_mul, self.hop_size)
         return {"res": res, "ss": ss, "ev": ev, "nq": len(qlen), "keep": (emb, I), "dev": dev}
+
+    def query_launch_chunks(self, emb, qstart, qlen, want_song_scores=False, mode=0):
+        """query_launch over as many sub-launches as the score-block budget asks for (PFANN_SCORE_BLOCK_MB, default
+        1024: one-segment queries against a 100 k-song database would otherwise want 7.8 GB of HBM and as much pinned
+        host memory per launch group).  -> [(first query, one past the last, launch)]"""
+        nq = len(qlen)
+        width = max(self.song_range[1] - self.song_range[0], 1)
+        step = nq if not want_song_scores else max(1, min(nq, self.max_score_pairs // width))
+        qstart = np.asarray(qstart, dtype=np.int64)
+        out = []
+        for j0 in range(0, nq, step):
+            j1 = min(j0 + step, nq)
+            r0 = int(qstart[j0])
+            r1 = int(qstart[j1 - 1]) + int(qlen[j1 - 1])
+            sub = emb if (j0 == 0 and j1 == nq) else emb[r0:r1]
+            out.append((j0, j1, self.query_launch(sub, qstart[j0:j1] - r0, qlen[j0:j1], want_song_scores, mode)))
+        return out
 
     def _pinned(self, shape, dtype):
         """one reusable pinned landing buffer per result kind (a pinned allocation costs milliseconds)"""
@@ -344,6 +405,15 @@ class Database:
     def query_embeddings(self, query):
         q = torch.as_tensor(np.ascontiguousarray(query, dtype=np.float32)) if not isinstance(query, torch.Tensor) else query
         q = q.to(self.index.device)
+        if self.sharded is not None:
+            # the reference's tuple on every rank: the shards' score columns all-gathered into the [n_songs, 2] block
+            from .dist import all_gather_ragged, shard_songs
+            p = self.query_launch(q, [0], [q.shape[0]], want_song_scores=True)
+            counts = [hi - lo for lo, hi in shard_songs(self.song_pos, self.ranks.world)]
+            full = all_gather_ragged(p["ss"][0], counts, self.ranks.group).cpu().numpy()
+            p["ss"] = None
+            (score, best_song_t, _), = self.query_finish(p)
+            return score, best_song_t, full
         (score, best_song_t, song_score), = self.query_batch(q, [0], [q.shape[0]], want_song_scores=True)
         return score, best_song_t, song_score
 

@@ -16,9 +16,104 @@ sequence score only touches consecutive rows of one song.
 The compute backend is any object with the DeviceIndex interface
 (search / merge_topk / match); the product uses pfann_amd.database.DeviceIndex (HIP).
 """
+import os
+import sys
+
 import numpy as np
 import torch
 import torch.distributed as dist
+
+
+class Ranks:
+    """The process group a product entry point (builder.py / matcher.py / extractemb.py / matchemb.py, `Database`) runs
+    in: one process per GPU.  `group` carries the data collectives (RCCL; gloo when PFANN_DIST_BACKEND=gloo), `meta` is
+    a gloo group for small host-side metadata (segment counts of a launch group, barriers around file creation) that
+    must not queue behind GPU work."""
+
+    def __init__(self, rank, world, device, backend, meta=None, force_sharded=False):
+        self.rank, self.world, self.device, self.backend = rank, world, device, backend
+        self.group = None                      # the default group
+        self.meta = meta
+        self.sharded = world > 1 or force_sharded
+
+    def barrier(self):
+        dist.barrier(group=self.meta)
+
+    def sum_host(self, arr):
+        """element-wise SUM of a small int64 host array over the ranks (gloo, never touches a HIP stream)"""
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int64).copy())
+        if self.world > 1:
+            dist.all_reduce(t, group=self.meta)
+        return t.numpy()
+
+    def max_host(self, value):
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.meta)
+        return float(t.item())
+
+
+def self_launch_if_asked(argv):
+    """`PFANN_GPUS=N python matcher.py ...` (N > 1, or "all") without a launcher: start N ranks of this very command,
+    one per GPU, through torch.distributed.run on 127.0.0.1, and return their exit status; None when there is nothing
+    to launch (no PFANN_GPUS, N == 1, or already running as a rank).  Refuses to start fewer RCCL ranks than asked for."""
+    want = os.environ.get("PFANN_GPUS", "")
+    if not want or "WORLD_SIZE" in os.environ:
+        return None
+    backend = os.environ.get("PFANN_DIST_BACKEND", "nccl")
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    n = have if want == "all" else int(want)
+    if n <= 1 and os.environ.get("PFANN_FORCE_SHARDED", "0") == "0":
+        return None
+    if backend == "nccl" and "PFANN_FORCE_DEVICE" not in os.environ and have < n:
+        print("PFANN_GPUS=%d: only %d HIP device(s) visible; an RCCL job needs one device per rank -- refusing to run fewer "
+              "ranks than asked for" % (n, have), file=sys.stderr)
+        return 2
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(max(n, 1)),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(argv[0])] + list(argv[1:])
+    return subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+
+
+def init_ranks():
+    """-> Ranks when this process was started as one rank of a job (WORLD_SIZE in the environment: torch.distributed.run,
+    or self_launch_if_asked), else None.  One rank per GPU (LOCAL_RANK; PFANN_FORCE_DEVICE pins every rank to one device:
+    a debugging aid for one-GPU boxes together with PFANN_DIST_BACKEND=gloo).  PFANN_FORCE_SHARDED=1 runs the sharded
+    protocol even at world 1, so every collective really goes through the backend."""
+    if "WORLD_SIZE" not in os.environ:
+        return None
+    backend = os.environ.get("PFANN_DIST_BACKEND", "nccl")
+    local = int(os.environ.get("PFANN_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    if torch.cuda.is_available():
+        if local >= torch.cuda.device_count():
+            raise RuntimeError("rank %s wants HIP device %d but only %d are visible" %
+                               (os.environ.get("RANK"), local, torch.cuda.device_count()))
+        torch.cuda.set_device(local)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if not dist.is_initialized():
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    meta = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else None
+    r = Ranks(dist.get_rank(), dist.get_world_size(), local, dist.get_backend(), meta,
+              force_sharded=os.environ.get("PFANN_FORCE_SHARDED", "0") != "0")
+    if backend == "nccl" and r.world > 1:
+        seen = [None] * r.world
+        dist.all_gather_object(seen, local, group=meta)
+        if len(set(seen)) != r.world:
+            raise RuntimeError("%d ranks share HIP devices %r: RCCL needs one device per rank" % (r.world, seen))
+    return r
+
+
+def finish_ranks(ranks):
+    if ranks is not None and dist.is_initialized():
+        dist.barrier(group=ranks.meta)
+        dist.destroy_process_group()
 
 
 def shard_songs(song_pos, world):
@@ -134,6 +229,16 @@ class ShardedIndex:
         gD = all_gather_rows(Dm, self.group).reshape(G * Qs, k)[:Q]
         gI = all_gather_rows(Im, self.group).reshape(G * Qs, k)[:Q]
         return gD.contiguous(), gI.contiguous()
+
+    def match_global(self, q, I, qstart, qlen, want_song_scores=False, mode=0):
+        """Second half of a sharded query, given the GLOBAL labels of search_global: -> (winners over all shards: device
+        tensor of results, identical on all ranks; this shard's song_scores block [nQ, owned songs, 2] with alignments in
+        fine frames, or None).  Nothing is read back."""
+        res, ss = self.b.match(q, I, qstart, qlen, self.fsm, self.alpha, mode, True, want_song_scores, to_host=False,
+                               owned_block=True)
+        keys = self.b.pack_winner_keys(res)
+        allk = all_gather_rows(keys, self.group)
+        return self.b.pick_winner(allk, to_host=False), ss
 
     def query_batch(self, q, qstart, qlen, to_host=True):
         """-> structured array (song, offset, shift, score) per query, identical on all ranks.

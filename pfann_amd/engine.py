@@ -228,6 +228,11 @@ class Engine:
         """-> True if the LayerNorm-fused GEMM path is now active."""
         return bool(self.lib.pfann_set_fused_layernorm(self.handle, 1 if on else 0))
 
+    def set_plan_batch(self, n=0):
+        """Kernel variants chosen as for a batch of n segments whatever the call's own size (0: per call, the default): a
+        segment's fingerprint then has the same bits in every batch (include/pfann_amd.h: pfann_set_plan_batch)."""
+        return int(self.lib.pfann_set_plan_batch(self.handle, int(n)))
+
     def set_encoder_precision(self, mode=0):
         """0 = fp32 MFMA (default, exact); 1 = 3-term fp16 split on the fp16 MFMA.  -> mode in effect."""
         return int(self.lib.pfann_set_encoder_precision(self.handle, int(mode)))

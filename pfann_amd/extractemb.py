@@ -10,7 +10,8 @@ import sys
 import numpy as np
 import torch
 
-from .builder import embed_file_batches
+from .builder import embed_file_batches, gather_round
+from .dist import finish_ranks, init_ranks, self_launch_if_asked
 from .engine import Engine
 from .musicdata import MusicDataset
 from .utils import StageTimer, read_config
@@ -21,31 +22,47 @@ def main(argv=None):
     if len(argv) < 4:
         print("Usage: python %s <query list> <database dir> <output embedding dir>" % argv[0])
         return 1
+    rc = self_launch_if_asked(argv)         # PFANN_GPUS=N: N ranks of this command, one per GPU
+    if rc is not None:
+        return rc
+    ranks = init_ranks()
+    multi = ranks is not None and ranks.world > 1
+    rank0 = ranks is None or ranks.rank == 0
+    say = print if rank0 else (lambda *a, **k: None)
     file_list_for_query, dir_for_db, out_embed_dir = argv[1], argv[2], argv[3]
     configs = os.path.join(dir_for_db, "configs.json")
     params = read_config(configs)
-    print("loading model...")
+    say("loading model...")
     max_batch = int(os.environ.get("PFANN_MAX_BATCH", "9728"))
-    engine = Engine(params, 0, max_batch=max_batch)
+    engine = Engine(params, ranks.device if ranks is not None else 0, max_batch=max_batch)
+    engine.set_plan_batch(max_batch)         # the same bits as matcher.py / builder.py give the same file, however it is grouped
     engine.load_state_dict(torch.load(os.path.join(dir_for_db, "model.pt"), map_location="cpu"))
-    print("model loaded")
+    say("model loaded")
     dataset = MusicDataset(file_list_for_query, params)
-    os.makedirs(out_embed_dir, exist_ok=True)
+    if rank0:
+        os.makedirs(out_embed_dir, exist_ok=True)
     timer = StageTimer()
     idx_pos = 0
     index = np.zeros((len(dataset), 2), dtype=np.int64)
-    with open(os.path.join(out_embed_dir, "query_embeddings"), "wb") as fe:
-        for group in embed_file_batches(engine, dataset, dataset.hop, batch_windows=max_batch, timer=timer):
-            rows = [emb for _, n_seg, emb in group if n_seg]
-            if rows:
-                fe.write(torch.cat(rows).cpu().numpy().tobytes())       # one device-to-host copy per launch group
-            for i, n_seg, _ in group:
-                index[i] = (idx_pos, n_seg)
-                idx_pos += n_seg
-    index.tofile(os.path.join(out_embed_dir, "query_index"))
-    print("total", idx_pos, "embeddings")
-    shutil.copyfile(file_list_for_query, os.path.join(out_embed_dir, "queryList.txt"))
-    shutil.copyfile(configs, os.path.join(out_embed_dir, "configs.json"))
+    fe = open(os.path.join(out_embed_dir, "query_embeddings"), "wb") if rank0 else None
+    # several ranks: a round = one launch group per rank, embedded where it was read; the rows are all-gathered (512
+    # bytes per segment) and rank 0 writes them in list order
+    for group in embed_file_batches(engine, dataset, dataset.hop, batch_windows=max_batch, timer=timer, ranks=ranks):
+        if multi:
+            group = gather_round(ranks, group, engine.d, engine.device)
+        rows = [emb for _, n_seg, emb in group if n_seg]
+        if rows and rank0:
+            fe.write(torch.cat(rows).cpu().numpy().tobytes())       # one device-to-host copy per launch group
+        for i, n_seg, _ in group:
+            index[i] = (idx_pos, n_seg)
+            idx_pos += n_seg
+    if rank0:
+        fe.close()
+        index.tofile(os.path.join(out_embed_dir, "query_index"))
+        print("total", idx_pos, "embeddings")
+        shutil.copyfile(file_list_for_query, os.path.join(out_embed_dir, "queryList.txt"))
+        shutil.copyfile(configs, os.path.join(out_embed_dir, "configs.json"))
+    finish_ranks(ranks)
     return 0
 
 

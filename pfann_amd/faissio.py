@@ -6,6 +6,7 @@ metric_type:int32}, then a size_t-prefixed float vector).  PARITY UNPINNED: not 
 against a real faiss build (none is installable); the builder also always writes the raw
 `embeddings` file, which the reference itself falls back to (database.py:96-97).
 """
+import os
 import struct
 
 import numpy as np
@@ -53,8 +54,37 @@ class FlatIndexWriter:
         self.f.close()
 
 
-def read_index_flat(path):
-    """-> (xb float32[n,d], metric); raises ValueError for any other index type."""
+HEADER_BYTES = len(_header(1, 0, METRIC_INNER_PRODUCT))
+
+
+def write_header(f, d, n, metric=METRIC_INNER_PRODUCT):
+    """(re)writes the header of a flat index whose rows are written positionally (the N-rank builder: every rank
+    pwrite()s its rows at HEADER_BYTES + row * d * 4)"""
+    os.pwrite(f.fileno() if hasattr(f, "fileno") else f, _header(d, n, metric), 0)
+
+
+def read_index_flat(path, rows=None):
+    """-> (xb float32[n,d], metric); raises ValueError for any other index type.  rows=(lo, hi): only that row range is
+    read (a rank of a song-sharded job reads its shard and nothing else); the row count of the whole index is then
+    returned as a third value."""
+    if rows is not None:
+        with open(path, "rb") as f:
+            fourcc = f.read(4)
+            if fourcc not in (b"IxFI", b"IxF2", b"IxFl"):
+                raise ValueError("landmarkValue is not a flat index (fourcc %r): only exact Flat "
+                                 "indexes are in scope" % fourcc)
+            d, n, _, _, _, metric = struct.unpack("<iqqqBi", f.read(4 + 8 * 3 + 1 + 4))
+            if metric > 1:
+                f.read(4)
+            (cnt,) = struct.unpack("<Q", f.read(8))
+            if cnt != n * d:
+                raise ValueError("corrupt flat index: %d floats for %d x %d" % (cnt, n, d))
+            lo, hi = max(0, int(rows[0])), min(int(rows[1]), n)
+            f.seek(lo * d * 4, 1)
+            xb = np.fromfile(f, dtype="<f4", count=max(hi - lo, 0) * d)
+        if xb.size != max(hi - lo, 0) * d:
+            raise ValueError("truncated flat index")
+        return xb.reshape(-1, d).astype(np.float32, copy=False), metric, n
     with open(path, "rb") as f:
         fourcc = f.read(4)
         if fourcc not in (b"IxFI", b"IxF2", b"IxFl"):

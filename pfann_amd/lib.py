@@ -58,6 +58,7 @@ SYMBOLS = {
     "pfann_debug_keep": (None, [c_void_p, c_int]),
     "pfann_set_fused_layernorm": (c_int, [c_void_p, c_int]),
     "pfann_set_encoder_precision": (c_int, [c_void_p, c_int]),
+    "pfann_set_plan_batch": (c_int64, [c_void_p, c_int64]),
     "pfann_set_streams": (c_int, [c_void_p, c_int]),
     "pfann_db_create": (c_void_p, [c_int, c_int]),
     "pfann_db_destroy": (None, [c_void_p]),
@@ -74,6 +75,8 @@ SYMBOLS = {
                                  c_void_p]),
     "pfann_match": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int,
                             c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "pfann_db_owned_songs": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
+    "pfann_song_scores_to_seconds": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_double, c_void_p]),
     "pfann_match_pack": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "pfann_match_pick": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     "pfann_prof_enable": (None, [c_int]),

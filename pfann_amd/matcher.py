@@ -16,28 +16,53 @@ import time
 import numpy as np
 import torch
 
-from .builder import embed_file_batches
+from .builder import embed_file_batches, gather_round
 from .database import Database
+from .dist import finish_ranks, init_ranks, self_launch_if_asked
 from .engine import Engine
 from .musicdata import MusicDataset
 from .utils import StageTimer, get_logger, init_logger, read_config
 
 
 class ResultWriter:
-    """The three matcher outputs (matcher.py:40-42,84,94-107,158-163; same in matchemb.py:27-29,55-78)."""
+    """The three matcher outputs (matcher.py:40-42,84,94-107,158-163; same in matchemb.py:27-29,55-78).
 
-    def __init__(self, result_file, n_songs):
-        self.fout = open(result_file, "w", encoding="utf8", newline="\n")
-        self.fout2 = open(os.path.splitext(result_file)[0] + "_detail.csv", "w", encoding="utf8", newline="\n")
-        self.fout_score = open(result_file + ".bin", "wb")
-        self.detail = csv.writer(self.fout2)
-        self.detail.writerow(["query", "answer", "score", "time", "part_scores"])
+    ranks (a song-sharded job, pfann_amd.dist.Ranks): rank 0 writes the two text files; the `.bin` matrix
+    [n_queries, n_songs, 2] is created at its final size by rank 0 and every rank writes ITS songs' columns of each
+    query's block in place (pwrite) -- the shards' score blocks never travel to another rank, and the file ends up
+    byte-identical to the one a single process appends (error rows stay the zeros the file was created with)."""
+
+    def __init__(self, result_file, n_songs, ranks=None, n_queries=0, song_range=None):
         self.n_songs = n_songs
+        self.sharded = ranks is not None and ranks.sharded
+        self.text = ranks is None or ranks.rank == 0
         self._run = None            # [address, bytes, arrays kept alive] of the pending run of score blocks
+        if self.text:
+            self.fout = open(result_file, "w", encoding="utf8", newline="\n")
+            self.fout2 = open(os.path.splitext(result_file)[0] + "_detail.csv", "w", encoding="utf8", newline="\n")
+            self.detail = csv.writer(self.fout2)
+            self.detail.writerow(["query", "answer", "score", "time", "part_scores"])
+        if not self.sharded:
+            self.fout_score = open(result_file + ".bin", "wb")
+        else:
+            if ranks.rank == 0:
+                with open(result_file + ".bin", "wb") as f:
+                    f.truncate(int(n_queries) * n_songs * 8)
+            ranks.barrier()
+            self.fd = os.open(result_file + ".bin", os.O_WRONLY)
+            self.lo, self.hi = song_range
 
-    def write(self, name, ans, sco, tim, song_score):
-        self.fout.write("%s\t%s\n" % (name, ans))
-        self.detail.writerow([name, ans, sco, tim])
+    def write(self, name, ans, sco, tim, song_score, qi=None):
+        if self.text:
+            self.fout.write("%s\t%s\n" % (name, ans))
+            self.detail.writerow([name, ans, sco, tim])
+        if self.sharded:
+            if self.hi > self.lo:                   # this shard's columns of query qi's block
+                blk = memoryview(np.ascontiguousarray(song_score, dtype=np.float32)).cast("B")
+                off, done = (int(qi) * self.n_songs + self.lo) * 8, 0
+                while done < len(blk):
+                    done += os.pwrite(self.fd, blk[done:], off + done)
+            return
         # score blocks of one launch group are consecutive rows of one buffer: they go out as ONE write at flush()
         # (a write per query is a system call and a GIL hand-over per query)
         blk = np.ascontiguousarray(song_score, dtype=np.float32)
@@ -56,19 +81,29 @@ class ResultWriter:
                 self.fout_score.write((ctypes.c_char * nb).from_address(ptr))
             self._run = None
 
-    def write_error(self, name):
+    def write_error(self, name, qi=None):
+        if self.sharded:                            # the block is already zero
+            if self.text:
+                self.fout.write("%s\t%s\n" % (name, "error"))
+                self.detail.writerow([name, "error", -1e999, 0])
+            return
         self.write(name, "error", -1e999, 0, np.zeros([self.n_songs, 2], dtype=np.float32))
 
     def flush(self):
         self._flush_run()
-        self.fout.flush()
-        self.fout2.flush()
+        if self.text:
+            self.fout.flush()
+            self.fout2.flush()
 
     def close(self):
         self._flush_run()
-        self.fout.close()
-        self.fout2.close()
-        self.fout_score.close()
+        if self.text:
+            self.fout.close()
+            self.fout2.close()
+        if self.sharded:
+            os.close(self.fd)
+        else:
+            self.fout_score.close()
 
 
 def main(argv=None):
@@ -76,60 +111,86 @@ def main(argv=None):
     if len(argv) < 4:
         print("Usage: python %s <query list> <database dir> <result file>" % argv[0])
         return 1
+    rc = self_launch_if_asked(argv)         # PFANN_GPUS=N: N ranks of this command, one per GPU
+    if rc is not None:
+        return rc
+    ranks = init_ranks()                    # None: a plain single-process run
+    multi = ranks is not None and ranks.world > 1
+    rank0 = ranks is None or ranks.rank == 0
+    dev = ranks.device if ranks is not None else 0
+    say = print if rank0 else (lambda *a, **k: None)
     file_list_for_query, dir_for_db, result_file = argv[1], argv[2], argv[3]
     params = read_config(os.path.join(dir_for_db, "configs.json"))
-    init_logger("matcher")                                                 # matcher.py:31-32
+    if rank0:
+        init_logger("matcher")                                             # matcher.py:31-32
 
-    print("loading model...")
+    say("loading model...")
     max_batch = int(os.environ.get("PFANN_MAX_BATCH", "9728"))
-    engine = Engine(params, 0, max_batch=max_batch)
+    engine = Engine(params, dev, max_batch=max_batch)
+    # kernel variants of a full launch group for every call: a query's fingerprints -- and with them every byte of the
+    # three output files -- do not depend on how the list is cut into groups or spread over ranks
+    engine.set_plan_batch(max_batch)
     engine.load_state_dict(torch.load(os.path.join(dir_for_db, "model.pt"), map_location="cpu"))
     engine.warmup(windows=max_batch)
-    print("model loaded")
-    print("loading database...")
-    db = Database(dir_for_db, params["indexer"], params["hop_size"], device=0, d=params["model"]["d"])
-    db.warmup(rows=max_batch)
-    print("database loaded")
+    say("model loaded")
+    say("loading database...")
+    db = Database(dir_for_db, params["indexer"], params["hop_size"], device=dev, d=params["model"]["d"], ranks=ranks)
+    db.warmup(rows=max_batch * (ranks.world if multi else 1))
+    say("database loaded")
 
     dataset = MusicDataset(file_list_for_query, params)
     timer = StageTimer()
     db.timer = timer
     tm_0 = time.time()
-    out = ResultWriter(result_file, len(db.songList))
+    out = ResultWriter(result_file, len(db.songList), ranks=ranks, n_queries=len(dataset), song_range=db.song_range)
 
     def launch(items):
         """items: one launch group of (index, n_seg, emb) in list order -> search + match in flight."""
         good = [(i, n, e) for i, n, e in items if n]
-        p = None
+        ps = []
         if good:
             emb = torch.cat([e for _, _, e in good])
             qlen = [n for _, n, _ in good]
             qstart = np.concatenate([[0], np.cumsum(qlen)[:-1]])
-            p = db.query_launch(emb, qstart, qlen, want_song_scores=True)
-        return items, good, p
+            ps = db.query_launch_chunks(emb, qstart, qlen, want_song_scores=True)
+        return items, good, ps
 
     def finish(launched):
-        items, good, p = launched
-        results = {}
-        if p is not None:
-            for (i, _, _), r in zip(good, db.query_finish(p, reuse_buffers=True)):
+        items, good, ps = launched
+        it = iter(items)
+        for j0, j1, p in ps:
+            results = {}
+            for (i, _, _), r in zip(good[j0:j1], db.query_finish(p, reuse_buffers=True)):
                 results[i] = r
+            last = good[j1 - 1][0]
+            with timer.stage("output answer"):
+                for i, n, _ in it:                                        # list order, error rows in their places
+                    write_one(i, n, results)
+                    if i == last:
+                        break
+                out.flush()
         with timer.stage("output answer"):
-            for i, n, _ in items:
-                name = dataset.files[i]
-                if n == 0:                                            # matcher.py:94-107
-                    out.write_error(name)
-                else:
-                    sco, (sid, tim), song_score = results[i]
-                    out.write(name, db.songList[sid], sco, tim, song_score)   # sid == -1 -> last song (matcher.py:138)
+            for i, n, _ in it:                                            # what follows the last query with segments
+                write_one(i, n, {})
             out.flush()
+
+    def write_one(i, n, results):
+        name = dataset.files[i]
+        if n == 0:                                                        # matcher.py:94-107
+            out.write_error(name, qi=i)
+        else:
+            sco, (sid, tim), song_score = results[i]
+            out.write(name, db.songList[sid], sco, tim, song_score, qi=i)   # sid == -1 -> last song (matcher.py:138)
 
     # matcher.py:120-126 asks the model for norm=False and L2-normalises on the CPU; the same formula runs inside the
     # projection kernel here.  One launch group = PFANN_MAX_BATCH windows (512 ten-second queries): enough 128x128
     # tiles to fill the chip in every encoder layer.  Group g+1 is decoded, uploaded and launched before group g's
-    # results are read back and written.
+    # results are read back and written.  Several ranks: a round = one group per rank, embedded where it was read,
+    # all-gathered, then searched by every rank in its own shard of the database.
     in_flight = None
-    for items in embed_file_batches(engine, dataset, dataset.hop, batch_windows=max_batch, timer=timer):
+    for items in embed_file_batches(engine, dataset, dataset.hop, batch_windows=max_batch, timer=timer, ranks=ranks):
+        if multi:
+            items = gather_round(ranks, items, engine.d, engine.device)
         nxt = launch(items)
         if in_flight is not None:
             finish(in_flight)
@@ -138,10 +199,14 @@ def main(argv=None):
         finish(in_flight)
     timer.resolve(wait=True)
     out.close()
+    if ranks is not None:
+        ranks.barrier()                                  # every rank's columns of the score matrix are on disk
     for name, secs in timer.t.items():                   # one stage per line, the format tools/stat.py:17 parses
-        print("%s %.6fs" % (name, secs))
-    get_logger().info("total query time %.6fs", time.time() - tm_0)
-    print("total query time %.6fs" % (time.time() - tm_0))
+        say("%s %.6fs" % (name, secs))
+    if rank0:
+        get_logger().info("total query time %.6fs", time.time() - tm_0)
+    say("total query time %.6fs" % (time.time() - tm_0))
+    finish_ranks(ranks)
     return 0
 
 
