@@ -16,9 +16,11 @@ HBM is reported beside it as `hbm_resident` (about 1 % faster).
     python bench.py --gpus N --steps K --warmup W           (N > 1: starts its own N ranks, one per GPU, RCCL)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...     (the driver's form)
 
-N > 1: the db is sharded by songs over the ranks (strong scaling: same db, same query batch);
-each rank embeds 1/N of the query windows, embeddings and per-shard top-k are all-gathered
-over RCCL, each rank sequence-scores the candidates it owns.
+The job is the same at every N (strong scaling, the default): one 1M-segment db, 4096 ten-second queries per step.
+N > 1: the db is sharded by songs over the ranks; each rank embeds 1/N of the step's query windows, the fingerprints
+and the per-shard top-k lists are exchanged over RCCL, each rank sequence-scores the candidates it owns.  Per N the
+line also carries `scan_throughput` (db rows x query rows per second of scan-kernel time, max over ranks) and the
+event time of every collective of the exchange protocol.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -160,11 +162,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--queries", type=int, default=512,
-                    help="10 s queries per step and GPU (--scaling weak, the default) or per step for the whole job (strong)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="N > 1: weak = every rank brings its own --queries queries per step (the db stays the one "
-                         "1M-segment db, song-sharded), strong = --queries split over the ranks")
+    ap.add_argument("--queries", type=int, default=None,
+                    help="10 s queries per step: for the WHOLE job (--scaling strong, the default: 4096 = 512 per GPU at 8 "
+                         "GPUs, the same job at every N) or per GPU (--scaling weak: 512)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="strong (default): the SAME job at every N -- one 1M-segment db, --queries queries per step split "
+                         "over the ranks; weak: every rank brings its own --queries queries per step")
     ap.add_argument("--db-songs", type=int, default=16950, help="16950 x 59 = 1,000,050 segments")
     ap.add_argument("--filler-db", action="store_true",
                     help="round-1 style database (48 real songs + seeded unit-norm filler rows): scan-only studies")
@@ -190,6 +193,8 @@ def main():
                          "world 1: every collective then really goes through the backend (RCCL on one GPU)")
     ap.add_argument("--dump-decisions", default=None, help="write (song, offset, score) per query as .npy (rank 0)")
     args = ap.parse_args()
+    if args.queries is None:
+        args.queries = 4096 if args.scaling == "strong" else 512
 
     # ------------------------------------------------------------------ ranks: launch, verify, never fall through
     # `python bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment) starts its own N ranks, one per GPU, through
@@ -389,7 +394,7 @@ def main():
             emb = emb.repeat(emu, 1)[: Q * QUERY_SEGS].contiguous()
             return sharded.query_batch(emb, w["qstart"], w["qlen"]), emb
         if use_sharded:
-            emb = all_gather_ragged(emb, w["q_counts"])
+            emb = sharded._timed("emb_allgather", all_gather_ragged, emb, w["q_counts"])
             return sharded.query_batch(emb, w["qstart"], w["qlen"]), emb
         D, I = cur_index[0].search(emb, k)
         res, _ = cur_index[0].match(emb, I, w["qstart"], w["qlen"])
@@ -424,7 +429,7 @@ def main():
             self.used[i & 1].record()
             e = eng.embed_windows(wav, w["starts"])
             if use_sharded:
-                e = all_gather_ragged(e, w["q_counts"])
+                e = sharded._timed("emb_allgather", all_gather_ragged, e, w["q_counts"])
                 return sharded.query_batch(e, w["qstart"], w["qlen"], to_host=False), e
             D, I = cur_index[0].search(e, k)
             r, _ = cur_index[0].match(e, I, w["qstart"], w["qlen"], to_host=False)
@@ -465,6 +470,8 @@ def main():
         lib.pfann_prof_reset()
         lib.pfann_prof_enable(1)
     fence()
+    if use_sharded and prof:
+        sharded.timing = {}
     lib.pfann_prof_marker(None)
     t0 = time.perf_counter()
     if two_deep is not None:
@@ -480,6 +487,15 @@ def main():
     elapsed = max_over_ranks(elapsed)
     n_seg = Q * QUERY_SEGS
     value = n_seg * args.steps / elapsed
+    collectives = None
+    if use_sharded and prof:
+        # event time of every collective of the exchange protocol (pfann_amd/dist.py: ShardedIndex._timed), per step,
+        # the slowest rank's: bound all-gather, all-to-all of the shard lists, merge kernel, merged-slice all-gather,
+        # winner-key all-gather, and the ragged all-gather of the step's fingerprints
+        mine = sharded.timing_ms()
+        sharded.timing = None
+        collectives = {nm: round(max_over_ranks(ms / args.steps), 4) for nm, ms in sorted(mine.items())}
+        collectives["unit"] = "ms per step, max over ranks"
 
     # ---- the same K batches one at a time (H2D, kernels, D2H, host wait; then the next): what `value` was through round 3's
     # first half, kept for comparison
@@ -512,7 +528,23 @@ def main():
     # ---- N > 1, default (weak) mode: the same job in the OTHER scaling mode as a side figure, so SCALE runs stay
     # comparable with round 1's strong-scaling numbers: --queries queries for the WHOLE job, split over the ranks
     other_mode = None
-    if world > 1 and args.scaling == "weak" and emu <= 1:
+    if world > 1 and args.scaling == "strong" and emu <= 1 and Q // 8 >= 1:
+        # the weak-scaling side figure: every rank brings Q/8 queries of its own (512 at the default 4096): equals the
+        # headline job at N = 8 and is 1/8 ... 1/2 of it below
+        per = min(Q // 8, my_q[1] - my_q[0])
+        sw = make_workload([per] * world)
+        step(True, sw)
+        fence()
+        tp = time.perf_counter()
+        for _ in range(args.steps):
+            step(True, sw)
+        fence()
+        el = max_over_ranks(time.perf_counter() - tp)
+        other_mode = {"scaling": "weak", "value": round(sw["Q"] * QUERY_SEGS * args.steps / el, 1), "unit": "segments/s",
+                      "ms_per_step": round(1e3 * el / args.steps, 3), "queries_per_step": sw["Q"],
+                      "what": "weak scaling: %d queries per step and rank (%d per step for the job) against the same 1 M-segment "
+                              "db" % (per, sw["Q"])}
+    elif world > 1 and args.scaling == "weak" and emu <= 1:
         sw = make_workload([hi - lo for lo, hi in split_even(args.queries, world)])
         step(True, sw)
         fence()
@@ -631,6 +663,25 @@ def main():
             work = lib.pfann_prof_work(tag.encode())
             kernels[tag] = {"ms_per_step": ms / args.steps, "launches_per_step": cnt.value / args.steps,
                             "avg_us": 1e3 * ms / max(cnt.value, 1), "work_per_launch": work / max(cnt.value, 1)}
+    # ---- scan throughput (north_star: ">= 6x scan throughput at 8 GPUs"): db rows x query rows per second of SCAN time, the
+    # scan being every kernel of the exact top-k search (sampled pass, full pass, selects, fallback, and the sharded
+    # path's bound / merge kernels); per rank from the kernel tags of the timed loop, the slowest rank's time counts
+    scan_throughput = None
+    if prof:
+        SCAN_TAGS = [t for t in kernels if t.startswith("scan_topk") or t.startswith("topk_")]
+        scan_ms = sum(kernels[t]["ms_per_step"] for t in SCAN_TAGS)
+        if in_group:
+            allms = [None] * world
+            dist.all_gather_object(allms, scan_ms)
+        else:
+            allms = [scan_ms]
+        slowest = max(allms)
+        if slowest > 0:
+            scan_throughput = {"value": float("%.4g" % (float(n_rows) * Q * QUERY_SEGS / (slowest * 1e-3))),
+                               "unit": "db rows x query rows / s of scan-kernel time (slowest rank)",
+                               "db_rows": n_rows, "query_rows_per_step": Q * QUERY_SEGS,
+                               "scan_ms_per_step_per_rank": [round(v, 4) for v in allms], "tags": sorted(SCAN_TAGS),
+                               "TFLOPs_equivalent": float("%.4g" % (2.0 * d * n_rows * Q * QUERY_SEGS / (slowest * 1e-3) / 1e12))}
     # roofline of the dominant kernel (most time in the timed region)
     ROOF = {"conv_gemm_ln_128": ("pfann::conv_gemm_ln_w22_kernel / conv_gemm_ln_kernel<128,128,64,32,...> (the 15 implicit-GEMM "
                                  "convs, 128x128 tiles, LayerNorm+ReLU of the input fused into the A-loader, LN statistics of the "
@@ -800,11 +851,12 @@ def main():
 
     # ------------------------------------------- the drop-in CLIs from WAV files on disk (rank 0, N = 1)
     cli = None
-    if rank == 0 and world == 1 and not use_sharded and emu <= 1 and not args.no_cli:
+    if rank == 0 and not args.force_sharded and emu <= 1 and not args.no_cli:
+        # N > 1: the tools start their own N ranks (PFANN_GPUS = --gpus) while this job's other ranks wait at the barrier
         sys.path.insert(0, os.path.join(REPO, "tools"))
         import cli_bench
         try:
-            cli = cli_bench.run(args.cli_songs, args.cli_queries, args.snr, device=local_rank, log=log)
+            cli = cli_bench.run(args.cli_songs, args.cli_queries, args.snr, device=local_rank, log=log, gpus=world)
             if "builder" in cli:
                 cli["cli_builder_segments_per_s"] = cli["builder"]["segments_per_s"]
                 cli["cli_matcher_segments_per_s"] = cli["matcher"]["segments_per_s"]
@@ -812,6 +864,8 @@ def main():
         except Exception as x:                                          # never lose the headline line to the side leg
             cli = {"error": repr(x)[:500]}
 
+    if in_group and not args.no_cli:
+        dist.barrier()                       # (the CLI leg ran on rank 0)
     if rank == 0 and args.dump_decisions:
         np.save(args.dump_decisions, np.stack([res["song"].astype(np.float64), res["offset"].astype(np.float64),
                                                res["score"].astype(np.float64)], 1))
@@ -852,7 +906,7 @@ def main():
                              "inside the timed region"),
             "serial": serial,
             "hbm_resident": pcie, "seq_score_seam": seam_info, "cli": cli,
-            "alt_modes": alt, "other_scaling_mode": other_mode,
+            "alt_modes": alt, "other_scaling_mode": other_mode, "scan_throughput": scan_throughput, "collectives": collectives,
             "kernels": {t: {kk: (float("%.4g" % vv) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                         for t, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
         }

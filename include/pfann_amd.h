@@ -283,10 +283,11 @@ int pfann_match(pfann_db *db, const float *q_dev, const int64_t *labels_dev, int
 int pfann_db_owned_songs(pfann_db *db, int *song_lo, int *song_hi);
 
 /* In place, for n_pairs (score, alignment) pairs of a song_scores block written by pfann_match: the alignment slot
- * goes from fine frames (t * frame_shift_mul - shift) to seconds, (t - shift / frame_shift_mul) * hop_size computed in
- * double and stored as float32 -- what database.py:148,160 leaves in song_score[:, 1].  Asynchronous on `stream`. */
+ * goes from fine frames (t * frame_shift_mul - shift) to seconds.  native_path 0: (t - shift / frame_shift_mul) * hop_size
+ * computed in double and stored as float32 -- what database.py:148,160 leaves in song_score[:, 1]; native_path 1: the
+ * float32 multiply of database.py:193, song_score[:, 1] *= hop_size / frame_shift_mul.  Asynchronous on `stream`. */
 int pfann_song_scores_to_seconds(pfann_db *db, float *song_scores_dev, int64_t n_pairs, int frame_shift_mul,
-                                 double hop_size, void *stream);
+                                 double hop_size, int native_path, void *stream);
 
 /* Song-sharded multi-GPU retrieval, winner selection without the host (no reference counterpart):
  * pfann_match_pack turns this rank's results_dev[nQ] (from pfann_match with only_owned=1, python path) into one

@@ -820,9 +820,9 @@ int pfann_match(pfann_db *db, const float *q, const int64_t *labels, int k, cons
 }
 
 int pfann_song_scores_to_seconds(pfann_db *db, float *song_scores_dev, int64_t n_pairs, int frame_shift_mul, double hop_size,
-                                 void *stream) {
+                                 int native_path, void *stream) {
     PF_HIP(hipSetDevice(db->device));
-    return launch_song_scores_to_seconds(song_scores_dev, n_pairs, frame_shift_mul, hop_size, (hipStream_t)stream);
+    return launch_song_scores_to_seconds(song_scores_dev, n_pairs, frame_shift_mul, hop_size, native_path, (hipStream_t)stream);
 }
 
 int pfann_db_owned_songs(pfann_db *db, int *song_lo, int *song_hi) {

@@ -115,7 +115,7 @@ struct RerankArgs {
 int launch_match(const RerankArgs &a, hipStream_t s);
 int launch_match_pack(const pfann_match_result *res, int64_t nQ, unsigned long long *keys, hipStream_t s);
 int launch_match_pick(const unsigned long long *keys, int G, int64_t nQ, pfann_match_result *out, hipStream_t s);
-int launch_song_scores_to_seconds(float *ss, int64_t n_pairs, int fsm, double hop_size, hipStream_t s);
+int launch_song_scores_to_seconds(float *ss, int64_t n_pairs, int fsm, double hop_size, int native_path, hipStream_t s);
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): the attribute is per device
 int ensure_dyn_lds(const void *func, int bytes);
 

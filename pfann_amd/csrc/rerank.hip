@@ -461,20 +461,24 @@ __global__ void match_pick_kernel(const unsigned long long *__restrict__ keys, i
 }
 // per-song slot 1: alignment in fine frames (t * fsm - shift) -> seconds, (t - shift / fsm) * hop_size, computed in double
 // like the reference's Python floats (database.py:148,193) and stored as float32; slots never written hold 0 -> 0 s
-__global__ void song_scores_to_seconds_kernel(float *__restrict__ ss, int64_t n_pairs, int fsm, double hop_size) {
+__global__ void song_scores_to_seconds_kernel(float *__restrict__ ss, int64_t n_pairs, int fsm, double hop_size, int native_path) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pairs) return;
+    if (native_path) {      // database.py:193: song_score[:, 1] *= hop_size / frame_shift_mul, a float32 multiply
+        ss[2 * i + 1] = ss[2 * i + 1] * (float)(hop_size / (double)fsm);
+        return;
+    }
     const long long fine = (long long)ss[2 * i + 1];
     long long shift = (-fine) % fsm;
     if (shift < 0) shift += fsm;
     const long long t = (fine + shift) / fsm;
     ss[2 * i + 1] = (float)(((double)t - (double)shift / (double)fsm) * hop_size);
 }
-int launch_song_scores_to_seconds(float *ss, int64_t n_pairs, int fsm, double hop_size, hipStream_t s) {
+int launch_song_scores_to_seconds(float *ss, int64_t n_pairs, int fsm, double hop_size, int native_path, hipStream_t s) {
     if (n_pairs <= 0) return 0;
     if (fsm < 1) { set_error("song_scores_to_seconds: frame_shift_mul=%d", fsm); return -1; }
     ProfScope ps("song_scores_to_seconds", s);
-    PF_LAUNCH(song_scores_to_seconds_kernel, dim3((unsigned)cdiv(n_pairs, 256)), dim3(256), 0, s, ss, n_pairs, fsm, hop_size);
+    PF_LAUNCH(song_scores_to_seconds_kernel, dim3((unsigned)cdiv(n_pairs, 256)), dim3(256), 0, s, ss, n_pairs, fsm, hop_size, native_path);
     PF_HIP(hipGetLastError());
     return 0;
 }

@@ -167,11 +167,12 @@ class DeviceIndex:
         self.lib.pfann_db_owned_songs(self.handle, ctypes.byref(lo), ctypes.byref(hi))
         return lo.value, hi.value
 
-    def song_scores_to_seconds(self, ss, fsm, hop_size):
+    def song_scores_to_seconds(self, ss, fsm, hop_size, native_path=False):
         """in place: the alignment slot of every (score, alignment) pair of a song_scores block, fine frames -> seconds"""
         if ss is not None and ss.numel():
             _l.check(self.lib.pfann_song_scores_to_seconds(self.handle, ss.data_ptr(), ss.numel() // 2, int(fsm), float(hop_size),
-                                                           self._stream()), "pfann_song_scores_to_seconds")
+                                                           1 if native_path else 0, self._stream()),
+                     "pfann_song_scores_to_seconds")
         return ss
 
     def match(self, q, labels, qstart, qlen, fsm=1, alpha=0.0, mode=0, only_owned=False, want_song_scores=False,
@@ -236,6 +237,12 @@ def _fine_to_time(fine, fsm, hop_size):
     shift = (-fine) % fsm
     t = (fine + shift) // fsm
     return (t - shift / fsm) * hop_size
+
+
+# The reference's module-level switch (database.py:12): False = the Python-path semantics of query_embeddings_base (the
+# default), True = those of query_embeddings_cpp / cpp/seqscore.cpp (fp32 divide, score_alpha honoured, score and time read
+# back from the per-song block).  PFANN_CPP_ACCELERATE=1 sets it for the CLIs.  Either way the work runs in the HIP kernels.
+cpp_accelerate = os.environ.get("PFANN_CPP_ACCELERATE", "0") not in ("0", "")
 
 
 class Database:
@@ -314,10 +321,12 @@ class Database:
             self.query_finish(self.query_launch(big, np.arange(nq) * 19, [19] * nq, want_song_scores=True), reuse_buffers=True)
 
     # ---- batched form ------------------------------------------------------------------
-    def query_launch(self, emb, qstart, qlen, want_song_scores=False, mode=0):
+    def query_launch(self, emb, qstart, qlen, want_song_scores=False, mode=None):
         """First half of query_batch: search + sequence match launched asynchronously, nothing read back.  The CLIs launch
         group g+1 before they finish group g, so the GPU never idles while the host formats and writes results."""
         dev = self.index.device
+        if mode is None:
+            mode = 1 if cpp_accelerate else 0
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         ev[0].record()
         if self.sharded is not None:
@@ -334,10 +343,10 @@ class Database:
         ev[2].record()
         # frames -> seconds where the block lives (database.py:148,193 do it on the host): (t - shift/fsm) * hop_size
         # with fine = t*fsm - shift, in double like the reference's Python floats, stored as float32
-        self.index.song_scores_to_seconds(ss, self.frame_shift_mul, self.hop_size)
-        return {"res": res, "ss": ss, "ev": ev, "nq": len(qlen), "keep": (emb, I), "dev": dev}
+        self.index.song_scores_to_seconds(ss, self.frame_shift_mul, self.hop_size, native_path=mode == 1)
+        return {"res": res, "ss": ss, "ev": ev, "nq": len(qlen), "keep": (emb, I), "dev": dev, "mode": mode}
 
-    def query_launch_chunks(self, emb, qstart, qlen, want_song_scores=False, mode=0):
+    def query_launch_chunks(self, emb, qstart, qlen, want_song_scores=False, mode=None):
         """query_launch over as many sub-launches as the score-block budget asks for (PFANN_SCORE_BLOCK_MB, default
         1024: one-segment queries against a 100 k-song database would otherwise want 7.8 GB of HBM and as much pinned
         host memory per launch group).  -> [(first query, one past the last, launch)]"""
@@ -390,6 +399,16 @@ class Database:
         for j in range(p["nq"]):
             r = res[j]
             song_score = ss_np[j] if ss_np is not None else None
+            if p.get("mode", 0) == 1:
+                # query_embeddings_cpp (database.py:166-195) reads score and time back from the per-song block, which only
+                # ever records scores > 0 (no candidate: song_score[-1], the last song's untouched row)
+                sc32 = float(np.float32(r["score"])) if r["song"] >= 0 else 0.0
+                if r["song"] < 0 or not sc32 > 0.0:
+                    out.append((0.0, (int(r["song"]) if r["song"] >= 0 else -1, 0.0), song_score))
+                else:
+                    fine = float(np.float32(int(r["offset"]) * fsm - int(r["shift"])))
+                    out.append((sc32, (int(r["song"]), fine * self.hop_size / fsm), song_score))
+                continue
             if self.index.ntotal == 0 or r["song"] < 0:
                 out.append((-1e999, (-1, 0), song_score))
                 continue
@@ -397,7 +416,7 @@ class Database:
             out.append((float(r["score"]), (int(r["song"]), real_time), song_score))
         return out
 
-    def query_batch(self, emb, qstart, qlen, want_song_scores=False, mode=0):
+    def query_batch(self, emb, qstart, qlen, want_song_scores=False, mode=None):
         """emb: torch cuda [sum(qlen), d] unit-norm rows; -> list of (score, (song, time), song_score|None)."""
         return self.query_finish(self.query_launch(emb, qstart, qlen, want_song_scores, mode))
 

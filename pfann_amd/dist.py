@@ -185,6 +185,32 @@ class ShardedIndex:
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self.timing = None          # a dict: every collective of the protocol is then bracketed by a pair of timing events
+
+    def _timed(self, name, fn, *a):
+        """runs one collective; with self.timing set, between two events on the current stream (the collective's own
+        stream is joined into the current one by the process group, so the pair spans it)"""
+        if self.timing is None or not torch.cuda.is_available():
+            return fn(*a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn(*a)
+        e1.record()
+        self.timing.setdefault(name, []).append((e0, e1))
+        return out
+
+    def timing_ms(self):
+        """-> {collective: total milliseconds} over the event pairs collected so far (waits for them), and forgets them"""
+        out = {}
+        for name, pairs in (self.timing or {}).items():
+            tot = 0.0
+            for e0, e1 in pairs:
+                e1.synchronize()
+                tot += e0.elapsed_time(e1)
+            out[name] = tot
+        if self.timing is not None:
+            self.timing = {}
+        return out
 
     @staticmethod
     def my_rows(song_pos, rank, world):
@@ -211,7 +237,7 @@ class ShardedIndex:
         Dl, Il = [], []
         for c0 in range(0, Q, self.b.BOUND_CHUNK):
             qc = q[c0:c0 + self.b.BOUND_CHUNK]
-            lb = self.b.reduce_bound(all_gather_rows(self.b.search_bound(qc, k, m), self.group), k)
+            lb = self.b.reduce_bound(self._timed("bound_allgather", all_gather_rows, self.b.search_bound(qc, k, m), self.group), k)
             Dc, Ic = self.b.search_bounded(qc, k, lb)
             Dl.append(Dc)
             Il.append(Ic)
@@ -221,13 +247,13 @@ class ShardedIndex:
         if pad:
             D = torch.cat([D, torch.full((pad, k), -3.4028234663852886e38, dtype=D.dtype, device=D.device)])
             I = torch.cat([I, torch.full((pad, k), -1, dtype=I.dtype, device=I.device)])
-        rD = all_to_all_rows(D.view(G, Qs, k), self.group)        # [source shard, my Qs queries, k]
-        rI = all_to_all_rows(I.view(G, Qs, k), self.group)
+        rD = self._timed("all_to_all", all_to_all_rows, D.view(G, Qs, k), self.group)        # [source shard, my Qs queries, k]
+        rI = self._timed("all_to_all", all_to_all_rows, I.view(G, Qs, k), self.group)
         S = rD.permute(1, 0, 2).reshape(Qs, G * k)                # shard-major: ascending labels on ties
         L = rI.permute(1, 0, 2).reshape(Qs, G * k)
-        Dm, Im = self.b.merge_topk(S.contiguous(), L.contiguous(), k)
-        gD = all_gather_rows(Dm, self.group).reshape(G * Qs, k)[:Q]
-        gI = all_gather_rows(Im, self.group).reshape(G * Qs, k)[:Q]
+        Dm, Im = self._timed("merge", self.b.merge_topk, S.contiguous(), L.contiguous(), k)
+        gD = self._timed("slice_allgather", all_gather_rows, Dm, self.group).reshape(G * Qs, k)[:Q]
+        gI = self._timed("slice_allgather", all_gather_rows, Im, self.group).reshape(G * Qs, k)[:Q]
         return gD.contiguous(), gI.contiguous()
 
     def match_global(self, q, I, qstart, qlen, want_song_scores=False, mode=0):
@@ -237,7 +263,7 @@ class ShardedIndex:
         res, ss = self.b.match(q, I, qstart, qlen, self.fsm, self.alpha, mode, True, want_song_scores, to_host=False,
                                owned_block=True)
         keys = self.b.pack_winner_keys(res)
-        allk = all_gather_rows(keys, self.group)
+        allk = self._timed("key_allgather", all_gather_rows, keys, self.group)
         return self.b.pick_winner(allk, to_host=False), ss
 
     def query_batch(self, q, qstart, qlen, to_host=True):
@@ -248,5 +274,5 @@ class ShardedIndex:
         D, I = self.search_global(q)
         res, _ = self.b.match(q, I, qstart, qlen, self.fsm, self.alpha, 0, True, False, to_host=False)
         keys = self.b.pack_winner_keys(res)                          # int64 [nQ, 2]
-        allk = all_gather_rows(keys, self.group)                     # [G, nQ, 2]
+        allk = self._timed("key_allgather", all_gather_rows, keys, self.group)       # [G, nQ, 2]
         return self.b.pick_winner(allk, to_host=to_host)      # to_host=False: the device tensor (results_to_host later)

@@ -76,7 +76,7 @@ SYMBOLS = {
     "pfann_match": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int,
                             c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pfann_db_owned_songs": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
-    "pfann_song_scores_to_seconds": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_double, c_void_p]),
+    "pfann_song_scores_to_seconds": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_double, c_int, c_void_p]),
     "pfann_match_pack": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "pfann_match_pick": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     "pfann_prof_enable": (None, [c_int]),

@@ -96,6 +96,33 @@ def test_two_rank_sharded_path_matches_single_gpu(tmp_path, scaling):
     assert out["config"]["queries_per_step"] == 24 and out["config"]["queries_per_step_per_gpu"] == 12
 
 
+def test_two_rank_default_is_the_same_job_strong_scaling_with_scan_throughput_and_collectives(tmp_path):
+    """The line the driver's SCALE runs will read: N > 1 defaults to STRONG scaling (the same job at
+    every N), carries `scan_throughput` (db rows x query rows per second of scan-kernel time, slowest rank), the event time
+    of every collective of the exchange protocol, the weak-scaling figure as the side key, and a CLI leg run by the
+    tools' own 2 ranks.  2 ranks on this box's one GPU (gloo-staged collectives)."""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--queries", "48", "--db-songs", "600", "--no-cpu-baseline", "--max-batch", "512", "--cli-songs", "60",
+                        "--cli-queries", "12"],
+                       capture_output=True, text=True, timeout=1200, cwd=REPO,
+                       env=_clean_env(PFANN_DIST_BACKEND="gloo", PFANN_FORCE_DEVICE="0", PFANN_MAX_BATCH="512"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["queries_per_step"] == 48
+    assert out["config"]["queries_per_step_per_gpu"] == 24
+    st = out["scan_throughput"]
+    assert st["value"] > 0 and len(st["scan_ms_per_step_per_rank"]) == 2 and st["db_rows"] == 600 * 59
+    assert st["query_rows_per_step"] == 48 * 19 and any(t.startswith("scan_topk") for t in st["tags"])
+    col = out["collectives"]
+    for name in ("emb_allgather", "bound_allgather", "all_to_all", "merge", "slice_allgather", "key_allgather"):
+        assert col[name] > 0, name
+    om = out["other_scaling_mode"]
+    assert om["scaling"] == "weak" and om["queries_per_step"] == 12 and om["value"] > 0
+    cli = out["cli"]
+    assert cli["gpus"] == 2 and cli["builder"]["segments"] == 60 * 59 and cli["matcher"]["segments"] == 12 * 19, cli
+    assert cli["matcher"]["top1_hit_rate"] >= 0.5
+
+
 def _clean_env(**kw):
     e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PFANN_DIST_BACKEND", "PFANN_FORCE_DEVICE")}
     e.update(kw)

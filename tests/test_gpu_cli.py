@@ -208,3 +208,102 @@ def test_extractemb_matchemb_seam_and_accuracy(tmp_path):
             assert "song correct" in out and "near match correct" in out and "exact match correct" in out
             acc = float(out.strip().splitlines()[-1].split()[-1])
             assert acc >= 50.0          # tiny random-weight encoder at 20 dB: well above chance (12.5 %)
+
+
+@pytest.mark.parametrize("variant", ["frame_shift_mul2", "native_score_alpha", "use_float16"])
+def test_matcher_cli_variants_vs_oracle(tmp_path, variant):
+    """The matcher's variants END TO END through the CLI (they were library-level only):
+      frame_shift_mul=2 in configs.json (query windows every half hop, per-shift candidate sets, time =
+          (t - shift/fsm) * hop: database.py:129-148)                       vs oracle/seqscore.py
+      score_alpha=2.0 with the reference's native path switched on (PFANN_CPP_ACCELERATE=1 = database.py:12
+          cpp_accelerate; exp(-alpha (1-ip)^2) scores, score/time read back from the per-song block, times scaled
+          by hop/fsm in float32: database.py:166-195, seqscore.cpp:100-110), together with frame_shift_mul=2
+                                                                            vs oracle/seqscore_c.c
+      "use_float16" in the indexer block (fp16-only storage, faiss' useFloat16, database.py:101-104)
+                                                                            vs oracle flat_ip_topk_f16 + fp16-rounded rows
+    The oracle searches and matches the CLI's OWN query fingerprints (extractemb.py writes the bits matcher.py used:
+    both pin the kernel plan), so decisions and times must agree exactly and scores to rounding; the fingerprints
+    themselves are checked against the oracle encoder."""
+    import torch
+    from oracle import native
+    from oracle import search as osr
+    from oracle import seqscore as osq
+    params = json.load(open(os.path.join(REPO, "configs", "tiny.json")))
+    fsm = 1
+    env = dict(os.environ, PYTHONPATH=REPO)
+    if variant in ("frame_shift_mul2", "native_score_alpha"):
+        params["indexer"]["frame_shift_mul"] = fsm = 2
+    if variant == "native_score_alpha":
+        params["indexer"]["score_alpha"] = 2.0
+        env["PFANN_CPP_ACCELERATE"] = "1"
+    if variant == "use_float16":
+        params["indexer"]["use_float16"] = True
+    d, k, hop_s = params["model"]["d"], params["indexer"]["top_k"], params["hop_size"]
+    sd = synth.make_state_dict(params, seed=77)
+    mdir = tmp_path / "model"
+    mdir.mkdir()
+    torch.save({n: torch.from_numpy(v) for n, v in sd.items()}, str(mdir / "model.pt"))
+    json.dump(params, open(str(mdir / "configs.json"), "w"))
+    music, songs = [], []
+    for s in range(9):
+        path = str(tmp_path / ("song%d.wav" % s))
+        songs.append(synth.make_song(300 + s, seconds=9.0 + s))
+        synth.write_wav(path, songs[-1])
+        music.append(path)
+    music.append(music[2])                                        # a duplicated song: ties -> the lower id
+    (tmp_path / "music.txt").write_text("".join(p + "\n" for p in music))
+    queries = []
+    for j in range(12):
+        q, _ = synth.make_query(songs[j % 9], 40 + j, 4.0 + (j % 3), snr_db=[30.0, 10.0, 3.0][j % 3])
+        path = str(tmp_path / ("q%02d.wav" % j))
+        synth.write_wav(path, q)
+        queries.append(path)
+    queries.insert(5, str(tmp_path / "nope.wav"))
+    (tmp_path / "queries.txt").write_text("".join(p + "\n" for p in queries))
+
+    def run(*cmd):
+        r = subprocess.run([sys.executable] + list(cmd), capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    db, result, edir = str(tmp_path / "db"), str(tmp_path / "result.txt"), str(tmp_path / "emb")
+    run(os.path.join(REPO, "builder.py"), str(tmp_path / "music.txt"), db, str(mdir))
+    run(os.path.join(REPO, "matcher.py"), str(tmp_path / "queries.txt"), db, result)
+    run(os.path.join(REPO, "extractemb.py"), str(tmp_path / "queries.txt"), db, edir)
+    assert json.load(open(os.path.join(db, "configs.json")))["indexer"].get("frame_shift_mul", 1) == fsm
+    dbe = np.fromfile(os.path.join(db, "embeddings"), np.float32).reshape(-1, d)
+    key = np.fromfile(os.path.join(db, "landmarkKey"), np.int32)
+    pos = osq.song_pos_from_key(key)
+    assert key[0] == (9 * 8000 - 8000) // 4000 + 1                 # the builder hops whole frames whatever fsm says (builder.py:64)
+    qe = np.fromfile(os.path.join(edir, "query_embeddings"), np.float32).reshape(-1, d)
+    qi = np.fromfile(os.path.join(edir, "query_index"), np.int64).reshape(-1, 2)
+    detail = list(csv.reader(open(os.path.splitext(result)[0] + "_detail.csv", newline="")))[1:]
+    blocks = np.fromfile(result + ".bin", np.float32).reshape(len(queries), len(music), 2)
+    worst_emb = 0.0
+    for j, qp in enumerate(queries):
+        if qi[j, 1] == 0:
+            assert detail[j][1:] == ["error", "-inf", "0"] and not blocks[j].any()
+            continue
+        e = qe[qi[j, 0]: qi[j, 0] + qi[j, 1]]
+        ref = oracle_embed(qp, params, sd)
+        assert ref.shape == e.shape
+        worst_emb = max(worst_emb, float(np.abs(ref - e).max()))
+        if variant == "use_float16":
+            _, I = osr.flat_ip_topk_f16(e, dbe, k)
+            rows = dbe.astype(np.float16).astype(np.float32)
+            tol = 2e-4                                               # the kernel accumulates the fp16 rows in fp32
+        else:
+            _, I = osr.flat_ip_topk(e, dbe, k)
+            rows, tol = dbe, 2e-6
+        if variant == "native_score_alpha":
+            best, ss = native.seq_score(rows, pos, e, I, fsm, 2.0)
+            sc, song, sec = float(ss[best, 0]), best, float(ss[best, 1]) * hop_s / fsm
+            ss[:, 1] *= hop_s / fsm
+        else:
+            sc, (song, sec), ss = osq.query_embeddings_base(e, I, rows, pos, hop_s, fsm)
+        assert detail[j][1] == music[song], (variant, j, detail[j], song)
+        assert float(detail[j][3]) == sec, (variant, j, detail[j], sec)
+        assert abs(float(detail[j][2]) - sc) < tol, (variant, j, detail[j], sc)
+        assert np.array_equal(blocks[j][:, 1], ss[:, 1]), (variant, j)
+        assert np.abs(blocks[j][:, 0] - ss[:, 0]).max() < tol
+        if j % 9 == 2:
+            assert song == 2                                        # the duplicate (song 9) never wins the tie
+    assert worst_emb < 1e-4

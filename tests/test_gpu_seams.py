@@ -293,3 +293,39 @@ def test_matcher_loop_on_the_mirror_classes(tmp_path, cfgname):
         w_sco, (w_song, w_tim), _ = osq.query_embeddings_base(e, I, db_emb, pos, params["hop_size"], fsm)
         assert ans == music[w_song] and tim == w_tim, (qp, ans, tim, w_song, w_tim)
         assert abs(sco - w_sco) < 1e-4
+
+
+def test_database_under_ranks_snippet(tmp_path):
+    """"ranks-database": INTEGRATION.md's Database-under-ranks script, as written, under torch.distributed.run with 2 ranks
+    (gloo-staged collectives on this box's one GPU): every rank gets the single-process answer for a query cut out of
+    the database, with the whole [n_songs, 2] score block."""
+    import subprocess
+    import sys
+    import torch
+    params = cfg("tiny")
+    d = params["model"]["d"]
+    key = [7, 0, 12, 9, 5, 11]
+    pos = np.concatenate([[0], np.cumsum(key)])
+    emb = synth.unit_rows(77, "ranks/db", int(pos[-1]), d).astype(np.float32)
+    db_dir = tmp_path / "db"
+    db_dir.mkdir()
+    emb.tofile(str(db_dir / "embeddings"))
+    np.asarray(key, np.int32).tofile(str(db_dir / "landmarkKey"))
+    (db_dir / "songList.txt").write_text("".join("song%d.wav\n" % i for i in range(len(key))))
+    json.dump(params, open(str(db_dir / "configs.json"), "w"))
+    q = emb[pos[3] + 2: pos[3] + 7]
+    np.save(str(tmp_path / "q.npy"), q)
+    head = ("import os, sys, json\nimport numpy as np\nsys.path.insert(0, %r)\ndir_for_db = %r\n"
+            "params = json.load(open(os.path.join(dir_for_db, 'configs.json')))\nembeddings = np.load(%r)\n"
+            % (REPO, str(db_dir), str(tmp_path / "q.npy")))
+    tail = ("\nassert ans == 3 and tim == 2 * params['hop_size'] and abs(sco - 1.0) < 1e-5, (ans, tim, sco)\n"
+            "assert hi - lo < len(db.songList) and song_score[3, 0] > 0.999 and song_score[1].sum() == 0\nprint('RANK_OK')\n")
+    script = tmp_path / "ranks_db.py"
+    script.write_text(head + snippets()["ranks-database"] + tail)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PFANN_GPUS")}
+    env.update(PFANN_DIST_BACKEND="gloo", PFANN_FORCE_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29771", str(script)], capture_output=True, text=True, timeout=600,
+                       env=env, cwd=str(tmp_path))
+    assert r.returncode == 0 and r.stdout.count("RANK_OK") == 2, r.stdout[-2000:] + r.stderr[-3000:]
+    assert torch.cuda.is_available()

@@ -481,6 +481,118 @@ def test_wav_reader_clamps_a_streamed_header(tmp_path):
     assert info[0].status == 0 and info[0].n_frames == 5000
 
 
+def test_native_loader_rounds_cut_alike_on_every_rank(tmp_path):
+    """Several ranks (one process per GPU): builder._native_groups cuts the list into rounds of `world` launch groups;
+    every rank probes all headers, so every rank must see the SAME layout, read only its own group, and together the
+    groups must cover the list exactly once in order -- for 1, 2 and 3 ranks, with and without the start-up ramp."""
+    import types
+    from pfann_amd import builder, lib as L
+    from pfann_amd.musicdata import MusicDataset
+    params = json.load(open(os.path.join(REPO, "configs", "tiny.json")))
+    rng = np.random.default_rng(11)
+    files, nseg = [], []
+    for j in range(41):
+        path = str(tmp_path / ("g%02d.wav" % j))
+        if j in (0, 17, 40):
+            open(path, "wb").write(b"junk")
+            nseg.append(0)
+        else:
+            n = int(rng.integers(8000, 60000))
+            synth.write_wav(path, rng.integers(-900, 900, n).astype(np.int16))
+            nseg.append((n - 8000) // 4000 + 1)
+        files.append(path)
+    ds = MusicDataset(files, params)
+    eng = types.SimpleNamespace(lib=L.load(), seg_len=8000, params=params, pcm16_to_mono=None)
+
+    class Pool:
+        def get(self, n):
+            import torch
+            return torch.empty(max(n, 1), dtype=torch.int16)
+    budget = 20
+    for ramp in ("1", "0"):
+        os.environ["PFANN_GROUP_RAMP"] = ramp
+        try:
+            for world in (1, 2, 3):
+                per_rank = [list(builder._native_groups(eng, ds, 4000, budget, Pool(), 2, r, world)) for r in range(world)]
+                n_rounds = len(per_rank[0])
+                assert all(len(x) == n_rounds for x in per_rank), "ranks disagree on the number of rounds"
+                covered = []
+                for k in range(n_rounds):
+                    if world == 1:
+                        items = per_rank[0][k][0]
+                        covered += [i for i, _, _ in items]
+                        continue
+                    layout = per_rank[0][k][4]
+                    for r in range(world):
+                        got = per_rank[r][k]
+                        assert [(b, list(p)) for b, p in got[4]] == [(b, list(p)) for b, p in layout]
+                        base, pred = layout[r]
+                        assert [i for i, _, _ in got[0]] == list(range(base, base + len(pred)))     # its own group only
+                        assert [n for _, n, _ in got[0]] == [nseg[i] for i in range(base, base + len(pred))] == list(pred)
+                        assert sum(pred) <= budget or len(pred) == 1
+                        covered += list(range(base, base + len(pred)))
+                assert covered == list(range(41)), (world, ramp, covered)
+        finally:
+            os.environ.pop("PFANN_GROUP_RAMP", None)
+
+
+WRITER_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from pfann_amd.dist import init_ranks, finish_ranks, shard_songs
+from pfann_amd.matcher import ResultWriter
+ranks = init_ranks()
+assert ranks.backend == "gloo" and ranks.sharded
+out_dir, n_songs, nq = sys.argv[2], 23, 9
+key = [3 + (7 * i) % 5 for i in range(n_songs)]
+pos = np.concatenate([[0], np.cumsum(key)])
+lo, hi = shard_songs(pos, ranks.world)[ranks.rank]
+tot = ranks.sum_host(np.asarray([hi - lo, ranks.rank]))
+assert tot[0] == n_songs and tot[1] == sum(range(ranks.world))
+rng = np.random.default_rng(5)
+blocks = rng.random((nq, n_songs, 2)).astype(np.float32)
+w = ResultWriter(os.path.join(out_dir, "sharded.txt"), n_songs, ranks=ranks, n_queries=nq, song_range=(lo, hi))
+for j in range(nq):
+    if j in (2, 8):
+        w.write_error("q%d" % j, qi=j)
+    else:
+        w.write("q%d" % j, "song %d" % j, 0.5 + j, 1.5 * j, blocks[j, lo:hi], qi=j)
+    w.flush()
+w.close()
+ranks.barrier()
+if ranks.rank == 0:
+    s = ResultWriter(os.path.join(out_dir, "single.txt"), n_songs)
+    for j in range(nq):
+        if j in (2, 8):
+            s.write_error("q%d" % j)
+        else:
+            s.write("q%d" % j, "song %d" % j, 0.5 + j, 1.5 * j, blocks[j])
+    s.close()
+    print("WRITER_OK")
+finish_ranks(ranks)
+'''
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_result_writer_equals_single_writer_gloo(tmp_path, world):
+    """matcher.ResultWriter under ranks: rank 0 writes the text files, every rank pwrite()s its songs' columns of the
+    `.bin` matrix in place (error rows stay the zeros the file was created with): the three files equal the single
+    writer's byte for byte.  Also Ranks.sum_host over the gloo group.  CPU only."""
+    script = tmp_path / "w.py"
+    script.write_text(WRITER_WORKER)
+    env = {k: v for k, v in os.environ.items() if k not in ("PFANN_GPUS", "PFANN_FORCE_SHARDED")}
+    env.update(MASTER_ADDR="127.0.0.1", PFANN_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(29300 + world + os.getpid() % 150), str(script), REPO, str(tmp_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=REPO)
+    assert r.returncode == 0 and "WRITER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    for suffix in (".txt", ".txt.bin", "_detail.csv"):
+        a = open(str(tmp_path / ("sharded" + suffix)), "rb").read()
+        b = open(str(tmp_path / ("single" + suffix)), "rb").read()
+        assert a == b and len(a) > 0, suffix
+
+
 def test_cli_bench_helpers(tmp_path):
     """tools/cli_bench.py host pieces: its WAV writer produces files the `wave` module (the reference's reader,
     audio.py:130-149) and the library's native reader agree on; the stage-line parser reads what the CLIs print."""

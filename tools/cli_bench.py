@@ -71,7 +71,9 @@ def parse_stdout(text):
     return stages, total
 
 
-def run(n_songs=10000, n_queries=2000, snr=0.0, device=0, keep=False, workdir=None, log=print):
+def run(n_songs=10000, n_queries=2000, snr=0.0, device=0, keep=False, workdir=None, log=print, gpus=1):
+    """gpus > 1: both tools are started with PFANN_GPUS=gpus and launch their own ranks, one per GPU (the database is
+    then built by, and sharded over, all of them)."""
     import torch
     from pfann_amd import synth
     from pfann_amd.utils import read_config
@@ -123,10 +125,17 @@ def run(n_songs=10000, n_queries=2000, snr=0.0, device=0, keep=False, workdir=No
             (n_songs, n_queries, (n_songs * SEG_PER_SONG * 8000 + n_queries * 160000) / 1e9, work, t_gen))
 
         env = dict(os.environ, PYTHONPATH=REPO)
-        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
-            env.pop(k, None)
+        under_launcher = "TORCHELASTIC_RUN_ID" in env
+        for k in list(env):                   # nothing of a launcher this process may itself be running under
+            if k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK",
+                     "ROLE_WORLD_SIZE", "ROLE_NAME", "MASTER_PORT") or k.startswith("TORCHELASTIC_") or \
+                    k.startswith("TORCH_NCCL_ASYNC") or k == "NCCL_ASYNC_ERROR_HANDLING" or \
+                    (k == "OMP_NUM_THREADS" and under_launcher):         # (the launcher's own default of 1)
+                env.pop(k, None)
+        if gpus > 1:
+            env["PFANN_GPUS"] = str(gpus)
         db = os.path.join(work, "db")
-        out = {"songs": n_songs, "queries": n_queries, "snr_db": snr, "dir": os.path.dirname(work),
+        out = {"songs": n_songs, "queries": n_queries, "snr_db": snr, "dir": os.path.dirname(work), "gpus": gpus,
                "decode_workers": int(os.environ.get("PFANN_DECODE_WORKERS", "8")),
                "wav_bytes": int(n_songs * SEG_PER_SONG * 8000 + n_queries * 160000)}
         # ---- builder

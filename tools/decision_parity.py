@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""Full-population decision parity (north_star: "top-1 match / segment-offset decisions exactly on the
+same queries"): EVERY query of a BASELINE config goes through the CPU oracle -- segmenter -> log-mel -> encoder (torch
+CPU fp32) -> exact top-k (BLAS) -> the reference's Python-path sequence matcher -- next to the GPU product path, and
+every query is compared: fingerprints within 1e-4, (song, offset) identical, score within 1e-5.  A flip is classified
+from the oracle's own numbers:
+    boundary tie  : the two top-k label sets differ only by rows whose scores lie within 1e-5 of the oracle's k-th score
+                    (5e-6 fingerprint differences move which of two equal-scoring rows is the k-th)
+    alignment tie : same candidates, and the two decisions' sequence scores lie within 1e-6 of each other in the oracle
+    bug           : anything else
+The oracle runs in W worker PROCESSES (each 8 torch threads; the oracle anti-scales beyond that), fed through .npy files
+in a tmpfs directory; nothing under oracle/ is imported by the product.
+
+    python tools/decision_parity.py --songs 10000 --queries 2000 --snr 0 [--workers 16] [--out profiles/r4/x.json]
+    python tools/decision_parity.py --worker <dir> <w> <W>        (internal)
+"""
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+SEG, QSEG, HOP = 59, 19, 4000
+
+
+def worker(work, w, W):
+    import torch
+    torch.set_num_threads(int(os.environ.get("PFANN_ORACLE_THREADS", "8")))
+    from oracle import encoder as oe
+    from oracle import melspec as om
+    from oracle import search as osr
+    from oracle import segmenter as osg
+    from oracle import seqscore as osq
+    meta = json.load(open(os.path.join(work, "meta.json")))
+    params, k = meta["params"], meta["k"]
+    sd = dict(np.load(os.path.join(work, "weights.npz")))
+    db = np.load(os.path.join(work, "db.npy"), mmap_mode="r")
+    db = np.ascontiguousarray(db)
+    song_pos = np.load(os.path.join(work, "song_pos.npy"))
+    pcm = np.load(os.path.join(work, "q_pcm.npy"), mmap_mode="r")
+    emb_gpu = np.load(os.path.join(work, "q_emb_gpu.npy"), mmap_mode="r")
+    js = list(range(w, pcm.shape[0], W))
+    out = {"j": [], "song": [], "sec": [], "score": [], "emb_err": [], "kth": [], "next": [], "runner_up": [], "labels": []}
+    for j in js:
+        segs = osg.segment(osg.pcm_to_mono(np.asarray(pcm[j])[:, None]), 8000, HOP)
+        e = oe.encode(om.melspec(segs, params), sd, params)
+        out["emb_err"].append(float(np.abs(e - emb_gpu[j * QSEG:(j + 1) * QSEG]).max()))
+        D, I = osr.flat_ip_topk_blas(e, db, k + 1)
+        sc, (song, sec), ss = osq.query_embeddings_base(e, I[:, :k], db, song_pos, meta["hop_s"], 1)
+        two = np.sort(ss[:, 0])[-2:]                       # best per-song scores: winner and the runner-up SONG
+        out["j"].append(j), out["song"].append(song), out["sec"].append(sec), out["score"].append(sc)
+        out["kth"].append(D[:, k - 1].copy()), out["next"].append(D[:, k].copy()), out["runner_up"].append(float(two[0]))
+        out["labels"].append(I[:, :k].copy())
+    np.savez(os.path.join(work, "res_%d.npz" % w), j=np.asarray(out["j"]), song=np.asarray(out["song"]), sec=np.asarray(out["sec"]),
+             score=np.asarray(out["score"]), emb_err=np.asarray(out["emb_err"]), kth=np.asarray(out["kth"]),
+             next=np.asarray(out["next"]), runner_up=np.asarray(out["runner_up"]), labels=np.asarray(out["labels"]))
+
+
+def run(n_songs, n_queries, snr, workers=16, config="default", plan=9728, max_batch=9728, log=print, keep=False):
+    import torch
+    from pfann_amd import synth
+    from pfann_amd.builder import embed_files
+    from pfann_amd.database import DeviceIndex
+    from pfann_amd.engine import Engine
+    params = json.load(open(os.path.join(REPO, "configs", config + ".json")))
+    d, k = params["model"]["d"], params["indexer"]["top_k"]
+    sd = synth.make_state_dict_calibrated(params, seed=123) if config == "default" else synth.make_state_dict(params, seed=123)
+    eng = Engine(params, 0, max_batch=max_batch)
+    eng.load_state_dict(sd)
+    eng.set_plan_batch(plan)
+    dev = eng.device
+    t0 = time.time()
+
+    class Pcm:
+        def __init__(self, ids, pcm):
+            self.files, self.pcm = ["song %d" % i for i in ids], pcm
+
+        def load_pcm(self, i):
+            return self.pcm[i]
+
+        def __len__(self):
+            return len(self.files)
+    shard = torch.empty((n_songs * SEG, d), device=dev, dtype=torch.float32)
+    for c0 in range(0, n_songs, 256):
+        ids = list(range(c0, min(c0 + 256, n_songs)))
+        pcm = synth.make_songs_torch(ids, 30.0, device=dev)
+        for i, n_seg, e in embed_files(eng, Pcm(ids, pcm), HOP, batch_windows=max_batch):
+            shard[ids[i] * SEG:(ids[i] + 1) * SEG] = e
+    song_pos = np.arange(n_songs + 1, dtype=np.int64) * SEG
+    q_song = [int((j * 7919 + 13) % n_songs) for j in range(n_queries)]
+    pcms, embs = [], []
+    for c0 in range(0, n_queries, 256):
+        ids = q_song[c0:c0 + 256]
+        qp, _ = synth.make_queries_torch(synth.make_songs_torch(ids, 30.0, device=dev), list(range(c0, c0 + len(ids))), 10.0, snr)
+        pcms.append(qp)
+    q_pcm = torch.cat(pcms)
+    # the GPU decisions the way the matcher CLI makes them: launch groups of max_batch windows, plan pinned
+    index = DeviceIndex(d, 0)
+    index.load(shard, song_pos, 0)
+    per = max(1, max_batch // QSEG)
+    res, labels = [], []
+    for c0 in range(0, n_queries, per):
+        qp = q_pcm[c0:c0 + per]
+        nq = qp.shape[0]
+        starts = (torch.arange(nq, device=dev)[:, None] * qp.shape[1] + torch.arange(QSEG, device=dev)[None, :] * HOP).reshape(-1)
+        e = eng.embed_windows(eng.pcm16_to_mono(qp.reshape(-1)), starts)
+        D, I = index.search(e, k)
+        r, _ = index.match(e, I, np.arange(nq, dtype=np.int64) * QSEG, np.full(nq, QSEG, np.int32))
+        embs.append(e), res.append(r), labels.append(I.cpu().numpy())
+    res = np.concatenate(res)
+    labels = np.concatenate(labels).reshape(n_queries, QSEG, k)
+    emb_gpu = torch.cat(embs).cpu().numpy()
+    torch.cuda.synchronize()
+    t_gpu = time.time() - t0
+    log("decision_parity: GPU side (db %d rows + %d queries) %.1f s" % (n_songs * SEG, n_queries, t_gpu))
+
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    work = tempfile.mkdtemp(prefix="pfann_parity_", dir=base)
+    try:
+        np.save(os.path.join(work, "db.npy"), shard.cpu().numpy())
+        np.save(os.path.join(work, "song_pos.npy"), song_pos)
+        np.save(os.path.join(work, "q_pcm.npy"), q_pcm.cpu().numpy())
+        np.save(os.path.join(work, "q_emb_gpu.npy"), emb_gpu)
+        np.savez(os.path.join(work, "weights.npz"), **{n: np.asarray(v) for n, v in sd.items()})
+        json.dump({"params": params, "k": k, "hop_s": params["hop_size"]}, open(os.path.join(work, "meta.json"), "w"))
+        t1 = time.time()
+        env = dict(os.environ, PYTHONPATH=REPO, OMP_NUM_THREADS=os.environ.get("PFANN_ORACLE_THREADS", "8"))
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", work, str(w), str(workers)], env=env)
+                 for w in range(workers)]
+        rcs = [p.wait() for p in procs]
+        if any(rcs):
+            raise RuntimeError("oracle workers failed: %r" % rcs)
+        t_cpu = time.time() - t1
+        parts = [np.load(os.path.join(work, "res_%d.npz" % w)) for w in range(workers)]
+    finally:
+        if not keep:
+            shutil.rmtree(work, ignore_errors=True)
+    order = np.argsort(np.concatenate([p["j"] for p in parts]))
+
+    def col(name):
+        return np.concatenate([p[name] for p in parts])[order]
+    o_song, o_sec, o_score, emb_err = col("song"), col("sec"), col("score"), col("emb_err")
+    kth, nxt, runner, o_lab = col("kth"), col("next"), col("runner_up"), col("labels")
+    log("decision_parity: oracle side %.1f s on %d processes" % (t_cpu, workers))
+    g_song, g_sec, g_score = res["song"].astype(np.int64), res["offset"] * params["hop_size"], res["score"]
+    same = (g_song == o_song) & (g_sec == o_sec)
+    flips = []
+    for j in np.nonzero(~same)[0]:
+        sets_equal = all(set(labels[j, t].tolist()) == set(o_lab[j, t].tolist()) for t in range(QSEG))
+        # rows that are in one list and not the other must score within 1e-5 of the oracle's k-th score
+        gap_k = float(np.min(kth[j] - nxt[j]))
+        align_gap = float(o_score[j] - runner[j])
+        if not sets_equal and gap_k <= 1e-5:
+            kind = "boundary tie"
+        elif abs(float(g_score[j]) - float(o_score[j])) <= 1e-6 or align_gap <= 1e-6:
+            kind = "alignment tie"
+        else:
+            kind = "bug"
+        flips.append({"query": int(j), "gpu": [int(g_song[j]), float(g_sec[j]), float(g_score[j])],
+                      "oracle": [int(o_song[j]), float(o_sec[j]), float(o_score[j])], "topk_sets_equal": bool(sets_equal),
+                      "min_gap_kth_vs_next": gap_k, "oracle_best_minus_runner_up_song": align_gap, "class": kind})
+    sets_differ = int(sum(1 for j in range(n_queries)
+                          if any(set(labels[j, t].tolist()) != set(o_lab[j, t].tolist()) for t in range(QSEG))))
+    hit = float(np.mean(g_song == np.asarray(q_song)))
+    out = {"config": config, "db_songs": n_songs, "db_rows": n_songs * SEG, "queries": n_queries, "snr_db": snr, "top_k": k,
+           "plan_batch": plan, "identical_song_and_offset": int(same.sum()), "flips": flips,
+           "bugs": int(sum(1 for f in flips if f["class"] == "bug")),
+           "max_embedding_abs_diff": float(emb_err.max()), "embedding_tolerance": 1e-4,
+           "max_score_abs_diff_where_decisions_agree": float(np.abs(g_score - o_score)[same].max()) if same.any() else None,
+           "score_tolerance": 1e-5,
+           "queries_whose_topk_label_sets_differ": sets_differ,
+           "smallest_kth_minus_next_gap_over_all_rows": float(np.min(kth - nxt)),
+           "top1_hit_rate_gpu": round(hit, 4), "top1_hit_rate_oracle": round(float(np.mean(o_song == np.asarray(q_song))), 4),
+           "gpu_side_s": round(t_gpu, 1), "oracle_side_s": round(t_cpu, 1), "oracle_processes": workers,
+           "oracle_threads_per_process": int(os.environ.get("PFANN_ORACLE_THREADS", "8")), "host_cpus": os.cpu_count(),
+           "oracle": "oracle/{segmenter,melspec,encoder,search,seqscore}.py (python path, database.py:117-166) against the same "
+                     "GPU-built db"}
+    return out
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--worker":
+        worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
+        sys.exit(0)
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--songs", type=int, default=10000)
+    ap.add_argument("--queries", type=int, default=2000)
+    ap.add_argument("--snr", type=float, default=0.0)
+    ap.add_argument("--workers", type=int, default=16)
+    ap.add_argument("--plan", type=int, default=9728)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    r = run(a.songs, a.queries, a.snr, a.workers, plan=a.plan, log=lambda *x: print(*x, file=sys.stderr, flush=True))
+    print(json.dumps({k: v for k, v in r.items() if k != "flips"}), "flips:", json.dumps(r["flips"])[:3000])
+    if a.out:
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+        json.dump(r, open(a.out, "w"), indent=1)
