@@ -312,7 +312,7 @@ class Database:
         largest number of query rows one launch group will bring (the matcher: PFANN_MAX_BATCH) -- the search workspace is
         sized by it, and growing it later means a hipFree, which waits for everything in flight: the first full group of
         a matcher run used to stall 30 ms behind its own encoder there (profiles/r3/NOTES.md)."""
-        if self.index.ntotal:
+        if int(self.song_pos[-1]):                   # (the WHOLE database: under ranks every rank must come along)
             q = torch.zeros((19, self.d), device=self.index.device)
             q[:, 0] = 1.0
             self.query_finish(self.query_launch(q, [0], [19], want_song_scores=True))

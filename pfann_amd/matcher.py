@@ -11,6 +11,7 @@ import csv
 import ctypes
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -21,7 +22,7 @@ from .database import Database
 from .dist import finish_ranks, init_ranks, self_launch_if_asked
 from .engine import Engine
 from .musicdata import MusicDataset
-from .utils import StageTimer, get_logger, init_logger, read_config
+from .utils import StageTimer, StartupClock, get_logger, init_logger, read_config
 
 
 class ResultWriter:
@@ -124,21 +125,43 @@ def main(argv=None):
     if rank0:
         init_logger("matcher")                                             # matcher.py:31-32
 
+    clock = StartupClock(say)
     say("loading model...")
     max_batch = int(os.environ.get("PFANN_MAX_BATCH", "9728"))
+    # the database (file read, upload, fp16 copy: host- and copy-engine work) loads on a thread while this one builds the
+    # engine and warms it up (weights, workspace allocation, first launch of every kernel)
+    db_box = []
+
+    def load_db():
+        try:
+            db_box.append(Database(dir_for_db, params["indexer"], params["hop_size"], device=dev, d=params["model"]["d"],
+                                   ranks=ranks))
+        except BaseException as x:                  # noqa: B902 -- re-raised on the main thread
+            db_box.append(x)
+    db_thread = threading.Thread(target=load_db, name="pfann-db-load")
+    db_thread.start()
+    dataset = MusicDataset(file_list_for_query, params)
     engine = Engine(params, dev, max_batch=max_batch)
     # kernel variants of a full launch group for every call: a query's fingerprints -- and with them every byte of the
     # three output files -- do not depend on how the list is cut into groups or spread over ranks
     engine.set_plan_batch(max_batch)
+    clock.lap("engine")
     engine.load_state_dict(torch.load(os.path.join(dir_for_db, "model.pt"), map_location="cpu"))
-    engine.warmup(windows=max_batch)
+    clock.lap("weights")
+    # a short list never fills a launch group: warm up (and size the search workspace) for what will really come
+    warm = min(max_batch, max(64, len(dataset) * int(os.environ.get("PFANN_WARMUP_SEGMENTS_PER_FILE", "19"))))
+    engine.warmup(windows=warm)
+    clock.lap("engine warm-up")
     say("model loaded")
     say("loading database...")
-    db = Database(dir_for_db, params["indexer"], params["hop_size"], device=dev, d=params["model"]["d"], ranks=ranks)
-    db.warmup(rows=max_batch * (ranks.world if multi else 1))
+    db_thread.join()
+    if isinstance(db_box[0], BaseException):
+        raise db_box[0]
+    db = db_box[0]
+    clock.lap("database (rest of its load after the engine was ready)")
+    db.warmup(rows=warm * (ranks.world if multi else 1))
+    clock.lap("database warm-up")
     say("database loaded")
-
-    dataset = MusicDataset(file_list_for_query, params)
     timer = StageTimer()
     db.timer = timer
     tm_0 = time.time()

@@ -107,3 +107,24 @@ class StageTimer:
             else:
                 keep.append((name, e0, e1))
         self._pending = keep
+
+
+class StartupClock:
+    """PFANN_STARTUP_TIMING=1: the CLIs print one 'startup <what> <seconds>s' line per start-up stage (tools/cli_bench.py
+    reads them; PFANN_T0 = the wall-clock time the process was spawned at, so that interpreter start + imports are a stage
+    too).  Off by default: the reference's tools print nothing of the kind."""
+
+    def __init__(self, say=print):
+        import os
+        self.on = os.environ.get("PFANN_STARTUP_TIMING", "0") not in ("0", "")
+        self.say = say
+        self.t = time.time()
+        t0 = os.environ.get("PFANN_T0")
+        if self.on and t0:
+            self.say("startup interpreter and imports %.3fs" % (self.t - float(t0)))
+
+    def lap(self, what):
+        now = time.time()
+        if self.on:
+            self.say("startup %s %.3fs" % (what, now - self.t))
+        self.t = now

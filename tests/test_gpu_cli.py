@@ -304,6 +304,5 @@ def test_matcher_cli_variants_vs_oracle(tmp_path, variant):
         assert abs(float(detail[j][2]) - sc) < tol, (variant, j, detail[j], sc)
         assert np.array_equal(blocks[j][:, 1], ss[:, 1]), (variant, j)
         assert np.abs(blocks[j][:, 0] - ss[:, 0]).max() < tol
-        if j % 9 == 2:
-            assert song == 2                                        # the duplicate (song 9) never wins the tie
+        assert song != 9                                            # the duplicate of song 2 never wins the tie
     assert worst_emb < 1e-4

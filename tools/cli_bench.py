@@ -57,10 +57,22 @@ def pick_tmp(need_bytes):
     return None
 
 
+def parse_startup(text):
+    """'startup <what> <seconds>s' lines (PFANN_STARTUP_TIMING=1) -> dict"""
+    out = {}
+    for ln in text.splitlines():
+        m = re.match(r"^startup (.+) ([0-9.]+)s$", ln.strip())
+        if m:
+            out[m.group(1)] = float(m.group(2))
+    return out
+
+
 def parse_stdout(text):
     """'<stage> <seconds>s' lines + the total line -> dict"""
     stages, total = {}, None
     for ln in text.splitlines():
+        if ln.startswith("startup "):
+            continue
         m = re.match(r"^(total (?:build|query) time) ([0-9.]+)s$", ln.strip())
         if m:
             total = float(m.group(2))
@@ -138,10 +150,11 @@ def run(n_songs=10000, n_queries=2000, snr=0.0, device=0, keep=False, workdir=No
         out = {"songs": n_songs, "queries": n_queries, "snr_db": snr, "dir": os.path.dirname(work), "gpus": gpus,
                "decode_workers": int(os.environ.get("PFANN_DECODE_WORKERS", "8")),
                "wav_bytes": int(n_songs * SEG_PER_SONG * 8000 + n_queries * 160000)}
+        env["PFANN_STARTUP_TIMING"] = "1"
         # ---- builder
         t0 = time.time()
         r = subprocess.run([sys.executable, os.path.join(REPO, "builder.py"), mlist, db, mdir], capture_output=True,
-                           text=True, env=env, cwd=work, timeout=3600)
+                           text=True, env=dict(env, PFANN_T0=repr(t0)), cwd=work, timeout=3600)
         wall = time.time() - t0
         if r.returncode != 0:
             raise RuntimeError("builder.py failed:\n" + r.stdout[-2000:] + r.stderr[-3000:])
@@ -151,13 +164,14 @@ def run(n_songs=10000, n_queries=2000, snr=0.0, device=0, keep=False, workdir=No
         assert int(key.sum()) == n_seg and os.path.getsize(os.path.join(db, "embeddings")) == n_seg * 128 * 4
         out["builder"] = {"segments": n_seg, "process_wall_s": round(wall, 3), "total_build_time_s": total,
                           "segments_per_s_process": round(n_seg / wall, 1),
-                          "segments_per_s": round(n_seg / total, 1) if total else None, "stages_s": stages}
+                          "segments_per_s": round(n_seg / total, 1) if total else None, "stages_s": stages,
+                          "startup_s": round(wall - total, 3) if total else None, "startup_split_s": parse_startup(r.stdout)}
         log("cli_bench: builder.py %d segments: process %.2f s, `total build time` %.2f s, stages %s" % (n_seg, wall, total or -1, stages))
         # ---- matcher
         result = os.path.join(work, "result.txt")
         t0 = time.time()
         r = subprocess.run([sys.executable, os.path.join(REPO, "matcher.py"), qlist, db, result], capture_output=True,
-                           text=True, env=env, cwd=work, timeout=3600)
+                           text=True, env=dict(env, PFANN_T0=repr(t0)), cwd=work, timeout=3600)
         wall = time.time() - t0
         if r.returncode != 0:
             raise RuntimeError("matcher.py failed:\n" + r.stdout[-2000:] + r.stderr[-3000:])
@@ -170,6 +184,7 @@ def run(n_songs=10000, n_queries=2000, snr=0.0, device=0, keep=False, workdir=No
         out["matcher"] = {"segments": n_qseg, "process_wall_s": round(wall, 3), "total_query_time_s": total,
                           "segments_per_s_process": round(n_qseg / wall, 1),
                           "segments_per_s": round(n_qseg / total, 1) if total else None, "stages_s": stages,
+                          "startup_s": round(wall - total, 3) if total else None, "startup_split_s": parse_startup(r.stdout),
                           "top1_hit_rate": round(hit / max(n_queries, 1), 4),
                           "bin_bytes": n_queries * n_songs * 8}
         log("cli_bench: matcher.py %d segments: process %.2f s, `total query time` %.2f s, hit-rate %.4f, stages %s" %
