@@ -2,7 +2,9 @@
 """Drop-in for the reference's `python extractemb.py ...` (see pfann_amd/extractemb.py)."""
 import sys
 
-from pfann_amd.extractemb import main
+from pfann_amd import prewarm
 
 if __name__ == "__main__":
-    sys.exit(main(sys.argv))
+    prewarm.start()                     # HIP init + code-object loading on a thread under the import of torch below
+    from pfann_amd.extractemb import main
+    prewarm.fast_exit(main(sys.argv))

@@ -171,6 +171,11 @@ int pfann_set_fused_layernorm(pfann_ctx *ctx, int on);
  * effect.  New capability: the reference computes these convolutions in fp32 (model.py:54-73). */
 int pfann_set_encoder_precision(pfann_ctx *ctx, int mode);
 
+/* Makes the HIP runtime initialise `device` and load every code object of this library now (one empty launch per
+ * translation unit) instead of at each unit's first real launch: about 0.45 s that the drop-in tools spend on a thread
+ * while the interpreter is still importing torch.  Needs no context; safe to call more than once.  0 / -1. */
+int pfann_prewarm(int device);
+
 /* Kernel-variant plan of the encoder.  By default every call picks its GEMM tile size, the split-K path and the
  * small-batch head from its OWN batch size, which makes the last bits of a fingerprint depend on the batch it was
  * computed in (different summation orders; all within 5e-6 of the fp32 reference).  pfann_set_plan_batch(ctx, n) with

@@ -1,8 +1,12 @@
 #!/usr/bin/env python
 """Drop-in for the reference's `python matcher.py <query list> <db dir> <result file>`."""
+import os
 import sys
 
-from pfann_amd.matcher import main
+from pfann_amd import prewarm
 
 if __name__ == "__main__":
-    sys.exit(main(sys.argv))
+    # HIP initialisation + code-object loading run on a thread under the import of torch below
+    prewarm.start([os.path.join(sys.argv[2], "model.pt")] if len(sys.argv) > 2 else [])
+    from pfann_amd.matcher import main
+    prewarm.fast_exit(main(sys.argv))

@@ -14,6 +14,12 @@
 
 namespace pfann { int launch_rows_to_half(const float *x, int64_t n, int d, void *xh, float *norm_max_dev, hipStream_t s); }
 
+__global__ void noop_api_kernel() {}
+static int launch_noop_api() {
+    hipLaunchKernelGGL(noop_api_kernel, dim3(1), dim3(1), 0, 0);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 namespace pfann {
 
 static thread_local char g_err[1024] = "";
@@ -556,6 +562,14 @@ int pfann_pcm16_files_to_mono(pfann_ctx *c, const void *const *host_pcm, const i
 }
 
 void pfann_debug_keep(pfann_ctx *c, int on) { c->keep = on != 0; }
+
+int pfann_prewarm(int device) {
+    if (hipSetDevice(device) != hipSuccess) { set_error("pfann_prewarm: no HIP device %d", device); return -1; }
+    int rc = launch_noop_api();
+    rc |= prewarm_mel() | prewarm_encoder() | prewarm_encoder_fused() | prewarm_search() | prewarm_search_f16() | prewarm_rerank();
+    if (hipDeviceSynchronize() != hipSuccess) rc = -1;
+    return rc ? -1 : 0;
+}
 
 int64_t pfann_set_plan_batch(pfann_ctx *c, int64_t n) {
     c->plan_batch = n <= 0 ? 0 : (n < 65 ? 65 : n);      // a plan below 65 would select the small-batch kernels, whose

@@ -119,4 +119,12 @@ int launch_song_scores_to_seconds(float *ss, int64_t n_pairs, int fsm, double ho
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): the attribute is per device
 int ensure_dyn_lds(const void *func, int bytes);
 
+// one per translation unit with device code (pfann_prewarm)
+int prewarm_mel();
+int prewarm_encoder();
+int prewarm_encoder_fused();
+int prewarm_search();
+int prewarm_search_f16();
+int prewarm_rerank();
+
 }  // namespace pfann

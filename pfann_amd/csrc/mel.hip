@@ -485,4 +485,11 @@ int launch_pcm16_to_mono(const int16_t *pcm, int64_t n_frames, int n_ch, float *
     return 0;
 }
 
+// pfann_prewarm: one empty launch per translation unit makes the runtime load this unit's code object now
+__global__ void noop_mel_kernel() {}
+int prewarm_mel() {
+    hipLaunchKernelGGL(noop_mel_kernel, dim3(1), dim3(1), 0, 0);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 }  // namespace pfann

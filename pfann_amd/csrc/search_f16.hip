@@ -1018,4 +1018,11 @@ int launch_select_rescore(SearchWorkspace &ws, int64_t nq, int k, int mode, floa
     return 0;
 }
 
+// pfann_prewarm: one empty launch per translation unit makes the runtime load this unit's code object now
+__global__ void noop_search_f16_kernel() {}
+int prewarm_search_f16() {
+    hipLaunchKernelGGL(noop_search_f16_kernel, dim3(1), dim3(1), 0, 0);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 }  // namespace pfann

@@ -58,6 +58,7 @@ SYMBOLS = {
     "pfann_debug_keep": (None, [c_void_p, c_int]),
     "pfann_set_fused_layernorm": (c_int, [c_void_p, c_int]),
     "pfann_set_encoder_precision": (c_int, [c_void_p, c_int]),
+    "pfann_prewarm": (c_int, [c_int]),
     "pfann_set_plan_batch": (c_int64, [c_void_p, c_int64]),
     "pfann_set_streams": (c_int, [c_void_p, c_int]),
     "pfann_db_create": (c_void_p, [c_int, c_int]),

@@ -952,3 +952,38 @@ def test_resample_to_mono_vs_oracle(torch_cuda, file_sr, seconds, n_ch):
     if n_ch == 2 and file_sr == 16000:
         assert np.abs(got).max() > 0.3                                           # the flipped channel did not cancel
     assert np.array_equal(eng.pcm16_to_mono(pcm, sample_rate=8000).cpu().numpy(), segmenter.pcm_to_mono(pcm))
+
+
+@pytest.mark.parametrize("cfgname", ["default", "seg", "tiny"])
+def test_plan_batch_makes_fingerprints_independent_of_the_batch(cfgname):
+    """pfann_set_plan_batch (include/pfann_amd.h; ADVICE r3: "one segment embeds to different bits depending on batch
+    size"): by default the GEMM tile size, the split-K path and the small-batch head are chosen per call, so the last
+    bits of a fingerprint depend on the batch it is computed in -- bounded here by 2e-5 between B <= 64 and B > 64; with
+    the plan pinned (what the drop-in tools do) a segment has the SAME bits alone, in a small batch, at any position of
+    a large one, and in a batch that is chunked by max_batch."""
+    import torch
+    from pfann_amd.engine import Engine
+    params = cfg(cfgname)
+    eng = Engine(params, 0, max_batch=256)
+    eng.load_state_dict(synth.make_state_dict(params, seed=5))
+    dev = eng.device
+    pcm = synth.make_songs_torch(list(range(12)), 30.0, device=dev)
+    wav = eng.pcm16_to_mono(pcm.reshape(-1))
+    L = pcm.shape[1]
+    starts = (torch.arange(12, device=dev)[:, None] * L + torch.arange(59, device=dev)[None, :] * 4000).reshape(-1)[:600]
+    # ---- default: per-call variants, different bits, same fingerprints to rounding
+    full = eng.embed_windows(wav, starts[:256])
+    small = eng.embed_windows(wav, starts[:19])
+    assert float((full[:19] - small).abs().max()) < 2e-5
+    # ---- plan pinned: bit-identical however the windows are batched
+    assert eng.set_plan_batch(256) == 256
+    full = eng.embed_windows(wav, starts)                          # 600 windows = chunks of 256, 256, 88
+    bits = full.view(torch.int32)
+    for idx in (torch.arange(1, device=dev) + 577, torch.arange(19, device=dev) * 3, torch.arange(64, device=dev) + 200,
+                torch.arange(65, device=dev) * 7 % 600, torch.arange(300, device=dev) * 2 % 600,
+                torch.randperm(600, device=dev, generator=torch.Generator(device=dev).manual_seed(3))):
+        e = eng.embed_windows(wav, starts[idx])
+        assert bool((e.view(torch.int32) == bits[idx]).all()), "plan pinned, yet bits depend on the batch (B = %d)" % idx.shape[0]
+    assert eng.set_plan_batch(0) == 0 and eng.set_plan_batch(5) == 65      # below 65 is raised: no small-batch variants
+    # the pinned plan is still the same arithmetic to rounding
+    assert float((eng.embed_windows(wav, starts[:19]) - full[:19]).abs().max()) < 2e-5
