@@ -37,7 +37,14 @@ __global__ void fill(float *p, size_t n, float scale, float bias) {
 
 // MODE 0: the F(2,2) scheme.  MODE 1: the same kernel skeleton doing the plain 6-block convolution (3 full 128-row
 // sub-steps per chunk, two accumulator blocks) -- the like-for-like baseline inside this file.
-template <int MODE, int EPI = 0>       // EPI 1: output rows stored straight from the accumulators (16 B per lane), no LDS staging
+// WHATIF bits (MODE 0 only; results meaningless, timing only; 1 = fewer MFMAs, 2 = + transform arithmetic, 4 = + 8 live registers): an optimistic bound for Winograd F(4,2) on the even phase -- 9
+// channel blocks per FOUR outputs instead of F(2,2)'s 10 -- inside F(2,2)'s own tile life: every second channel chunk
+// leaves out the 16 MFMAs of its e1 x (W0+W2) half step (80 + 64 = 144 per two chunks = 72 per chunk = 9/10), the loader
+// pays the extra transform arithmetic F(4,2) needs (5 transformed even samples from 5 inputs with coefficients 2, 3:
+// ~10 more FMAs per 16 loaded bytes) and a fourth accumulator block is kept live (F(4,2): 7 blocks per quad = 56
+// registers per 64 x 32 wave tile instead of 48).  What it does NOT pay: F(4,2)'s 9 sub-steps (and barriers) per chunk
+// instead of 4, its wider epilogue (coefficients up to 8) and its larger rounding error.
+template <int MODE, int EPI = 0, int WHATIF = 0>       // EPI 1: output rows stored straight from the accumulators (16 B per lane), no LDS staging
 __global__ __launch_bounds__(512, 4) void kw(const float *__restrict__ x, const float *__restrict__ lw, const float *__restrict__ lb,
                                              const float *__restrict__ w, const float *__restrict__ stats, float *__restrict__ y,
                                              float *__restrict__ part, int rps_out, unsigned long long *ts, int hot) {
@@ -71,6 +78,19 @@ __global__ __launch_bounds__(512, 4) void kw(const float *__restrict__ x, const 
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf((xv[e] - mu) * rs, wv[e], bv[e]), 0.f);
         return v;
     };
+    f32x4 carry;                          // WHATIF: the running neighbours an F(4,2) input transform combines
+    for (int e = 0; e < 4; ++e) carry[e] = 0.25f * e;
+    auto extra = [&](f32x4 v) {           // ~10 dependent-free FMAs per vector, the result feeds what is stored
+        if (!(WHATIF & 2)) return v;
+        f32x4 t = v;
+        for (int e = 0; e < 4; ++e) {
+            const float a = fmaf(2.f, v[e], -carry[e]), b2 = fmaf(-3.f, carry[e], v[e]), c = fmaf(2.f, carry[e], v[e]);
+            const float d2 = fmaf(-2.f, v[e], carry[e]), g = fmaf(a, 1e-30f, b2), h2 = fmaf(c, 1e-30f, d2);
+            t[e] = fmaf(g, 1e-30f, fmaf(h2, 1e-30f, v[e]));
+            carry[e] = fmaf(v[e], 1e-30f, carry[e]);
+        }
+        return t;
+    };
     auto issue = [&](int kind, int cc) {                      // global loads of sub-step (kind, channel chunk cc)
         if (MODE == 0) {
             if (kind == 0) {
@@ -98,9 +118,9 @@ __global__ __launch_bounds__(512, 4) void kw(const float *__restrict__ x, const 
             } else if (kind == 1) {
                 const f32x4 f0 = fx(px[0], pw[0], pb[0]);
                 fe1 = fx(px[1], pw[1], pb[1]);
-                *reinterpret_cast<f32x4 *>(&Ad[rowq * LDK + col4 * 4]) = f0 - fe1;
+                *reinterpret_cast<f32x4 *>(&Ad[rowq * LDK + col4 * 4]) = extra(f0 - fe1);
             } else if (kind == 2) {
-                *reinterpret_cast<f32x4 *>(&Ad[rowq * LDK + col4 * 4]) = fe1 - fx(px[0], pw[0], pb[0]);
+                *reinterpret_cast<f32x4 *>(&Ad[rowq * LDK + col4 * 4]) = extra(fe1 - fx(px[0], pw[0], pb[0]));
             } else {
                 *reinterpret_cast<f32x4 *>(&Ad[rowq * LDK + col4 * 4]) = fe1;
             }
@@ -111,6 +131,8 @@ __global__ __launch_bounds__(512, 4) void kw(const float *__restrict__ x, const 
     };
     f32x16 acc[3];
     for (int i = 0; i < 3; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    f32x4 acc_extra[2];                   // WHATIF: 8 more live accumulator registers (56 instead of 48)
+    for (int i = 0; i < 2; ++i) for (int r = 0; r < 4; ++r) acc_extra[i][r] = 0.f;
     constexpr int NST = NSUB * (C / 32);
     issue(0, 0);
     const unsigned long long t_p1 = __builtin_readcyclecounter();
@@ -146,7 +168,8 @@ __global__ __launch_bounds__(512, 4) void kw(const float *__restrict__ x, const 
                         acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[s], a1[s], acc[2], 0, 0, 0);
                     } else if (KIND == 1) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[s], a0[s], acc[0], 0, 0, 0);
                     else if (KIND == 2) acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[s], a0[s], acc[2], 0, 0, 0);
-                    else acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[s], a0[s], acc[1], 0, 0, 0);
+                    else if (!(WHATIF & 1) || ((st / NSUB) & 1) == 0) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[s], a0[s], acc[1], 0, 0, 0);
+                    else if (WHATIF & 4) { acc_extra[s & 1][s >> 1] += b0[s] * a0[s]; }
                 } else {
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[s], a0[s], acc[0], 0, 0, 0);
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[s], a1[s], acc[1], 0, 0, 0);
@@ -181,7 +204,7 @@ __global__ __launch_bounds__(512, 4) void kw(const float *__restrict__ x, const 
         for (int g = 0; g < 4; ++g) {
             f32x4 z4;
             for (int e = 0; e < 4; ++e) {
-                const float z = (MODE == 0 ? acc[i][4 * g + e] + acc[i + 1][4 * g + e] : acc[i][4 * g + e]) + 0.5f;
+                const float z = (MODE == 0 ? acc[i][4 * g + e] + acc[i + 1][4 * g + e] : acc[i][4 * g + e]) + 0.5f + ((WHATIF & 4) ? acc_extra[i][g & 3] * 1e-30f : 0.f);
                 a1s[i] += z; a2s[i] = fmaf(z, z, a2s[i]); z4[e] = z;
             }
             if (EPI == 1) st4(sy, (unsigned)row * (BN * 4u) + (unsigned)(wn * 32 + 8 * g + 4 * lhalf) * 4u, z4);
@@ -235,8 +258,9 @@ int main(int argc, char **argv) {
     const double flop = 2.0 * M * 128 * 384;                  // ALGORITHMIC: the convolution's 3 taps
     printf("M = %lld rows, N = 128, K = 384 (algorithmic), %d tiles, LDS %zu B\n", (long long)M, ntiles, lds);
     for (int rep = 0; rep < 2; ++rep)
-        for (int mode = 2; mode >= 0; --mode) {
-            auto kp = mode == 0 ? kw<0> : (mode == 1 ? kw<1> : kw<0, 1>);
+        for (int mode = 6; mode >= 0; --mode) {
+            auto kp = mode == 0 ? kw<0> : (mode == 1 ? kw<1> : (mode == 2 ? kw<0, 1> : (mode == 3 ? kw<0, 0, 1> : (mode == 4 ? kw<0, 0, 3> :
+                      (mode == 5 ? kw<0, 0, 5> : kw<0, 0, 7>)))));
             (void)hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
             hipLaunchKernelGGL(kp, dim3(ntiles), dim3(512), lds, 0, x, lw, lb, w, stats, y, part, rps_out, nullptr, hot); (void)hipDeviceSynchronize();
@@ -244,7 +268,9 @@ int main(int argc, char **argv) {
             for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kp, dim3(ntiles), dim3(512), lds, 0, x, lw, lb, w, stats, y, part, rps_out, nullptr, hot);
             (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 3;
             printf("%-64s %8.3f ms  %6.1f TFLOP/s (algorithmic)  %.3f  %s\n",
-                   mode == 0 ? "F(2,2): 5 blocks per output pair, 4 sub-steps per chunk" : (mode == 1 ? "plain: 6 blocks per output pair, 3 sub-steps per chunk" : "F(2,2), rows stored straight from the accumulators (no LDS staging)"),
+                   mode == 0 ? "F(2,2): 5 blocks per output pair, 4 sub-steps per chunk" : (mode == 1 ? "plain: 6 blocks per output pair, 3 sub-steps per chunk" : (mode == 2 ? "F(2,2), rows stored straight from the accumulators (no LDS staging)" :
+                    (mode == 3 ? "WHAT-IF F(4,2): 9/10 of F(2,2)'s MFMAs, nothing else" : (mode == 4 ? "WHAT-IF F(4,2): 9/10 MFMAs + transform arithmetic" :
+                     (mode == 5 ? "WHAT-IF F(4,2): 9/10 MFMAs + 8 more live registers" : "WHAT-IF F(4,2): 9/10 MFMAs + transform + 8 registers"))))),
                    ms, flop / ms / 1e9, flop / ms / 1e9 / 157.3, hipGetErrorString(hipGetLastError()));
         }
     // per-tile phase stamps (shader clock cycles; two workgroups resident per CU)
