@@ -240,6 +240,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        # host-side waits that may last a minute (the CLI leg runs on rank 0 only) go through a gloo group: an RCCL
+        # barrier would spin a kernel on the other ranks' GPUs for as long
+        meta_group = dist.new_group(backend="gloo") if backend != "gloo" else None
         seen = [None] * world
         dist.all_gather_object(seen, (rank, torch.cuda.current_device() if have_gpu else -1))
         ranks_info = {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(),
@@ -531,7 +534,7 @@ def main():
     if world > 1 and args.scaling == "strong" and emu <= 1 and Q // 8 >= 1:
         # the weak-scaling side figure: every rank brings Q/8 queries of its own (512 at the default 4096): equals the
         # headline job at N = 8 and is 1/8 ... 1/2 of it below
-        per = min(Q // 8, my_q[1] - my_q[0])
+        per = min(Q // 8, Q // world)            # (every rank synthesised at least Q // world queries)
         sw = make_workload([per] * world)
         step(True, sw)
         fence()
@@ -732,6 +735,16 @@ def main():
     if roofline is not None:
         try:
             tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
+            meta = tj.pop("_meta", {})
+            import glob
+            import hashlib
+            hh = hashlib.sha256()
+            for f in sorted(glob.glob(os.path.join(REPO, "pfann_amd", "csrc", "*.hip")) + glob.glob(os.path.join(REPO, "pfann_amd", "csrc", "*.h"))):
+                hh.update(open(f, "rb").read())
+            # NOT measured in this run (hardware counters need the rocprofv3 wrapper): a committed observation
+            roofline["traffic_from_committed_profile"] = True
+            roofline["traffic_profile"] = dict(meta, kernels_unchanged_since_profile=(meta.get("csrc_sha16") == hh.hexdigest()[:16])
+                                               if meta.get("csrc_sha16") else None)
             key = ROOF[dom][0].split("<")[0].split(" ")[0]
             tmpl = ROOF[dom][0].split(" ")[0].replace(",...>", "").replace(",", ", ")
             if "tag:" + dom in tj:
@@ -865,7 +878,7 @@ def main():
             cli = {"error": repr(x)[:500]}
 
     if in_group and not args.no_cli:
-        dist.barrier()                       # (the CLI leg ran on rank 0)
+        dist.barrier(group=meta_group)       # (the CLI leg ran on rank 0)
     if rank == 0 and args.dump_decisions:
         np.save(args.dump_decisions, np.stack([res["song"].astype(np.float64), res["offset"].astype(np.float64),
                                                res["score"].astype(np.float64)], 1))

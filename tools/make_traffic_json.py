@@ -55,6 +55,21 @@ def main(d):
             "hbm_bytes_per_launch": sum(r["hbm_bytes_per_launch"] * r["dispatches"] for r in rs) / nd,
             "correction": "FETCH_SIZE x2 (gfx950, 16 B/lane loads), WRITE_SIZE x1; launch-weighted over "
                           "conv_gemm_ln_w22_kernel<*> and conv_gemm_ln_kernel<128,*>"}
+    # which build the counters were collected on: bench.py copies this next to roofline.traffic, so that the line says
+    # the figure is a committed observation of THAT commit, not a measurement of the run that prints it
+    import hashlib
+    import subprocess
+    try:
+        head = subprocess.check_output(["git", "rev-parse", "HEAD"], text=True).strip()
+        dirty = bool(subprocess.check_output(["git", "status", "--porcelain", "--", "pfann_amd", "bench.py"], text=True).strip())
+    except (OSError, subprocess.CalledProcessError):
+        head, dirty = None, None
+    src = hashlib.sha256()
+    import glob
+    for f in sorted(glob.glob("pfann_amd/csrc/*.hip") + glob.glob("pfann_amd/csrc/*.h")):
+        src.update(open(f, "rb").read())
+    res["_meta"] = {"profiled_commit": head, "tree_dirty_when_written": dirty, "csrc_sha16": src.hexdigest()[:16], "profile_dir": d,
+                    "command": "tools/profile_bench.sh (rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, separate passes)"}
     json.dump(res, open("profiles/traffic.json", "w"), indent=1, sort_keys=True)
     print(json.dumps(res, indent=1)[:1500])
 
