@@ -29,6 +29,9 @@ def test_bench_json_contract_small():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+    mp = cb["multi_process"]
+    assert mp["value"] > 0 and mp["queries"] == 16 and mp["identical_song_and_offset_vs_gpu"] == "16/16", mp
+    assert cb["value"] == max(mp["value"], cb["single_process"]["value"]) and cb["cores"] in (mp["cores"], cb["single_process"]["cores"])
     par = out["oracle_decision_parity"]
     assert par["identical_song_and_offset"] == par["queries"]
     assert out["top1_hit_rate"] > 0.5

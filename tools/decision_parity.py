@@ -8,11 +8,10 @@ from the oracle's own numbers:
                     (5e-6 fingerprint differences move which of two equal-scoring rows is the k-th)
     alignment tie : same candidates, and the two decisions' sequence scores lie within 1e-6 of each other in the oracle
     bug           : anything else
-The oracle runs in W worker PROCESSES (each 8 torch threads; the oracle anti-scales beyond that), fed through .npy files
-in a tmpfs directory; nothing under oracle/ is imported by the product.
+The oracle runs in W worker PROCESSES (tools/oracle_pool.py: each 8 torch threads; the oracle anti-scales beyond that), fed
+through .npy files in a tmpfs directory; nothing under oracle/ is imported by the product.
 
     python tools/decision_parity.py --songs 10000 --queries 2000 --snr 0 [--workers 16] [--out profiles/r4/x.json]
-    python tools/decision_parity.py --worker <dir> <w> <W>        (internal)
 """
 import argparse
 import json
@@ -26,42 +25,10 @@ import time
 import numpy as np
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-if REPO not in sys.path:
-    sys.path.insert(0, REPO)
+for _p in (REPO, os.path.join(REPO, "tools")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
 SEG, QSEG, HOP = 59, 19, 4000
-
-
-def worker(work, w, W):
-    import torch
-    torch.set_num_threads(int(os.environ.get("PFANN_ORACLE_THREADS", "8")))
-    from oracle import encoder as oe
-    from oracle import melspec as om
-    from oracle import search as osr
-    from oracle import segmenter as osg
-    from oracle import seqscore as osq
-    meta = json.load(open(os.path.join(work, "meta.json")))
-    params, k = meta["params"], meta["k"]
-    sd = dict(np.load(os.path.join(work, "weights.npz")))
-    db = np.load(os.path.join(work, "db.npy"), mmap_mode="r")
-    db = np.ascontiguousarray(db)
-    song_pos = np.load(os.path.join(work, "song_pos.npy"))
-    pcm = np.load(os.path.join(work, "q_pcm.npy"), mmap_mode="r")
-    emb_gpu = np.load(os.path.join(work, "q_emb_gpu.npy"), mmap_mode="r")
-    js = list(range(w, pcm.shape[0], W))
-    out = {"j": [], "song": [], "sec": [], "score": [], "emb_err": [], "kth": [], "next": [], "runner_up": [], "labels": []}
-    for j in js:
-        segs = osg.segment(osg.pcm_to_mono(np.asarray(pcm[j])[:, None]), 8000, HOP)
-        e = oe.encode(om.melspec(segs, params), sd, params)
-        out["emb_err"].append(float(np.abs(e - emb_gpu[j * QSEG:(j + 1) * QSEG]).max()))
-        D, I = osr.flat_ip_topk_blas(e, db, k + 1)
-        sc, (song, sec), ss = osq.query_embeddings_base(e, I[:, :k], db, song_pos, meta["hop_s"], 1)
-        two = np.sort(ss[:, 0])[-2:]                       # best per-song scores: winner and the runner-up SONG
-        out["j"].append(j), out["song"].append(song), out["sec"].append(sec), out["score"].append(sc)
-        out["kth"].append(D[:, k - 1].copy()), out["next"].append(D[:, k].copy()), out["runner_up"].append(float(two[0]))
-        out["labels"].append(I[:, :k].copy())
-    np.savez(os.path.join(work, "res_%d.npz" % w), j=np.asarray(out["j"]), song=np.asarray(out["song"]), sec=np.asarray(out["sec"]),
-             score=np.asarray(out["score"]), emb_err=np.asarray(out["emb_err"]), kth=np.asarray(out["kth"]),
-             next=np.asarray(out["next"]), runner_up=np.asarray(out["runner_up"]), labels=np.asarray(out["labels"]))
 
 
 def run(n_songs, n_queries, snr, workers=16, config="default", plan=9728, max_batch=9728, log=print, keep=False):
@@ -122,33 +89,12 @@ def run(n_songs, n_queries, snr, workers=16, config="default", plan=9728, max_ba
     t_gpu = time.time() - t0
     log("decision_parity: GPU side (db %d rows + %d queries) %.1f s" % (n_songs * SEG, n_queries, t_gpu))
 
-    base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
-    work = tempfile.mkdtemp(prefix="pfann_parity_", dir=base)
-    try:
-        np.save(os.path.join(work, "db.npy"), shard.cpu().numpy())
-        np.save(os.path.join(work, "song_pos.npy"), song_pos)
-        np.save(os.path.join(work, "q_pcm.npy"), q_pcm.cpu().numpy())
-        np.save(os.path.join(work, "q_emb_gpu.npy"), emb_gpu)
-        np.savez(os.path.join(work, "weights.npz"), **{n: np.asarray(v) for n, v in sd.items()})
-        json.dump({"params": params, "k": k, "hop_s": params["hop_size"]}, open(os.path.join(work, "meta.json"), "w"))
-        t1 = time.time()
-        env = dict(os.environ, PYTHONPATH=REPO, OMP_NUM_THREADS=os.environ.get("PFANN_ORACLE_THREADS", "8"))
-        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", work, str(w), str(workers)], env=env)
-                 for w in range(workers)]
-        rcs = [p.wait() for p in procs]
-        if any(rcs):
-            raise RuntimeError("oracle workers failed: %r" % rcs)
-        t_cpu = time.time() - t1
-        parts = [np.load(os.path.join(work, "res_%d.npz" % w)) for w in range(workers)]
-    finally:
-        if not keep:
-            shutil.rmtree(work, ignore_errors=True)
-    order = np.argsort(np.concatenate([p["j"] for p in parts]))
-
-    def col(name):
-        return np.concatenate([p[name] for p in parts])[order]
-    o_song, o_sec, o_score, emb_err = col("song"), col("sec"), col("score"), col("emb_err")
-    kth, nxt, runner, o_lab = col("kth"), col("next"), col("runner_up"), col("labels")
+    import oracle_pool
+    pool = oracle_pool.run(params, sd, shard.cpu().numpy(), song_pos, q_pcm.cpu().numpy(), k, workers=workers, q_emb_gpu=emb_gpu,
+                           keep=keep)
+    t_cpu = pool["wall_s"]
+    o_song, o_sec, o_score, emb_err = pool["song"], pool["sec"], pool["score"], pool["emb_err"]
+    kth, nxt, runner, o_lab = pool["kth"], pool["next"], pool["runner_up"], pool["labels"]
     log("decision_parity: oracle side %.1f s on %d processes" % (t_cpu, workers))
     g_song, g_sec, g_score = res["song"].astype(np.int64), res["offset"] * params["hop_size"], res["score"]
     same = (g_song == o_song) & (g_sec == o_sec)
@@ -187,9 +133,6 @@ def run(n_songs, n_queries, snr, workers=16, config="default", plan=9728, max_ba
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "--worker":
-        worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
-        sys.exit(0)
     ap = argparse.ArgumentParser()
     ap.add_argument("--songs", type=int, default=10000)
     ap.add_argument("--queries", type=int, default=2000)
