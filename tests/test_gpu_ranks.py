@@ -221,3 +221,75 @@ for song in (1, 298, 300, 599):                      # songs of both shards, nex
 print("DB_RANK_OK")
 finish_ranks(ranks)
 '''
+
+
+def test_edge_lists_and_variants_under_two_ranks(tmp_path):
+    """Lists the round cutting must not trip over -- empty, one file, fewer files than ranks, nothing but unreadable
+    files -- and the matcher variants (fp16-only storage + frame_shift_mul = 2, tiny d = 16 model) under 2 ranks: every
+    output byte-identical to the single-process run; a one-song database built by 2 ranks likewise."""
+    tmp = str(tmp_path)
+
+    def patch(p):
+        p["indexer"].update(frame_shift_mul=2, use_float16=True)
+    mdir, params = _model_dir(tmp, "tiny", 9, patch=patch)
+    music = []
+    for s in range(5):
+        path = os.path.join(tmp, "m%d.wav" % s)
+        synth.write_wav(path, synth.make_song(500 + s, seconds=7.0 + 2 * s))
+        music.append(path)
+    lists = {"all": music, "one": music[:1]}
+    for name, files in lists.items():
+        open(os.path.join(tmp, name + ".txt"), "w").write("".join(p + "\n" for p in files))
+    dbs = {}
+    for name in lists:
+        for tag, env in (("a", _env()), ("b", _two_ranks())):
+            dbs[name + tag] = os.path.join(tmp, "db_" + name + tag)
+            _run(_tool("builder.py") + [os.path.join(tmp, name + ".txt"), dbs[name + tag], mdir], tmp, env)
+        _db_files_equal(dbs[name + "a"], dbs[name + "b"])
+    qs = []
+    for j in range(7):
+        q, _ = synth.make_query(synth.make_song(500 + j % 5, seconds=7.0 + 2 * (j % 5)), 60 + j, 3.0 + j % 3, snr_db=12.0)
+        path = os.path.join(tmp, "q%d.wav" % j)
+        synth.write_wav(path, q)
+        qs.append(path)
+    cases = {"empty": [], "single": qs[:1], "missing_only": [os.path.join(tmp, "no1.wav"), os.path.join(tmp, "no2.wav")],
+             "seven": qs[:3] + [os.path.join(tmp, "no3.wav")] + qs[3:]}
+    for name, files in cases.items():
+        ql = os.path.join(tmp, "ql_%s.txt" % name)
+        open(ql, "w").write("".join(p + "\n" for p in files))
+        r1, r2 = os.path.join(tmp, "r1_%s.txt" % name), os.path.join(tmp, "r2_%s.txt" % name)
+        _run(_tool("matcher.py") + [ql, dbs["alla"], r1], tmp, _env())
+        _run(_tool("matcher.py") + [ql, dbs["alla"], r2], tmp, _two_ranks())
+        _results_equal(r1, r2)
+        assert os.path.getsize(r1 + ".bin") == len(files) * 5 * 8
+        assert len(open(r1).read().splitlines()) == len(files)
+    rows = [ln.rstrip("\n").split("\t")[1] for ln in open(os.path.join(tmp, "r2_seven.txt"))]
+    assert rows[3] == "error" and sum(1 for j, a in enumerate(rows) if a in music) == 7
+    # the one-song database (its single song lives on one rank, the other shard is empty)
+    r1, r2 = os.path.join(tmp, "o1.txt"), os.path.join(tmp, "o2.txt")
+    ql = os.path.join(tmp, "ql_seven.txt")
+    _run(_tool("matcher.py") + [ql, dbs["onea"], r1], tmp, _env())
+    _run(_tool("matcher.py") + [ql, dbs["onea"], r2], tmp, _two_ranks())
+    _results_equal(r1, r2)
+
+
+def test_eight_ranks_on_one_gpu_byte_identical(tmp_path):
+    """World size 8 -- BASELINE config 4's "sharded 8 ways" -- as far as a one-GPU box allows: eight ranks of builder.py
+    and matcher.py share this GPU (gloo-staged collectives, PFANN_MAX_BATCH=2048 so that eight workspaces fit), which
+    exercises rounds of eight launch groups, the equal-share tail, eight-way song shards, the all-to-all / merge / key
+    pick with G = 8 and eight writers of one `.bin` -- against the single-process files, byte for byte."""
+    tmp = str(tmp_path)
+    mdir, params = _model_dir(tmp, "default", 123, patch=lambda p: p["indexer"].update(index_factory="Flat"))
+    mlist, qlist, music, q_song = _write_set(tmp, 300, 120, bad_songs=(150,), bad_queries=(60,))
+    common = dict(PFANN_MAX_BATCH="2048")
+    eight = _env(PFANN_GPUS="8", PFANN_DIST_BACKEND="gloo", PFANN_FORCE_DEVICE="0", **common)
+    db1, db8 = os.path.join(tmp, "db1"), os.path.join(tmp, "db8")
+    _run(_tool("builder.py") + [mlist, db1, mdir], tmp, _env(**common))
+    _run(_tool("builder.py") + [mlist, db8, mdir], tmp, eight, timeout=1500)
+    _db_files_equal(db1, db8)
+    r1, r8 = os.path.join(tmp, "r1.txt"), os.path.join(tmp, "r8.txt")
+    _run(_tool("matcher.py") + [qlist, db1, r1], tmp, _env(**common))
+    _run(_tool("matcher.py") + [qlist, db8, r8], tmp, eight, timeout=1500)
+    _results_equal(r1, r8)
+    rows = [ln.rstrip("\n").split("\t") for ln in open(r8)]
+    assert rows[60][1] == "error" and sum(1 for j, (_, a) in enumerate(rows) if a == music[q_song[j]]) >= 100
