@@ -272,13 +272,16 @@ def main():
     in_group = "WORLD_SIZE" in os.environ            # also at world 1 under a launcher: the RCCL calls then really run
     ranks_info = {"ranks_seen": 1, "backend": None, "devices": [local_rank if have_gpu else -1]}
     if in_group:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-        # host-side waits that may last a minute (the CLI leg runs on rank 0 only) go through a gloo group: an RCCL
-        # barrier would spin a kernel on the other ranks' GPUs for as long
-        meta_group = dist.new_group(backend="gloo") if backend != "gloo" else None
+        from pfann_amd.dist import quiet_stdout
+        with quiet_stdout():                 # gloo announces its connections on stdout; stdout is the ONE JSON line
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
+            # host-side waits that may last a minute (the CLI leg runs on rank 0 only) go through a gloo group: an RCCL
+            # barrier would spin a kernel on the other ranks' GPUs for as long
+            meta_group = dist.new_group(backend="gloo") if backend != "gloo" else None
+            dist.barrier(group=meta_group)   # (gloo connects lazily: make it talk now)
         seen = [None] * world
         dist.all_gather_object(seen, (rank, torch.cuda.current_device() if have_gpu else -1))
         ranks_info = {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(),

@@ -53,6 +53,21 @@ class Ranks:
         return float(t.item())
 
 
+class quiet_stdout:
+    """File descriptor 1 points at stderr inside the block: gloo announces every connection on stdout ("[Gloo] Rank 0 is
+    connected to 7 peer ranks ..."), and the tools' / bench.py's stdout is a contract (stage lines, ONE JSON line)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *a):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def self_launch_if_asked(argv):
     """`PFANN_GPUS=N python matcher.py ...` (N > 1, or "all") without a launcher: start N ranks of this very command,
     one per GPU, through torch.distributed.run on 127.0.0.1, and return their exit status; None when there is nothing
@@ -94,12 +109,14 @@ def init_ranks():
                                (os.environ.get("RANK"), local, torch.cuda.device_count()))
         torch.cuda.set_device(local)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if not dist.is_initialized():
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
-    meta = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else None
+    with quiet_stdout():
+        if not dist.is_initialized():
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            else:
+                dist.init_process_group(backend)
+        meta = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else None
+        dist.barrier(group=meta)                   # (gloo connects lazily: make it talk now)
     r = Ranks(dist.get_rank(), dist.get_world_size(), local, dist.get_backend(), meta,
               force_sharded=os.environ.get("PFANN_FORCE_SHARDED", "0") != "0")
     if backend == "nccl" and r.world > 1:

@@ -27,6 +27,8 @@ def test_plain_invocation_spawns_the_ranks_it_was_asked_for():
     out = _json(r)
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["backend"] == "gloo"
     assert len(out["devices"]) == 2 and out["all_reduce_of_ones"] == 2
+    # stdout is the JSON line and NOTHING else: gloo's "[Gloo] Rank 0 is connected to ..." chatter goes to stderr
+    assert [ln for ln in r.stdout.splitlines() if ln.strip()] == [ln for ln in r.stdout.splitlines() if ln.startswith("{")], r.stdout
 
 
 def test_world_size_mismatch_is_fatal():
