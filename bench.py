@@ -129,7 +129,9 @@ def cpu_baseline_leg(args, params, sd, shard, song_pos, q_pcm_mine, res, k, n_ro
     if n_pool > 0:
         sys.path.insert(0, os.path.join(REPO, "tools"))
         import oracle_pool
-        procs = max(1, min(32, ncpu // 8, n_pool))
+        # 8 processes: measured on this pool's 256-thread hosts with 192 queries (profiles/r4/NOTES.md): 8 / 16 / 24 / 32
+        # processes x 8 threads = 300 / 279 / 239 / 214 segments/s -- the host saturates at about 64 busy threads
+        procs = max(1, min(int(os.environ.get("PFANN_CPU_POOL_PROCS", "8")), ncpu // 8, n_pool))
         try:
             pool = oracle_pool.run(params, sd, db_host, song_pos, q_pcm_mine[:n_pool].cpu().numpy(), k, workers=procs)
             same = int(np.sum((pool["song"] == res["song"][:n_pool]) & (pool["sec"] == res["offset"][:n_pool] * 0.5)))
