@@ -255,6 +255,19 @@ int pfann_search_topk_bounded(pfann_db *db, const float *q_dev, int64_t nq, int 
 int pfann_topk_merge(pfann_db *db, const float *S_dev, const int64_t *L_dev, int64_t nq, int m,
                      int k, float *D_dev, int64_t *I_dev, void *stream);
 
+/* The two reductions of the sharded search in the layouts the collectives deliver, one wavefront per query row:
+ *   pfann_bound_reduce     : cands_dev[n_ranks][nq][m] (the all-gathered pfann_search_bound outputs) -> lb_dev[nq], the k-th
+ *                            largest of each row's n_ranks * m values (-inf entries are absent; fewer than k present:
+ *                            -FLT_MAX) -- what pfann_search_topk_bounded wants.  n_ranks * m <= 1024.
+ *   pfann_topk_merge_lists : D_lists_dev / I_lists_dev[n_lists][nq][k] (every shard's list for these query rows, as the
+ *                            all-to-all delivers them; label < 0 = padding) -> the exact top-k of the union, ordered like
+ *                            pfann_topk_merge over the shard-major concatenation (ties: lower list first, then list order).
+ *                            k <= 128, n_lists * k <= 1024. */
+int pfann_bound_reduce(pfann_db *db, const float *cands_dev, int n_ranks, int64_t nq, int m, int k, float *lb_dev,
+                       void *stream);
+int pfann_topk_merge_lists(pfann_db *db, const float *D_lists_dev, const int64_t *I_lists_dev, int n_lists, int64_t nq,
+                           int k, float *D_dev, int64_t *I_dev, void *stream);
+
 /* Result of the sequence matcher for one query. */
 typedef struct pfann_match_result {
     int32_t song;        /* best song id (global), -1 if no candidate                     */

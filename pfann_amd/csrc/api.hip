@@ -795,6 +795,17 @@ int pfann_topk_merge(pfann_db *db, const float *S, const int64_t *L, int64_t nq,
     return topk_merge(S, L, nq, m, k, D, I, (hipStream_t)stream);
 }
 
+int pfann_bound_reduce(pfann_db *db, const float *cands_dev, int n_ranks, int64_t nq, int m, int k, float *lb_dev, void *stream) {
+    PF_HIP(hipSetDevice(db->device));
+    return bound_reduce(cands_dev, n_ranks, nq, m, k, lb_dev, (hipStream_t)stream);
+}
+
+int pfann_topk_merge_lists(pfann_db *db, const float *D_lists_dev, const int64_t *I_lists_dev, int n_lists, int64_t nq, int k,
+                           float *D_dev, int64_t *I_dev, void *stream) {
+    PF_HIP(hipSetDevice(db->device));
+    return merge_lists(D_lists_dev, I_lists_dev, n_lists, nq, k, D_dev, I_dev, (hipStream_t)stream);
+}
+
 int pfann_match(pfann_db *db, const float *q, const int64_t *labels, int k, const int64_t *qstart,
                 const int32_t *qlen, int64_t nQ, int max_qlen, int frame_shift_mul, float score_alpha, int mode,
                 int only_owned, pfann_match_result *results, float *song_scores, void *stream) {

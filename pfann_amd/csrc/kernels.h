@@ -96,6 +96,9 @@ int search_topk(const float *db, const void *dbh, float xnorm_max, int64_t n, in
                 int phase = 0, float *lb = nullptr, int mtop = 1);
 int topk_merge(const float *S, const int64_t *L, int64_t nq, int m, int k, float *D, int64_t *I,
                hipStream_t s);
+// one wavefront per query row (search.hip): k-th largest of the gathered bound candidates; merge of G sorted shard lists
+int bound_reduce(const float *cands, int G, int64_t nq, int m, int k, float *lb, hipStream_t s);
+int merge_lists(const float *Dl, const int64_t *Il, int G, int64_t nq, int k, float *D, int64_t *I, hipStream_t s);
 
 // ---- rerank.hip ----------------------------------------------------------------------
 struct RerankArgs {

@@ -434,28 +434,37 @@ __global__ __launch_bounds__(256) void group_max_select_kernel(const float *__re
                                                                int *zero_me) {
     constexpr int GMAX = 4096;
     __shared__ unsigned sv[GMAX];
-    __shared__ int hist[256];
-    __shared__ int s_bin, s_kk, s_n;
+    __shared__ int s_n;
     const int64_t m = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (zero_me != nullptr && m == 0 && tid == 0) *zero_me = 0;      // the select's overflow counter (one memset less)
     for (int i = tid; i < ncnt; i += 256) cnt[m * ncnt + i] = 0;
     for (int i = tid; i < G; i += 256) sv[i] = ~f2ord(gmax[m * G + i]);          // ascending = descending score
     __syncthreads();
-    // key of the kk-th smallest entry of sv (= kk-th best score): MSB radix select, 4 x 8 bits
-    auto kth = [&](int kk) -> unsigned {
-        unsigned prefix = 0;
+    // keys of the kA-th and the kB-th smallest entry of sv (= kA-th / kB-th best score) in ONE sweep: MSB radix select,
+    // 4 x 8 bits, two histograms per pass (wave 0 resolves rank A, wave 1 rank B).  kB <= 0: only A.  Phase 1 of a
+    // sharded search needs both the row's k-th best group maximum and its mtop-th: two separate selects cost the kernel
+    // twice (0.85 vs 0.47 ms per 77,824 rows).
+    __shared__ int hist2[2][256];
+    __shared__ int s_bin2[2], s_kk2[2];
+    auto kth2 = [&](int kA, int kB, unsigned &outA, unsigned &outB) {
+        unsigned pA = 0, pB = 0;
+        const bool two = kB > 0;
         for (int pass = 0; pass < 4; ++pass) {
             const int shift = 24 - 8 * pass;
-            hist[tid] = 0;
+            hist2[0][tid] = 0;
+            hist2[1][tid] = 0;
             __syncthreads();
             for (int i = tid; i < G; i += 256) {
                 const unsigned hi = sv[i];
-                if (pass == 0 || (hi >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(hi >> shift) & 255], 1);
+                if (pass == 0 || (hi >> (shift + 8)) == (pA >> (shift + 8))) atomicAdd(&hist2[0][(hi >> shift) & 255], 1);
+                if (two && (pass == 0 || (hi >> (shift + 8)) == (pB >> (shift + 8)))) atomicAdd(&hist2[1][(hi >> shift) & 255], 1);
             }
             __syncthreads();
-            if (wave == 0) {
-                const int c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+            if (wave < (two ? 2 : 1)) {
+                const int *h = hist2[wave];
+                const int kk = wave == 0 ? kA : kB;
+                const int c0 = h[4 * lane], c1 = h[4 * lane + 1], c2 = h[4 * lane + 2], c3 = h[4 * lane + 3];
                 const int sum4 = c0 + c1 + c2 + c3;
                 int incl = sum4;
 #pragma unroll
@@ -467,24 +476,28 @@ __global__ __launch_bounds__(256) void group_max_select_kernel(const float *__re
                 if (excl < kk && kk <= incl) {          // exactly one lane
                     int rem = kk - excl, bin = 4 * lane;
                     if (rem > c0) { rem -= c0; ++bin; if (rem > c1) { rem -= c1; ++bin; if (rem > c2) { rem -= c2; ++bin; } } }
-                    s_bin = bin;
-                    s_kk = rem;
+                    s_bin2[wave] = bin;
+                    s_kk2[wave] = rem;
                 }
             }
             __syncthreads();
-            prefix |= (unsigned)s_bin << shift;
-            kk = s_kk;
+            pA |= (unsigned)s_bin2[0] << shift;
+            kA = s_kk2[0];
+            if (two) { pB |= (unsigned)s_bin2[1] << shift; kB = s_kk2[1]; }
         }
-        return prefix;
+        outA = pA;
+        outB = pB;
     };
     // topm[m][0..mtop): the mtop best group maxima minus margin_out * eps -- each the score of a DIFFERENT real row of
     // this shard, lowered to a bound of its true score -- for the cross-shard bound (search_topk phase 1); -inf padded
+    const int mm = topm != nullptr ? (mtop < G ? mtop : G) : 0;
+    unsigned prefix = 0, tm = 0;
+    if (G >= k) kth2(k, mm, prefix, tm);
+    else if (mm > 0) kth2(mm, 0, tm, prefix);
     if (topm != nullptr) {
         const float e = eps != nullptr ? margin_out * eps[m] : 0.f;
-        const int mm = mtop < G ? mtop : G;
         for (int i = mm + tid; i < mtop; i += 256) topm[m * mtop + i] = -INFINITY;
         if (mm > 0) {
-            const unsigned tm = kth(mm);
             if (tid == 0) s_n = 0;
             __syncthreads();
             for (int i = tid; i < G; i += 256)
@@ -498,7 +511,6 @@ __global__ __launch_bounds__(256) void group_max_select_kernel(const float *__re
         if (tid == 0) { thr[m] = -INFINITY; if (eps != nullptr) thr_adj[m] = -1000.f * eps[m]; }
         return;
     }
-    const unsigned prefix = kth(k);
     if (tid == 0) {
         const float t = ord2f(~prefix);
         thr[m] = t;
@@ -930,6 +942,141 @@ int topk_merge(const float *S, const int64_t *L, int64_t nq, int m, int k, float
     if (ensure_dyn_lds((const void *)merge_kernel, 16384 * 8)) return -1;
     ProfScope ps("topk_merge", s);
     PF_LAUNCH(merge_kernel, dim3((unsigned)nq), dim3(1024), (size_t)P * 8, s, S, L, m, k, D, I);
+    PF_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// The sharded search's two small reductions, one WAVEFRONT per query row (round 4).  Both used to go through merge_kernel
+// -- a 1024-thread workgroup and a full bitonic sort in LDS per row -- and were, at 8 shards, the second largest item of
+// a rank's scan time (2.1 of 7.4 ms per 77,824-row step: tools/ubench/sharded_scan_model.py).
+//   bound_reduce_kernel : cands[G][nq][m] (the all-gathered pfann_search_bound outputs, as gathered: no transposed copy)
+//                         -> lb[nq] = the k-th largest of the row's G*m values (-inf entries are absent); fewer than k
+//                         present: -FLT_MAX.  A selection, not a sort: MSB-first bisection on the orderable bit patterns,
+//                         one ballot + popcount per value and bit.
+//   merge_lists_kernel  : Dl/Il[G][nq][k] (every shard's list for this rank's query slice, as the all-to-all delivers
+//                         them) -> the exact top-k of the union, sorted by (score descending, shard-major position
+//                         ascending) exactly like merge_kernel: k-th smallest packed key by bisection, ballot compaction
+//                         of the k winners into LDS, rank sort (k <= 128: every lane counts the keys below its two).
+// Rows of at most 64 * 16 = 1024 values; larger unions keep merge_kernel.
+// ------------------------------------------------------------------------------------
+constexpr int WPR_VPL = 16;       // values per lane
+
+template <int VPL>
+__global__ __launch_bounds__(256) void bound_reduce_kernel(const float *__restrict__ cands, int G, int64_t nq, int m, int k,
+                                                           float *__restrict__ lb) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nq) return;
+    const int n = G * m;
+    unsigned key[VPL];
+    int present = 0;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int i = lane + 64 * j;
+        key[j] = 0u;                                            // absent: below every real value (f2ord(x) > 0 for finite x)
+        if (i < n) {
+            const int g = i / m, c = i - g * m;
+            const float v = cands[((int64_t)g * nq + row) * m + c];
+            if (v > -3.0e38f) { key[j] = f2ord(v); ++present; }   // -inf / -FLT_MAX padding = absent
+        }
+    }
+    int total = 0;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) total += __popcll(__ballot(key[j] != 0u));
+    (void)present;
+    if (total < k) { if (lane == 0) lb[row] = -3.4028234663852886e38f; return; }
+    unsigned prefix = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned cand = prefix | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) c += __popcll(__ballot(key[j] >= cand));
+        if (c >= k) prefix = cand;                               // at least k values reach cand: the k-th largest does too
+    }
+    if (lane == 0) lb[row] = ord2f(prefix);
+}
+
+__global__ __launch_bounds__(256) void merge_lists_kernel(const float *__restrict__ Dl, const int64_t *__restrict__ Il, int G,
+                                                          int64_t nq, int k, float *__restrict__ D, int64_t *__restrict__ I) {
+    __shared__ unsigned long long win[4][128];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + w;
+    if (row >= nq) return;
+    const int n = G * k;
+    unsigned long long key[WPR_VPL];
+    int nvalid = 0;
+#pragma unroll
+    for (int j = 0; j < WPR_VPL; ++j) {
+        const int i = lane + 64 * j;
+        key[j] = ~0ull;
+        if (i < n) {
+            const int g = i / k, c = i - g * k;
+            const int64_t at = ((int64_t)g * nq + row) * k + c;
+            if (Il[at] >= 0) key[j] = pack_key(Dl[at], (unsigned)i);   // i = shard-major position: ascending labels on ties
+        }
+        nvalid += __popcll(__ballot(key[j] != ~0ull));
+    }
+    const int kk = nvalid < k ? nvalid : k;
+    // the kk-th smallest key (keys of valid entries are unique: the position is part of them)
+    unsigned long long prefix = 0ull;
+    if (kk > 0) {
+        // largest P with count(key < P) < kk  <=>  P is the kk-th smallest: build P bit by bit
+        for (int bit = 63; bit >= 0; --bit) {
+            const unsigned long long cand = prefix | (1ull << bit);
+            int c = 0;
+#pragma unroll
+            for (int j = 0; j < WPR_VPL; ++j) c += __popcll(__ballot(key[j] < cand));
+            if (c < kk) prefix = cand;
+        }
+    }
+    // winners (key <= prefix) -> LDS, in any order
+    int base = 0;
+#pragma unroll
+    for (int j = 0; j < WPR_VPL; ++j) {
+        const bool take = kk > 0 && key[j] <= prefix && key[j] != ~0ull;
+        const unsigned long long mask = __ballot(take);
+        if (take) win[w][base + __popcll(mask & ((1ull << lane) - 1ull))] = key[j];
+        base += __popcll(mask);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // one wave: its LDS writes are visible to its own lanes
+    // rank sort of the kk winners: lane owns winners lane and lane + 64
+    for (int e = lane; e < k; e += 64) {
+        float dv = -3.4028234663852886e38f;
+        int64_t iv = -1;
+        int pos = e;
+        if (e < kk) {
+            const unsigned long long me = win[w][e];
+            int r = 0;
+            for (int o = 0; o < kk; ++o) r += win[w][o] < me ? 1 : 0;
+            const unsigned i = (unsigned)(me & 0xFFFFFFFFull);
+            const int g = (int)i / k, c = (int)i - g * k;
+            dv = ord2f(~(unsigned)(me >> 32));
+            iv = Il[((int64_t)g * nq + row) * k + c];
+            pos = r;
+        }
+        D[row * k + pos] = dv;
+        I[row * k + pos] = iv;
+    }
+}
+
+int bound_reduce(const float *cands, int G, int64_t nq, int m, int k, float *lb, hipStream_t s) {
+    if (nq <= 0) return 0;
+    if (G < 1 || m < 1 || (int64_t)G * m > 64 * WPR_VPL) { set_error("bound_reduce: %d x %d values per row > %d", G, m, 64 * WPR_VPL); return -1; }
+    ProfScope ps("topk_bound_reduce", s);
+    const int n = G * m;                      // values per lane: 5 covers dist.py's G * (2k/G + 8) at k = 100 up to G = 8
+    if (n <= 64 * 5) PF_LAUNCH(bound_reduce_kernel<5>, dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, s, cands, G, nq, m, k, lb);
+    else if (n <= 64 * 8) PF_LAUNCH(bound_reduce_kernel<8>, dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, s, cands, G, nq, m, k, lb);
+    else PF_LAUNCH(bound_reduce_kernel<WPR_VPL>, dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, s, cands, G, nq, m, k, lb);
+    PF_HIP(hipGetLastError());
+    return 0;
+}
+
+int merge_lists(const float *Dl, const int64_t *Il, int G, int64_t nq, int k, float *D, int64_t *I, hipStream_t s) {
+    if (nq <= 0) return 0;
+    if (G < 1 || k < 1 || k > 128 || (int64_t)G * k > 64 * WPR_VPL) { set_error("merge_lists: %d lists of %d outside the wave kernel's range", G, k); return -1; }
+    ProfScope ps("topk_merge_lists", s);
+    PF_LAUNCH(merge_lists_kernel, dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, s, Dl, Il, G, nq, k, D, I);
     PF_HIP(hipGetLastError());
     return 0;
 }

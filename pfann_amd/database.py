@@ -106,6 +106,13 @@ class DeviceIndex:
         bound of the row's k-th best score over all shards (>= k different real rows reach it); -FLT_MAX when the union
         holds fewer than k finite values."""
         G, nq, m = cands.shape
+        if G * m <= 1024 and nq:
+            # one wavefront per row straight from the gathered layout (pfann_bound_reduce): a selection, not a sort
+            c = cands.to(self.device, torch.float32).contiguous()
+            lb = torch.empty((nq,), device=self.device, dtype=torch.float32)
+            _l.check(self.lib.pfann_bound_reduce(self.handle, c.data_ptr(), G, nq, m, k, lb.data_ptr(), self._stream()),
+                     "pfann_bound_reduce")
+            return lb
         vals = cands.to(self.device).permute(1, 0, 2).reshape(nq, G * m).contiguous()
         if G * m < k:
             return torch.full((nq,), -3.4028234663852886e38, device=self.device, dtype=torch.float32)
@@ -125,6 +132,22 @@ class DeviceIndex:
                                                         D.data_ptr(), I.data_ptr(), self._stream()),
                      "pfann_search_topk_bounded")
         return D, I
+
+    def merge_lists(self, Dl, Il, k):
+        """Dl / Il [G, nq, k] (every shard's list for these query rows, as the all-to-all delivers them) -> exact top-k of
+        the union (D [nq, k] descending, I), ties to the lower shard: the merge of ShardedIndex.search_global."""
+        G, nq, kk = Dl.shape
+        if kk == k and k <= 128 and G * k <= 1024:
+            Dl, Il = Dl.to(self.device, torch.float32).contiguous(), Il.to(self.device, torch.int64).contiguous()
+            D = torch.empty((nq, k), device=self.device, dtype=torch.float32)
+            I = torch.empty((nq, k), device=self.device, dtype=torch.int64)
+            if nq:
+                _l.check(self.lib.pfann_topk_merge_lists(self.handle, Dl.data_ptr(), Il.data_ptr(), G, nq, k, D.data_ptr(),
+                                                         I.data_ptr(), self._stream()), "pfann_topk_merge_lists")
+            return D, I
+        S = Dl.permute(1, 0, 2).reshape(nq, G * kk).contiguous()            # shard-major: ascending labels on ties
+        L = Il.permute(1, 0, 2).reshape(nq, G * kk).contiguous()
+        return self.merge_topk(S, L, k)
 
     def merge_topk(self, S, L, k):
         nq, m = S.shape

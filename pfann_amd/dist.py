@@ -266,9 +266,12 @@ class ShardedIndex:
             I = torch.cat([I, torch.full((pad, k), -1, dtype=I.dtype, device=I.device)])
         rD = self._timed("all_to_all", all_to_all_rows, D.view(G, Qs, k), self.group)        # [source shard, my Qs queries, k]
         rI = self._timed("all_to_all", all_to_all_rows, I.view(G, Qs, k), self.group)
-        S = rD.permute(1, 0, 2).reshape(Qs, G * k)                # shard-major: ascending labels on ties
-        L = rI.permute(1, 0, 2).reshape(Qs, G * k)
-        Dm, Im = self._timed("merge", self.b.merge_topk, S.contiguous(), L.contiguous(), k)
+        if hasattr(self.b, "merge_lists"):                        # the lists as delivered, one wavefront per row
+            Dm, Im = self._timed("merge", self.b.merge_lists, rD, rI, k)
+        else:
+            S = rD.permute(1, 0, 2).reshape(Qs, G * k)            # shard-major: ascending labels on ties
+            L = rI.permute(1, 0, 2).reshape(Qs, G * k)
+            Dm, Im = self._timed("merge", self.b.merge_topk, S.contiguous(), L.contiguous(), k)
         gD = self._timed("slice_allgather", all_gather_rows, Dm, self.group).reshape(G * Qs, k)[:Q]
         gI = self._timed("slice_allgather", all_gather_rows, Im, self.group).reshape(G * Qs, k)[:Q]
         return gD.contiguous(), gI.contiguous()

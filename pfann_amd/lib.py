@@ -74,6 +74,8 @@ SYMBOLS = {
     "pfann_search_topk_bounded": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pfann_topk_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
                                  c_void_p]),
+    "pfann_bound_reduce": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "pfann_topk_merge_lists": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "pfann_match": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int,
                             c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pfann_db_owned_songs": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),

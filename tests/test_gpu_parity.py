@@ -987,3 +987,43 @@ def test_plan_batch_makes_fingerprints_independent_of_the_batch(cfgname):
     assert eng.set_plan_batch(0) == 0 and eng.set_plan_batch(5) == 65      # below 65 is raised: no small-batch variants
     # the pinned plan is still the same arithmetic to rounding
     assert float((eng.embed_windows(wav, starts[:19]) - full[:19]).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("G,m,k", [(2, 100, 100), (4, 58, 100), (8, 33, 100), (3, 7, 5), (8, 128, 128)])
+def test_sharded_search_wave_reductions_vs_the_sorting_kernel(G, m, k):
+    """pfann_bound_reduce / pfann_topk_merge_lists (one wavefront per query row, selection by bisection) against what they
+    replace: the k-th largest through torch, and pfann_topk_merge (full bitonic sort per row) over the shard-major
+    concatenation -- identical values, labels and ORDER, with ties inside and across lists, -inf / -1 padding, rows with
+    fewer than k entries and rows with none."""
+    import torch
+    from pfann_amd.database import DeviceIndex
+    ix = DeviceIndex(16, 0)
+    dev = ix.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(100 * G + m)
+    nq = 777
+    # ---- bound candidates [G, nq, m]: quantised values (many ties), -inf padding, some rows nearly empty
+    c = (torch.randint(-50, 50, (G, nq, m), device=dev, generator=g).float() / 64.0)
+    c[torch.rand((G, nq, m), device=dev, generator=g) < 0.2] = float("-inf")
+    c[:, 5] = float("-inf")                                        # nothing present
+    c[:, 6, 1:] = float("-inf")                                    # G values present
+    lb = ix.reduce_bound(c, k)
+    flat = c.permute(1, 0, 2).reshape(nq, G * m)
+    want = torch.sort(flat, dim=1, descending=True).values[:, k - 1] if G * m >= k else torch.full((nq,), float("-inf"), device=dev)
+    want = torch.where(torch.isfinite(want), want, torch.full_like(want, -3.4028234663852886e38))
+    assert torch.equal(lb, want)
+    # ---- shard lists [G, nq, kk]: sorted descending per list, labels unique, tails padded with (-FLT_MAX, -1)
+    kk = k
+    D = torch.sort(torch.randint(-30, 30, (G, nq, kk), device=dev, generator=g).float() / 32.0, dim=2, descending=True).values
+    I = torch.arange(G * nq * kk, device=dev, dtype=torch.int64).reshape(G, nq, kk) * 3 + 1
+    n_valid = torch.randint(0, kk + 1, (G, nq), device=dev, generator=g)
+    n_valid[:, 3] = 0                                              # a row without any entry
+    pad = torch.arange(kk, device=dev)[None, None, :] >= n_valid[:, :, None]
+    D = torch.where(pad, torch.full_like(D, -3.4028234663852886e38), D).contiguous()
+    I = torch.where(pad, torch.full_like(I, -1), I).contiguous()
+    Dn, In = ix.merge_lists(D, I, k)
+    S = D.permute(1, 0, 2).reshape(nq, G * kk).contiguous()
+    L = I.permute(1, 0, 2).reshape(nq, G * kk).contiguous()
+    Do, Io = ix.merge_topk(S, L, k)
+    assert torch.equal(Dn, Do) and torch.equal(In, Io)
+    assert bool((In[3] == -1).all())
