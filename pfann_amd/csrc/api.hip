@@ -366,6 +366,15 @@ static int keep_tap(pfann_ctx *c, int idx, const float *act, int64_t B, hipStrea
 static int ensure_workspace(pfann_ctx *c, bool need_mel) {
     const int64_t mb = c->cfg.max_batch;
     if (!c->buf[0]) {
+        // the activation workspace: max_batch x the two largest sub-layer outputs (29 GB at 9728 segments of the default
+        // model -- sized for a 288 GB MI355X; a device that cannot give it gets told which knob to turn)
+        const size_t need = (size_t)mb * (c->buf_elems[0] + c->buf_elems[1]) * sizeof(float);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < need) {
+            set_error("the encoder workspace for max_batch = %lld segments needs %.1f GB but only %.1f GB of device memory are "
+                      "free: lower max_batch (the tools: PFANN_MAX_BATCH)", (long long)mb, need / 1e9, free_b / 1e9);
+            return -1;
+        }
         PF_HIP(hipMalloc(&c->buf[0], mb * c->buf_elems[0] * sizeof(float)));
         PF_HIP(hipMalloc(&c->buf[1], mb * c->buf_elems[1] * sizeof(float)));
         PF_HIP(hipMalloc(&c->part[0], mb * c->part_slots * 2 * sizeof(float)));

@@ -203,10 +203,11 @@ if __name__ == "__main__":
     ap.add_argument("--songs", type=int, default=10000)
     ap.add_argument("--queries", type=int, default=2000)
     ap.add_argument("--snr", type=float, default=0.0)
+    ap.add_argument("--gpus", type=int, default=1, help="> 1: the tools start their own ranks (PFANN_GPUS)")
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
-    res = run(a.songs, a.queries, a.snr, keep=a.keep, log=lambda *x: print(*x, file=sys.stderr, flush=True))
+    res = run(a.songs, a.queries, a.snr, keep=a.keep, log=lambda *x: print(*x, file=sys.stderr, flush=True), gpus=a.gpus)
     print(json.dumps(res))
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
