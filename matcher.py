@@ -3,9 +3,12 @@
 import os
 import sys
 
-from pfann_amd import prewarm
+from pfann_amd import launch, prewarm
 
 if __name__ == "__main__":
+    _rc = launch.self_launch_if_asked(sys.argv)      # PFANN_GPUS=N: N ranks of this command, one per GPU (no torch import yet)
+    if _rc is not None:
+        sys.exit(_rc)
     # HIP initialisation + code-object loading run on a thread under the import of torch below
     prewarm.start([os.path.join(sys.argv[2], "model.pt")] if len(sys.argv) > 2 else [])
     from pfann_amd.matcher import main

@@ -69,29 +69,9 @@ class quiet_stdout:
 
 
 def self_launch_if_asked(argv):
-    """`PFANN_GPUS=N python matcher.py ...` (N > 1, or "all") without a launcher: start N ranks of this very command,
-    one per GPU, through torch.distributed.run on 127.0.0.1, and return their exit status; None when there is nothing
-    to launch (no PFANN_GPUS, N == 1, or already running as a rank).  Refuses to start fewer RCCL ranks than asked for."""
-    want = os.environ.get("PFANN_GPUS", "")
-    if not want or "WORLD_SIZE" in os.environ:
-        return None
-    backend = os.environ.get("PFANN_DIST_BACKEND", "nccl")
-    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    n = have if want == "all" else int(want)
-    if n <= 1 and os.environ.get("PFANN_FORCE_SHARDED", "0") == "0":
-        return None
-    if backend == "nccl" and "PFANN_FORCE_DEVICE" not in os.environ and have < n:
-        print("PFANN_GPUS=%d: only %d HIP device(s) visible; an RCCL job needs one device per rank -- refusing to run fewer "
-              "ranks than asked for" % (n, have), file=sys.stderr)
-        return 2
-    import socket
-    import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(max(n, 1)),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(argv[0])] + list(argv[1:])
-    return subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    """See pfann_amd/launch.py (the torch-free launcher the root shims call before they import anything heavy)."""
+    from .launch import self_launch_if_asked as _go
+    return _go(argv)
 
 
 def init_ranks():

@@ -593,6 +593,49 @@ def test_sharded_result_writer_equals_single_writer_gloo(tmp_path, world):
         assert a == b and len(a) > 0, suffix
 
 
+LAUNCH_WORKER = r'''
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+from pfann_amd import launch
+rc = launch.self_launch_if_asked(sys.argv)
+if rc is not None:
+    sys.exit(rc)
+from pfann_amd.dist import init_ranks, finish_ranks
+ranks = init_ranks()
+mode = sys.argv[2]
+print("RANK %d of %d backend %s omp %s" % (ranks.rank, ranks.world, ranks.backend, os.environ.get("OMP_NUM_THREADS")), flush=True)
+if mode == "fail" and ranks.rank == 1:
+    sys.exit(7)                      # the launcher must take the other rank down and report 7
+if mode == "fail":
+    time.sleep(60)
+ranks.barrier()
+finish_ranks(ranks)
+'''
+
+
+def test_torch_free_rank_launcher(tmp_path):
+    """pfann_amd/launch.py (what `PFANN_GPUS=N python matcher.py ...` goes through): N ranks of the same command meet in
+    one process group over the env:// rendezvous; a rank that fails takes the job down with its exit status instead of
+    leaving the others waiting; no PFANN_GPUS = nothing launched; the launcher never imports torch.  CPU, gloo."""
+    import time
+    script = tmp_path / "lw.py"
+    script.write_text(LAUNCH_WORKER)
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PFANN_GPUS", "PFANN_FORCE_SHARDED",
+                                                             "OMP_NUM_THREADS")}
+    env = dict(base, PFANN_GPUS="3", PFANN_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, str(script), REPO, "ok"], capture_output=True, text=True, timeout=300, env=env, cwd=REPO)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert sorted(ln.split()[1] for ln in r.stdout.splitlines() if ln.startswith("RANK")) == ["0", "1", "2"]
+    assert "of 3 backend gloo" in r.stdout and "[Gloo]" not in r.stdout
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(script), REPO, "fail"], capture_output=True, text=True, timeout=300, env=env, cwd=REPO)
+    assert r.returncode == 7 and time.time() - t0 < 45, (r.returncode, r.stderr[-2000:])
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from pfann_amd import launch; "
+                        "print(launch.self_launch_if_asked(['x']), 'torch' in sys.modules)" % REPO],
+                       capture_output=True, text=True, timeout=120, env=dict(base), cwd=REPO)
+    assert r.stdout.split() == ["None", "False"], r.stdout + r.stderr
+
+
 def test_cli_bench_helpers(tmp_path):
     """tools/cli_bench.py host pieces: its WAV writer produces files the `wave` module (the reference's reader,
     audio.py:130-149) and the library's native reader agree on; the stage-line parser reads what the CLIs print."""
