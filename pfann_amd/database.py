@@ -295,7 +295,10 @@ class Database:
         r_lo, r_hi = 0, n_rows
         if self.ranks is not None:
             from .dist import shard_songs
-            self.song_range = shard_songs(self.song_pos, self.ranks.world)[self.ranks.rank]
+            ranges = shard_songs(self.song_pos, self.ranks.world)
+            self.song_range = ranges[self.ranks.rank]
+            # (query_launch_chunks must cut alike on every rank -- its launches are collective: the widest shard decides)
+            self._widest_shard = max(hi - lo for lo, hi in ranges)
             r_lo, r_hi = int(self.song_pos[self.song_range[0]]), int(self.song_pos[self.song_range[1]])
         emb = None
         lv = os.path.join(dir_for_db, "landmarkValue")
@@ -374,7 +377,7 @@ class Database:
         1024: one-segment queries against a 100 k-song database would otherwise want 7.8 GB of HBM and as much pinned
         host memory per launch group).  -> [(first query, one past the last, launch)]"""
         nq = len(qlen)
-        width = max(self.song_range[1] - self.song_range[0], 1)
+        width = max(getattr(self, "_widest_shard", self.song_range[1] - self.song_range[0]), 1)
         step = nq if not want_song_scores else max(1, min(nq, self.max_score_pairs // width))
         qstart = np.asarray(qstart, dtype=np.int64)
         out = []

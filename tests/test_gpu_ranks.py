@@ -263,6 +263,14 @@ def test_edge_lists_and_variants_under_two_ranks(tmp_path):
         _results_equal(r1, r2)
         assert os.path.getsize(r1 + ".bin") == len(files) * 5 * 8
         assert len(open(r1).read().splitlines()) == len(files)
+    # a tiny score-block budget: every launch group is split into several sub-launches, which are COLLECTIVE under ranks
+    # -- the cut must be the same on every rank although the shards are 2 and 3 songs wide (13 pairs: 4 queries per launch)
+    ql = os.path.join(tmp, "ql_seven.txt")
+    r3, r4 = os.path.join(tmp, "r3_seven.txt"), os.path.join(tmp, "r4_seven.txt")
+    _run(_tool("matcher.py") + [ql, dbs["alla"], r3], tmp, _env(PFANN_SCORE_BLOCK_MB="0.0001"))
+    _run(_tool("matcher.py") + [ql, dbs["alla"], r4], tmp, _two_ranks(PFANN_SCORE_BLOCK_MB="0.0001"), timeout=300)
+    _results_equal(os.path.join(tmp, "r1_seven.txt"), r3)
+    _results_equal(r3, r4)
     rows = [ln.rstrip("\n").split("\t")[1] for ln in open(os.path.join(tmp, "r2_seven.txt"))]
     assert rows[3] == "error" and sum(1 for j, a in enumerate(rows) if a in music) == 7
     # the one-song database (its single song lives on one rank, the other shard is empty)
