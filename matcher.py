@@ -1,6 +1,5 @@
 #!/usr/bin/env python
 """Drop-in for the reference's `python matcher.py <query list> <db dir> <result file>`."""
-import os
 import sys
 
 from pfann_amd import launch, prewarm
@@ -9,7 +8,8 @@ if __name__ == "__main__":
     _rc = launch.self_launch_if_asked(sys.argv)      # PFANN_GPUS=N: N ranks of this command, one per GPU (no torch import yet)
     if _rc is not None:
         sys.exit(_rc)
-    # HIP initialisation + code-object loading run on a thread under the import of torch below
-    prewarm.start([os.path.join(sys.argv[2], "model.pt")] if len(sys.argv) > 2 else [])
+    # HIP initialisation, code-object loading and the model (configs.json -> context, model.pt -> weights) on a thread under
+    # the import of torch below
+    prewarm.start(engine=prewarm.engine_job_for("matcher", sys.argv))
     from pfann_amd.matcher import main
     prewarm.fast_exit(main(sys.argv))

@@ -466,18 +466,18 @@ def main(argv=None):
     if rank0:
         init_logger("builder")                                             # builder.py:27-28
 
-    from .utils import AsyncLoad, StartupClock
+    from .utils import StartupClock
     clock = StartupClock(say)
     say("loading model...")
     max_batch = int(os.environ.get("PFANN_MAX_BATCH", "9728"))
     model_pt = os.path.join(params["model_dir"], "model.pt")
-    weights = AsyncLoad(model_pt)
     engine = Engine(params, ranks.device if ranks is not None else 0, max_batch=max_batch)
     # kernel variants of a full launch group for every call: a song's fingerprints -- every byte of `embeddings` -- do not
     # depend on how the list is cut into groups or spread over ranks (include/pfann_amd.h: pfann_set_plan_batch)
     engine.set_plan_batch(max_batch)
     clock.lap("engine")
-    engine.load_state_dict(weights.result())
+    if not engine.weights_loaded:             # (else: the start-up thread read model.pt and loaded it while torch was importing)
+        engine.load_state_dict(torch.load(model_pt, map_location="cpu"))
     clock.lap("weights")
     engine.warmup(windows=max_batch)
     clock.lap("engine warm-up")

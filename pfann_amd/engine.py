@@ -9,6 +9,7 @@ import numpy as np
 import torch
 
 from . import lib as _l
+from .config import config_from_params          # noqa: F401 -- (re-exported: callers import it from here)
 from .synth import model_dims
 
 
@@ -46,34 +47,6 @@ def mel_filterbank(sample_rate, n_fft, n_mels, f_min, f_max, naf_mode=False):
     return fb.to(torch.float32).contiguous()
 
 
-def config_from_params(params, max_batch=512):
-    """configs/*.json dict -> pfann_config (keys read exactly where the reference reads them:
-    builder.py:46-51, melspec.py:52-63, model.py:135-140)."""
-    d, h, u, F, T = model_dims(params)
-    m = params["model"]
-    naf = params.get("naf_mode", False)
-    cfg = _l.Config()
-    cfg.segment_len = int(params["segment_size"] * params["sample_rate"])
-    cfg.stft_n = params["stft_n"]
-    cfg.stft_hop = params["stft_hop"]
-    cfg.n_mels = params["n_mels"]
-    cfg.power = 1 if naf else 2
-    cfg.pad_reflect = 0 if naf else 1
-    cfg.log_mode = {"log": 1, "log10": 2}.get(params.get("mel_log", "log"), 0)
-    cfg.spec_norm_max = 1 if params.get("spec_norm", "l2") == "max" else 0
-    cfg.log_eps = 0.06 if naf else 1e-8
-    cfg.d, cfg.h, cfg.u = d, h, u
-    cfg.fuller = 1 if m.get("fuller", False) else 0
-    cfg.activation = {"ReLU": 0, "ELU": 1}[m.get("conv_activation", "ReLU")]
-    cfg.relu_after_bn = 1 if m.get("relu_after_bn", True) else 0
-    strides = m.get("strides")
-    for i in range(8):
-        cfg.stride_t[i] = 2 if strides is None else strides[i][0][1]
-        cfg.stride_f[i] = 2 if strides is None else strides[i][1][0]
-    cfg.max_batch = max_batch
-    return cfg
-
-
 class Engine:
     def __init__(self, params, device=0, max_batch=512, encoder_only=False):
         """encoder_only: the context serves `encode` alone (FpNetwork built without a full config, model.py:132-146
@@ -86,7 +59,12 @@ class Engine:
         self.cfg = config_from_params(params, max_batch)
         self.d, self.h, self.u, self.F, self.T = model_dims(params)
         self.seg_len = self.cfg.segment_len
-        self.handle = self.lib.pfann_create(ctypes.byref(self.cfg), self.device.index)
+        # the tools' start-up thread may already have built this very context, weights included (prewarm.py)
+        from . import prewarm
+        self.handle = prewarm.take_engine(self.cfg, self.device.index) if not encoder_only else None
+        self.weights_loaded = self.handle is not None
+        if self.handle is None:
+            self.handle = self.lib.pfann_create(ctypes.byref(self.cfg), self.device.index)
         self._resample_tables = {}
         if not self.handle:
             raise _l.PfannError("pfann_create failed: " + _l.last_error())

@@ -36,7 +36,8 @@ def main(argv=None):
     max_batch = int(os.environ.get("PFANN_MAX_BATCH", "9728"))
     engine = Engine(params, ranks.device if ranks is not None else 0, max_batch=max_batch)
     engine.set_plan_batch(max_batch)         # the same bits as matcher.py / builder.py give the same file, however it is grouped
-    engine.load_state_dict(torch.load(os.path.join(dir_for_db, "model.pt"), map_location="cpu"))
+    if not engine.weights_loaded:             # (else: the start-up thread has read and loaded model.pt already)
+        engine.load_state_dict(torch.load(os.path.join(dir_for_db, "model.pt"), map_location="cpu"))
     say("model loaded")
     dataset = MusicDataset(file_list_for_query, params)
     if rank0:

@@ -22,7 +22,7 @@ from .database import Database
 from .dist import finish_ranks, init_ranks, self_launch_if_asked
 from .engine import Engine
 from .musicdata import MusicDataset
-from .utils import AsyncLoad, StageTimer, StartupClock, get_logger, init_logger, read_config
+from .utils import StageTimer, StartupClock, get_logger, init_logger, read_config
 
 
 class ResultWriter:
@@ -140,14 +140,14 @@ def main(argv=None):
             db_box.append(x)
     db_thread = threading.Thread(target=load_db, name="pfann-db-load")
     db_thread.start()
-    weights = AsyncLoad(os.path.join(dir_for_db, "model.pt"))
     dataset = MusicDataset(file_list_for_query, params)
     engine = Engine(params, dev, max_batch=max_batch)
     # kernel variants of a full launch group for every call: a query's fingerprints -- and with them every byte of the
     # three output files -- do not depend on how the list is cut into groups or spread over ranks
     engine.set_plan_batch(max_batch)
     clock.lap("engine")
-    engine.load_state_dict(weights.result())
+    if not engine.weights_loaded:             # (else: the start-up thread read model.pt and loaded it while torch was importing)
+        engine.load_state_dict(torch.load(os.path.join(dir_for_db, "model.pt"), map_location="cpu"))
     clock.lap("weights")
     # a short list never fills a launch group: warm up (and size the search workspace) for what will really come
     warm = min(max_batch, max(64, len(dataset) * int(os.environ.get("PFANN_WARMUP_SEGMENTS_PER_FILE", "19"))))

@@ -9,13 +9,70 @@ import sys
 import threading
 
 _thread = None
+_engine = None          # (handle, bytes of its pfann_config, device) built by the start-up thread, or None
 
 
 def _device():
     return int(os.environ.get("PFANN_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
 
 
-def _work(paths):
+def _engine_job(lib, job):
+    """The encoder context with its weights, built without torch: configs.json -> pfann_config (config.py), model.pt ->
+    numpy (ptfile.py) -> pfann_load_weight.  Anything unexpected (an unknown pickle, a missing tensor): no context, and
+    the tool loads the model the ordinary way."""
+    global _engine
+    import json
+    from . import lib as _l
+    from .config import config_from_params
+    from .ptfile import load_state_dict_numpy
+    import numpy as np
+    configs_json, model_pt, max_batch = job
+    params = json.load(open(configs_json))
+    cfg = config_from_params(params, max_batch)
+    sd = load_state_dict_numpy(model_pt)
+    lib.pfann_create.restype = ctypes.c_void_p
+    lib.pfann_create.argtypes = [ctypes.POINTER(_l.Config), ctypes.c_int]
+    lib.pfann_load_weight.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int64]
+    lib.pfann_weights_missing.argtypes = [ctypes.c_void_p]
+    lib.pfann_destroy.argtypes = [ctypes.c_void_p]
+    h = lib.pfann_create(ctypes.byref(cfg), _device())
+    if not h:
+        return
+    ok = True
+    for name, val in sd.items():
+        arr = np.ascontiguousarray(val, dtype=np.float32)
+        if lib.pfann_load_weight(h, name.encode(), arr.ctypes.data, arr.size) < 0:
+            ok = False
+            break
+    if ok and lib.pfann_weights_missing(h) == 0:
+        _engine = (h, bytes(cfg), _device())
+    else:
+        lib.pfann_destroy(h)
+
+
+def take_engine(cfg, device):
+    """-> the handle of the context the start-up thread built, if it built one for exactly this pfann_config on this
+    device (waits for the thread); else None.  The caller owns the handle from then on."""
+    global _engine
+    if _thread is None:
+        return None
+    _thread.join()
+    got, _engine = _engine, None
+    if got is None:
+        return None
+    h, cfg_bytes, dev = got
+    if cfg_bytes == bytes(cfg) and dev == int(device):
+        return h
+    try:                                              # built for something else (should not happen): give it back
+        lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpfann_amd.so"))
+        lib.pfann_destroy.argtypes = [ctypes.c_void_p]
+        lib.pfann_destroy(h)
+    except OSError:
+        pass
+    return None
+
+
+def _work(paths, job=None):
     try:
         # torch ships its own HIP runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7): it has to be the one in the
         # process BEFORE libpfann_amd.so is loaded, or the library binds to /opt/rocm's copy and the process ends up with
@@ -29,7 +86,12 @@ def _work(paths):
         lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpfann_amd.so"))
         lib.pfann_prewarm.argtypes = [ctypes.c_int]
         lib.pfann_prewarm.restype = ctypes.c_int
-        lib.pfann_prewarm(_device())                  # no device / no library: the tool itself will say so, loudly
+        rc = lib.pfann_prewarm(_device())             # no device / no library: the tool itself will say so, loudly
+        if rc == 0 and job is not None and os.environ.get("PFANN_PREWARM_ENGINE", "1") != "0":
+            try:
+                _engine_job(lib, job)
+            except Exception:                         # noqa: BLE001 -- any surprise: the ordinary path loads the model
+                pass
     except (OSError, AttributeError, ImportError, ValueError):
         pass
     for p in paths:                                   # model.pt / landmarkValue: into the page cache
@@ -41,14 +103,33 @@ def _work(paths):
             pass
 
 
-def start(paths=()):
-    """Idempotent; does nothing when this process is only going to launch ranks (PFANN_GPUS set, not yet a rank)."""
+def engine_job_for(tool, argv):
+    """(configs.json, model.pt, max_batch) of the model the tool is about to load, from its argv (builder.py:38-44,
+    matcher.py:44-60, extractemb.py); None when that cannot be told without doing the tool's own work."""
+    try:
+        mb = int(os.environ.get("PFANN_MAX_BATCH", "9728"))
+        if tool in ("matcher", "extractemb") and len(argv) > 2:
+            return os.path.join(argv[2], "configs.json"), os.path.join(argv[2], "model.pt"), mb
+        if tool == "builder" and len(argv) > 2:
+            cfg = argv[3] if len(argv) > 3 else "configs/default.json"
+            if os.path.isdir(cfg):
+                return os.path.join(cfg, "configs.json"), os.path.join(cfg, "model.pt"), mb
+            import json
+            return cfg, os.path.join(json.load(open(cfg))["model_dir"], "model.pt"), mb
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
+def start(paths=(), engine=None):
+    """Idempotent; does nothing when this process is only going to launch ranks (PFANN_GPUS set, not yet a rank).
+    engine = (configs.json path, model.pt path, max_batch): also build the encoder context and load its weights."""
     global _thread
     if _thread is not None or os.environ.get("PFANN_PREWARM", "1") == "0":
         return
     if os.environ.get("PFANN_GPUS") and "WORLD_SIZE" not in os.environ:
         return
-    _thread = threading.Thread(target=_work, args=(list(paths),), name="pfann-prewarm", daemon=True)
+    _thread = threading.Thread(target=_work, args=(list(paths), engine), name="pfann-prewarm", daemon=True)
     _thread.start()
 
 

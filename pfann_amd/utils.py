@@ -129,26 +129,3 @@ class StartupClock:
             self.say("startup %s %.3fs" % (what, now - self.t))
         self.t = now
 
-
-class AsyncLoad:
-    """torch.load(path, map_location="cpu") on a thread (the file read and the unpickling overlap the creation of the
-    engine context); result() joins and re-raises."""
-
-    def __init__(self, path):
-        import threading
-        self._box = []
-
-        def work():
-            try:
-                import torch
-                self._box.append(torch.load(path, map_location="cpu"))
-            except BaseException as x:          # noqa: B902 -- handed to result()
-                self._box.append(x)
-        self._th = threading.Thread(target=work, name="pfann-weights-load")
-        self._th.start()
-
-    def result(self):
-        self._th.join()
-        if isinstance(self._box[0], BaseException):
-            raise self._box[0]
-        return self._box[0]

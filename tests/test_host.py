@@ -661,3 +661,31 @@ def test_cli_bench_helpers(tmp_path):
     assert total == 2.87 and stages == {"load": 0.27, "stereo to mono": 0.0276, "compute embedding": 2.4232}
     stages, total = cli_bench.parse_stdout("search 0.019200s\nrerank 0.003900s\noutput answer 0.029600s\ntotal query time 0.390000s\n")
     assert total == 0.39 and set(stages) == {"search", "rerank", "output answer"}
+
+
+def test_ptfile_reads_a_state_dict_without_torch(tmp_path):
+    """pfann_amd/ptfile.py (the tools read model.pt on their start-up thread before torch is imported): same arrays as
+    torch.load for contiguous, sliced, transposed, scalar and nn.Parameter entries; anything it does not understand raises
+    Unsupported (the tool then falls back to torch.load); the module itself never imports torch."""
+    import collections
+    import torch
+    from pfann_amd import ptfile
+    sd = collections.OrderedDict([("a.weight", torch.randn(3, 4)), ("b", torch.arange(9).float()[2:7]), ("c", torch.randn(2, 5).t()),
+                                  ("s", torch.tensor(3.5)), ("p", torch.nn.Parameter(torch.randn(2, 2))),
+                                  ("h", torch.randn(4).half()), ("i", torch.arange(6).reshape(2, 3))])
+    path = str(tmp_path / "m.pt")
+    torch.save(sd, path)
+    got = ptfile.load_state_dict_numpy(path)
+    assert list(got) == list(sd)
+    for k, v in sd.items():
+        assert np.array_equal(got[k], v.detach().numpy()) and got[k].dtype == v.detach().numpy().dtype, k
+    torch.save({"w": torch.randn(2), "meta": {"epoch": 3}}, path)          # a checkpoint, not a state_dict
+    with pytest.raises(ptfile.Unsupported):
+        ptfile.load_state_dict_numpy(path)
+    torch.save([torch.randn(2)], path)
+    with pytest.raises(ptfile.Unsupported):
+        ptfile.load_state_dict_numpy(path)
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import pfann_amd.ptfile, pfann_amd.config, "
+                        "pfann_amd.prewarm, pfann_amd.launch; print('torch' in sys.modules)" % REPO],
+                       capture_output=True, text=True, timeout=120)
+    assert r.stdout.strip() == "False", r.stdout + r.stderr
