@@ -508,6 +508,17 @@ int launch_scan_f16_gmax(const void *dbh, int64_t n, int d, int64_t stride, cons
     if (!(d == 128 || d == 64) || nq < 1024 || db_tiles < 16) return 1;
     int S = (int)(2048 / p.n_tiles_m);
     S = S < 1 ? 1 : (S > 32 ? 32 : S);
+    // no more groups than the threshold needs: 5 k of them (64 per slice) give the k-th best group maximum the same quality
+    // as 1000-1600 did -- the full pass that follows is not a microsecond slower -- while the group select, whose cost is
+    // the number of groups, halves: 0.77 -> 0.45 ms per 77,824 rows at 8 shards, 0.48 -> 0.29 on one GPU
+    // (profiles/r4/sharded_scan_model.txt; PFANN_GMAX_S overrides)
+    // ... but never fewer slices than fill the chip twice, and WHOLE rounds of the 512 resident workgroups: 76 query tiles x
+    // 8 slices are 1.2 rounds (the sampled pass itself slows from 0.64 to 0.78 ms), x 14 are 2.08 rounds (0.72: the last
+    // 0.08 of a round costs a round), x 13 are 1.93
+    const int s_cap = std::max(std::max(8, (5 * k + 63) / 64), (int)(1024 / p.n_tiles_m));
+    if (S > s_cap) S = s_cap;
+    static const int gs_env = getenv("PFANN_GMAX_S") ? atoi(getenv("PFANN_GMAX_S")) : 0;      // tuning aid: slices of the sampled pass
+    if (gs_env > 0) S = gs_env;
     if (S > db_tiles) S = (int)db_tiles;
     const int G = S * 64;                    // one group per (slice, row position in the 128-row tile up to the lane half)
     if (G < 4 * k || db_tiles < 4 * (int64_t)S) return 1;      // >= 4 rows per group
