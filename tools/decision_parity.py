@@ -31,7 +31,7 @@ for _p in (REPO, os.path.join(REPO, "tools")):
 SEG, QSEG, HOP = 59, 19, 4000
 
 
-def run(n_songs, n_queries, snr, workers=16, config="default", plan=9728, max_batch=9728, log=print, keep=False):
+def run(n_songs, n_queries, snr, workers=16, config="default", plan=9728, max_batch=9728, log=print, keep=False, shards=1):
     import torch
     from pfann_amd import synth
     from pfann_amd.builder import embed_files
@@ -70,8 +70,16 @@ def run(n_songs, n_queries, snr, workers=16, config="default", plan=9728, max_ba
         pcms.append(qp)
     q_pcm = torch.cat(pcms)
     # the GPU decisions the way the matcher CLI makes them: launch groups of max_batch windows, plan pinned
-    index = DeviceIndex(d, 0)
-    index.load(shard, song_pos, 0)
+    # shards > 1: the SHARDED protocol of pfann_amd/dist.py with all N song shards held as N handles on this one GPU and
+    # the collectives replaced by stacking (two-phase bounded search per shard, merge of the shard lists, owner-side
+    # matcher on every shard, 128-bit winner keys, device pick) -- BASELINE config 4's "sharded 8 ways", decision by decision
+    from pfann_amd.dist import shard_songs
+    handles = []
+    for lo, hi in (shard_songs(song_pos, shards) if shards > 1 else [(0, n_songs)]):
+        ix = DeviceIndex(d, 0)
+        ix.load(shard[int(song_pos[lo]):int(song_pos[hi])], song_pos, int(song_pos[lo]))
+        handles.append(ix)
+    index = handles[0]
     per = max(1, max_batch // QSEG)
     res, labels = [], []
     for c0 in range(0, n_queries, per):
@@ -79,8 +87,17 @@ def run(n_songs, n_queries, snr, workers=16, config="default", plan=9728, max_ba
         nq = qp.shape[0]
         starts = (torch.arange(nq, device=dev)[:, None] * qp.shape[1] + torch.arange(QSEG, device=dev)[None, :] * HOP).reshape(-1)
         e = eng.embed_windows(eng.pcm16_to_mono(qp.reshape(-1)), starts)
-        D, I = index.search(e, k)
-        r, _ = index.match(e, I, np.arange(nq, dtype=np.int64) * QSEG, np.full(nq, QSEG, np.int32))
+        qs, ql = np.arange(nq, dtype=np.int64) * QSEG, np.full(nq, QSEG, np.int32)
+        if shards > 1:
+            m = min(k, 2 * k // shards + 8)
+            cands = torch.stack([ix.search_bound(e, k, m) for ix in handles])                 # "all-gather"
+            lists = [ix.search_bounded(e, k, ix.reduce_bound(cands, k)) for ix in handles]
+            D, I = index.merge_lists(torch.stack([a for a, _ in lists]), torch.stack([b for _, b in lists]), k)
+            keys = torch.stack([ix.pack_winner_keys(ix.match(e, I, qs, ql, 1, 0.0, 0, True, False, to_host=False)[0]) for ix in handles])
+            r = index.pick_winner(keys)
+        else:
+            D, I = index.search(e, k)
+            r, _ = index.match(e, I, qs, ql)
         embs.append(e), res.append(r), labels.append(I.cpu().numpy())
     res = np.concatenate(res)
     labels = np.concatenate(labels).reshape(n_queries, QSEG, k)
@@ -117,7 +134,7 @@ def run(n_songs, n_queries, snr, workers=16, config="default", plan=9728, max_ba
                           if any(set(labels[j, t].tolist()) != set(o_lab[j, t].tolist()) for t in range(QSEG))))
     hit = float(np.mean(g_song == np.asarray(q_song)))
     out = {"config": config, "db_songs": n_songs, "db_rows": n_songs * SEG, "queries": n_queries, "snr_db": snr, "top_k": k,
-           "plan_batch": plan, "identical_song_and_offset": int(same.sum()), "flips": flips,
+           "plan_batch": plan, "shards": shards, "identical_song_and_offset": int(same.sum()), "flips": flips,
            "bugs": int(sum(1 for f in flips if f["class"] == "bug")),
            "max_embedding_abs_diff": float(emb_err.max()), "embedding_tolerance": 1e-4,
            "max_score_abs_diff_where_decisions_agree": float(np.abs(g_score - o_score)[same].max()) if same.any() else None,
@@ -139,9 +156,10 @@ if __name__ == "__main__":
     ap.add_argument("--snr", type=float, default=0.0)
     ap.add_argument("--workers", type=int, default=16)
     ap.add_argument("--plan", type=int, default=9728)
+    ap.add_argument("--shards", type=int, default=1, help="> 1: the sharded protocol over N handles on this GPU (no collectives)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
-    r = run(a.songs, a.queries, a.snr, a.workers, plan=a.plan, log=lambda *x: print(*x, file=sys.stderr, flush=True))
+    r = run(a.songs, a.queries, a.snr, a.workers, plan=a.plan, shards=a.shards, log=lambda *x: print(*x, file=sys.stderr, flush=True))
     print(json.dumps({k: v for k, v in r.items() if k != "flips"}), "flips:", json.dumps(r["flips"])[:3000])
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)

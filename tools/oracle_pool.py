@@ -35,7 +35,7 @@ def worker(work, w, W):
     meta = json.load(open(os.path.join(work, "meta.json")))
     params, k = meta["params"], meta["k"]
     sd = dict(np.load(os.path.join(work, "weights.npz")))
-    db = np.ascontiguousarray(np.load(os.path.join(work, "db.npy"), mmap_mode="r"))
+    db = np.load(os.path.join(work, "db.npy"), mmap_mode="r")          # shared page cache: no per-process copy (3 GB at config 4)
     song_pos = np.load(os.path.join(work, "song_pos.npy"))
     pcm = np.load(os.path.join(work, "q_pcm.npy"), mmap_mode="r")
     emb_gpu = np.load(os.path.join(work, "q_emb_gpu.npy"), mmap_mode="r") if os.path.exists(os.path.join(work, "q_emb_gpu.npy")) else None
