@@ -69,6 +69,7 @@ def self_launch_if_asked(argv):
     try:
         rc = 0
         alive = list(procs)
+        t_stop = None
         while alive:
             for p in list(alive):
                 r = p.poll()
@@ -77,6 +78,11 @@ def self_launch_if_asked(argv):
                     if r != 0 and rc == 0:             # one rank failed: the others would wait for it forever
                         rc = r
                         stop()
+                        t_stop = time.time()
+            if alive and t_stop is not None and time.time() - t_stop > 15.0:
+                for p in alive:                        # a rank stuck in a collective may not act on SIGTERM
+                    p.kill()
+                t_stop = time.time()
             if alive:
                 time.sleep(0.01)
         return rc
