@@ -102,7 +102,7 @@ class OracleIndex:
         return out
 
     def match(self, q, labels, qstart, qlen, fsm=1, alpha=0.0, mode=0, only_owned=False, want_song_scores=False,
-              to_host=True):
+              to_host=True, owned_block=False):
         """Python-path oracle restricted to owned songs: labels of other shards' songs are
         dropped before candidate generation, local rows are addressed through label_base."""
         q, labels = q.numpy(), labels.numpy()
@@ -111,20 +111,26 @@ class OracleIndex:
         # full-size db view so the oracle can index rows globally
         full = np.zeros((int(self.song_pos[-1]), self.d), np.float32)
         full[self.label_base:self.label_base + self.ntotal] = self.emb
+        blocks = []
         for j in range(len(qlen)):
             sl = slice(int(qstart[j]), int(qstart[j]) + int(qlen[j]))
             lab = labels[sl].copy()
             if only_owned:
                 own_lo, own_hi = self.song_pos[self.song_lo], self.song_pos[self.song_hi]
                 lab[(lab < own_lo) | (lab >= own_hi)] = -1
+            ss = np.zeros((self.n_songs, 2), np.float32)
             if (lab >= 0).any():
-                score, (song, sec), _ = osq.query_embeddings_base(q[sl], lab, full, self.song_pos, 1.0, fsm)
+                score, (song, sec), ss = osq.query_embeddings_base(q[sl], lab, full, self.song_pos, 1.0, fsm)
             else:
                 score, song, sec = -np.inf, -1, 0
+            if want_song_scores:            # alignments in FINE FRAMES like pfann_match (hop 1.0 above: seconds == frames / fsm)
+                ss = ss.copy()
+                ss[:, 1] = np.round(ss[:, 1] * fsm)
+                blocks.append(ss[self.song_lo:self.song_hi] if owned_block else ss)
             if song < 0:
                 out[j] = (-1, 0, 0, 0, -np.inf)
             else:
                 fine = int(round(sec * fsm))
                 shift = (-fine) % fsm
                 out[j] = (song, (fine + shift) // fsm, shift, 0, score)
-        return out, None
+        return out, (torch.from_numpy(np.stack(blocks)) if want_song_scores and blocks else None)

@@ -194,7 +194,17 @@ sh = ShardedIndex(idx, pos, k, 1, 0.0)
 D, I = sh.search_global(qt)
 Dr, Ir = osr.flat_ip_topk(q, db, k)
 assert np.array_equal(I.numpy(), Ir), "global top-k differs from single-device"
+# the product's second half (Database.query_launch under ranks): winners on every rank + THIS shard's columns of the score matrix
+win, ss_own = sh.match_global(qt, I, qstart, qlen, want_song_scores=True)
+counts = [h - l for l, h in __import__("pfann_amd.dist", fromlist=["shard_songs"]).shard_songs(pos, world)]
+assert ss_own.shape == (12, counts[rank], 2)
+ss_all = all_gather_ragged(ss_own.permute(1, 0, 2).contiguous(), counts).permute(1, 0, 2)      # [12, n_songs, 2]
 res = sh.query_batch(qt, qstart, qlen)
+assert np.array_equal(np.asarray(win), res)
+for j in range(12):
+    sl = slice(qstart[j], qstart[j] + qlen[j])
+    _, _, ss_ref = osq.query_embeddings_base(q[sl], Ir[sl], db, pos, 1.0, 1)
+    assert np.allclose(ss_all[j].numpy(), ss_ref, atol=1e-6), j
 for j in range(12):
     sl = slice(qstart[j], qstart[j] + qlen[j])
     score, (song, sec), _ = osq.query_embeddings_base(q[sl], Ir[sl], db, pos, 1.0, 1)
