@@ -156,10 +156,11 @@ if __name__ == "__main__":
     ap.add_argument("--snr", type=float, default=0.0)
     ap.add_argument("--workers", type=int, default=16)
     ap.add_argument("--plan", type=int, default=9728)
+    ap.add_argument("--config", default="default", help="configs/<name>.json (default, seg, n640d64)")
     ap.add_argument("--shards", type=int, default=1, help="> 1: the sharded protocol over N handles on this GPU (no collectives)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
-    r = run(a.songs, a.queries, a.snr, a.workers, plan=a.plan, shards=a.shards, log=lambda *x: print(*x, file=sys.stderr, flush=True))
+    r = run(a.songs, a.queries, a.snr, a.workers, config=a.config, plan=a.plan, shards=a.shards, log=lambda *x: print(*x, file=sys.stderr, flush=True))
     print(json.dumps({k: v for k, v in r.items() if k != "flips"}), "flips:", json.dumps(r["flips"])[:3000])
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
