@@ -39,7 +39,10 @@ def run(n_songs, n_queries, snr, workers=16, config="default", plan=9728, max_ba
     from pfann_amd.engine import Engine
     params = json.load(open(os.path.join(REPO, "configs", config + ".json")))
     d, k = params["model"]["d"], params["indexer"]["top_k"]
-    sd = synth.make_state_dict_calibrated(params, seed=123) if config == "default" else synth.make_state_dict(params, seed=123)
+    try:                    # calibrated output bias (an untrained network's fingerprints then spread over the sphere); configs
+        sd = synth.make_state_dict_calibrated(params, seed=123)      # without constants fall back to the raw seeded weights,
+    except KeyError:                                                 # whose fingerprints all but coincide (a degenerate db)
+        sd = synth.make_state_dict(params, seed=123)
     eng = Engine(params, 0, max_batch=max_batch)
     eng.load_state_dict(sd)
     eng.set_plan_batch(plan)
