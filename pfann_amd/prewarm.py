@@ -144,6 +144,9 @@ def fast_exit(rc):
         sys.stderr.flush()
     except (OSError, ValueError):
         pass
-    if os.environ.get("PFANN_FAST_EXIT", "1") == "0":
+    # a profiler that finalises at exit (rocprofv3 writes its trace database from an atexit hook) must get its normal exit
+    profiled = any(k.startswith(("ROCPROF", "ROCP_TOOL", "ROCPROFILER")) for k in os.environ) or \
+        "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if os.environ.get("PFANN_FAST_EXIT", "1") == "0" or profiled:
         sys.exit(rc)
     os._exit(int(rc or 0))

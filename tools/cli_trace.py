@@ -24,7 +24,7 @@ def main():
         print("# un-profiled: matcher.py %d segments, `total query time` %.3f s (%.0f segments/s), stages %s" %
               (res["matcher"]["segments"], res["matcher"]["total_query_time_s"], res["matcher"]["segments_per_s"], res["matcher"]["stages_s"]))
         out = os.path.join(work, "trace")
-        env = dict(os.environ, PYTHONPATH=REPO, TMPDIR="/tmp")
+        env = dict(os.environ, PYTHONPATH=REPO, TMPDIR="/tmp", PFANN_FAST_EXIT="0")     # (the profiler finalises at exit)
         r = subprocess.run(["rocprofv3", "--kernel-trace", "-d", out, "-o", "t", "--", sys.executable, os.path.join(REPO, "matcher.py"),
                             os.path.join(work, "queries.txt"), os.path.join(work, "db"), os.path.join(work, "result2.txt")],
                            capture_output=True, text=True, env=env, cwd="/tmp")
