@@ -502,6 +502,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    # what has been imported and built so far goes to the garbage collector's permanent generation: a full collection over
+    # torch's million objects takes ~50 ms and would land in whichever timed step crosses the allocation threshold
+    import gc
+    gc.freeze()
     for _ in range(args.warmup):
         step()
     two_deep = None if (args.serial or emu > 1) else TwoDeep(main_w)

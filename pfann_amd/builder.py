@@ -35,6 +35,12 @@ class _PinnedPool:
     def __init__(self):
         self.free = {}
         self.lock = threading.Lock()
+        # slabs the tools' start-up thread allocated while torch was importing (prewarm.py): a pinned allocation in the
+        # middle of a run stalls every launch of the process for its 10-40 ms
+        from . import prewarm
+        for addr, n in prewarm.take_pinned():
+            t = torch.frombuffer((ctypes.c_int16 * n).from_address(addr), dtype=torch.int16)
+            self.free.setdefault(n, []).append(t)
 
     def get(self, n):
         # per-file buffers: powers of two; a launch group's slab (tens of MB): the next multiple of 8 M samples -- a
@@ -44,10 +50,16 @@ class _PinnedPool:
             lst = self.free.get(cap)
             if lst:
                 return lst.pop()
+            if n > (1 << 20):                   # a smaller group (the ramp, the tail) takes a free larger slab rather than a new one
+                for c in sorted(self.free):
+                    if c >= cap and self.free[c]:
+                        return self.free[c].pop()
         # allocated pinned (torch.empty(...).pin_memory() allocates pageable memory, pins a second block and copies the
         # garbage over: 60 ms per 134 MB slab on the loader thread -- with a fresh slab per group until the first one comes
         # back, a 2000-query matcher run was fed one group per 83 ms for a GPU that needs 41)
-        return torch.empty(cap, dtype=torch.int16, pin_memory=True)
+        # ... and allocated WITHOUT the GIL (lib.pinned_int16): the loader thread takes its first slabs while the main thread
+        # is launching the first groups
+        return _l.pinned_int16(cap)
 
     def put(self, bufs):
         with self.lock:
@@ -248,6 +260,8 @@ def _native_groups(engine, dataset, hop, batch_windows, pool, workers, rank=0, w
 
     th = threading.Thread(target=produce, name="pfann-wav-loader", daemon=True)
     th.start()
+    if _TIMELINE:
+        print("timeline loader thread started at %.1f ms" % (1e3 * (time.perf_counter() - _T0[0])), file=sys.stderr)
     try:
         while True:
             t0 = time.perf_counter()
@@ -262,6 +276,8 @@ def _native_groups(engine, dataset, hop, batch_windows, pool, workers, rank=0, w
                 yield [], None, [], t_load, layout
                 continue
             base, g_info, g_seg, offs, slab, tot = mine
+            if _TIMELINE:
+                print("timeline group received at %.1f ms (waited %.1f)" % (1e3 * (time.perf_counter() - _T0[0]), 1e3 * t_load), file=sys.stderr)
             ok = g_info["status"] == 0
             for j in np.nonzero(~ok)[0]:
                 print("load %s error! (%s)" % (files[base + j], _WAV_ERR.get(int(g_info["status"][j]), "error")))
@@ -296,6 +312,10 @@ def _native_groups(engine, dataset, hop, batch_windows, pool, workers, rank=0, w
                 out_q.get_nowait()
             except queue.Empty:
                 th.join(0.05)
+
+
+_TIMELINE = os.environ.get("PFANN_TIMELINE", "0") not in ("0", "")
+_T0 = [time.perf_counter()]
 
 
 class Round(list):
@@ -337,6 +357,7 @@ def embed_file_batches(engine, dataset, hop, batch_windows=4096, timer=None, nor
     and the launches and never waits for the GPU: stage times of GPU work are taken with events
     (utils.StageTimer.stage_gpu)."""
     timer = timer or StageTimer()
+    _T0[0] = time.perf_counter()
     seg = engine.seg_len
     workers = int(os.environ.get("PFANN_DECODE_WORKERS", "8")) if workers is None else workers
     ahead = max(4 * workers, 16) if ahead is None else ahead
@@ -397,9 +418,15 @@ def embed_file_batches(engine, dataset, hop, batch_windows=4096, timer=None, nor
                 starts = np.concatenate(parts)
         timer.add("load", t_load)                      # one record per launch group (the reference: one per file)
         timer.add("stereo to mono", time.perf_counter() - t1)
+        t2 = time.perf_counter()
         if wav_all is not None:
             with timer.stage_gpu("compute embedding"):
                 emb = engine.embed_windows(wav_all, starts, norm=norm)
+        if _TIMELINE:                                  # PFANN_TIMELINE=1: where the feeding thread's time goes, group by group
+            print("timeline group of %d files, %d windows: at %.1f ms, waited %.1f ms for the loader, upload + conversion issued "
+                  "in %.1f ms, embed issued in %.1f ms" % (len(pending), sum(n for _, n, _ in pending), 1e3 * (t1 - _T0[0]), 1e3 * t_load,
+                                                        1e3 * (t2 - t1), 1e3 * (time.perf_counter() - t2)), file=sys.stderr)
+        if wav_all is not None:
             out, o = [], 0
             for idx, n_seg, _ in pending:
                 out.append((idx, n_seg, emb[o:o + n_seg] if n_seg else None))
@@ -470,6 +497,8 @@ def main(argv=None):
     clock = StartupClock(say)
     say("loading model...")
     max_batch = int(os.environ.get("PFANN_MAX_BATCH", "9728"))
+    import gc
+    gc.freeze()       # (imports -> the collector's permanent generation: no 50 ms full collection in the middle of the run)
     model_pt = os.path.join(params["model_dir"], "model.pt")
     engine = Engine(params, ranks.device if ranks is not None else 0, max_batch=max_batch)
     # kernel variants of a full launch group for every call: a song's fingerprints -- every byte of `embeddings` -- do not
@@ -479,7 +508,7 @@ def main(argv=None):
     if not engine.weights_loaded:             # (else: the start-up thread read model.pt and loaded it while torch was importing)
         engine.load_state_dict(torch.load(model_pt, map_location="cpu"))
     clock.lap("weights")
-    engine.warmup(windows=max_batch)
+    engine.warmup(windows=max_batch, group_hop=int(params["sample_rate"] * params["hop_size"]))
     clock.lap("engine warm-up")
     say("model loaded")
 

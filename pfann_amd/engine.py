@@ -192,15 +192,22 @@ class Engine:
                                                   self._stream()), "pfann_pcm16_to_mono")
         return out
 
-    def warmup(self, windows=512):
+    def warmup(self, windows=512, group_hop=0):
         """Allocates the activation workspace (max_batch segments: 29 GB at 9728) and makes the runtime load every
         kernel of the path by embedding `windows` windows of silence once.  The CLIs call it while "loading model...",
-        so that first-use costs are not billed to the first batch of files."""
+        so that first-use costs are not billed to the first batch of files.  group_hop (samples between the windows of
+        the files the tools are about to read): also reserve the device blocks a launch group of `windows` windows needs."""
         n = max(1, min(int(windows), int(self.cfg.max_batch)))
         wav = torch.zeros(self.seg_len + (n - 1) * 16, device=self.device, dtype=torch.float32)
         self.embed_windows(wav, np.arange(n, dtype=np.int64) * 16)
         self.pcm16_to_mono(torch.zeros((64, 1), dtype=torch.int16))
         torch.cuda.synchronize(self.device)
+        if group_hop:
+            # the caching allocator gets the blocks a launch group's PCM and mono signal will want (two groups in flight),
+            # so that the first groups of a run do not each stop for a hipMalloc (8-10 ms per new size)
+            samples = int(n * int(group_hop) * 1.12) + self.seg_len        # (every file ends on a partly used hop: 10 s -> 19 windows)
+            keep = [torch.empty(samples, dtype=dt, device=self.device) for dt in (torch.int16, torch.float32) for _ in range(2)]
+            del keep
 
     def set_fused_layernorm(self, on=True):
         """-> True if the LayerNorm-fused GEMM path is now active."""

@@ -31,6 +31,8 @@ def main(argv=None):
     say = print if rank0 else (lambda *a, **k: None)
     file_list_for_query, dir_for_db, out_embed_dir = argv[1], argv[2], argv[3]
     configs = os.path.join(dir_for_db, "configs.json")
+    import gc
+    gc.freeze()       # (imports -> the collector's permanent generation: no 50 ms full collection in the middle of the run)
     params = read_config(configs)
     say("loading model...")
     max_batch = int(os.environ.get("PFANN_MAX_BATCH", "9728"))

@@ -136,6 +136,32 @@ def upload_async(arr, device, dtype):
     return t.pin_memory().to(device, non_blocking=True)
 
 
+_hip = None
+
+
+def pinned_int16(n):
+    """-> torch int16 tensor of n elements in PINNED host memory, allocated by hipHostMalloc through ctypes: the call
+    releases the GIL.  `torch.empty(n, pin_memory=True)` holds it for the whole allocation -- 30-40 ms per 100 MB slab --
+    and when the tools' loader thread took its first slabs that way, the thread that feeds the GPU stood still for 43 ms at
+    the start of every run (PFANN_TIMELINE=1).  The memory is never freed: the slab pool lives as long as the process."""
+    global _hip
+    import torch
+    try:
+        if _hip is None:
+            _hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+            _hip.hipHostMalloc.argtypes = [POINTER(c_void_p), ctypes.c_size_t, ctypes.c_uint]
+            _hip.hipHostMalloc.restype = c_int
+        ptr = c_void_p()
+        if _hip.hipHostMalloc(ctypes.byref(ptr), int(n) * 2, 0) != 0 or not ptr.value:
+            raise OSError("hipHostMalloc failed")
+        t = torch.frombuffer((c_int16 * int(n)).from_address(ptr.value), dtype=torch.int16)
+        if not t.is_pinned():
+            raise OSError("the runtime does not report the block as pinned")
+        return t
+    except (OSError, AttributeError):
+        return torch.empty(int(n), dtype=torch.int16, pin_memory=True)
+
+
 def require_gpu():
     import torch
     if not torch.cuda.is_available():

@@ -33,6 +33,8 @@ def main(argv=None):
     rank0 = ranks is None or ranks.rank == 0
     say = print if rank0 else (lambda *a, **k: None)
     dir_for_query, dir_for_db, result_file = argv[1], argv[2], argv[3]
+    import gc
+    gc.freeze()       # (imports -> the collector's permanent generation: no 50 ms full collection in the middle of the run)
     params = read_config(os.path.join(dir_for_db, "configs.json"))
     file_list = read_file_list(os.path.join(dir_for_query, "queryList.txt"))
     d = params["model"]["d"]

@@ -9,6 +9,7 @@ searched (exact flat IP top-k) and sequence-matched on the MI355X, many queries 
 """
 import csv
 import ctypes
+import gc
 import os
 import sys
 import threading
@@ -140,6 +141,9 @@ def main(argv=None):
             db_box.append(x)
     db_thread = threading.Thread(target=load_db, name="pfann-db-load")
     db_thread.start()
+    # everything imported so far (torch: a million objects) goes to the collector's permanent generation: a full collection
+    # in the middle of the run -- it fell between the first and the second launch group, every time -- took 52 ms
+    gc.freeze()
     dataset = MusicDataset(file_list_for_query, params)
     engine = Engine(params, dev, max_batch=max_batch)
     # kernel variants of a full launch group for every call: a query's fingerprints -- and with them every byte of the
@@ -151,7 +155,7 @@ def main(argv=None):
     clock.lap("weights")
     # a short list never fills a launch group: warm up (and size the search workspace) for what will really come
     warm = min(max_batch, max(64, len(dataset) * int(os.environ.get("PFANN_WARMUP_SEGMENTS_PER_FILE", "19"))))
-    engine.warmup(windows=warm)
+    engine.warmup(windows=warm, group_hop=dataset.hop)
     clock.lap("engine warm-up")
     say("model loaded")
     say("loading database...")
@@ -215,9 +219,13 @@ def main(argv=None):
     for items in embed_file_batches(engine, dataset, dataset.hop, batch_windows=max_batch, timer=timer, ranks=ranks):
         if multi:
             items = gather_round(ranks, items, engine.d, engine.device)
+        _t = time.perf_counter()
         nxt = launch(items)
+        _t1 = time.perf_counter()
         if in_flight is not None:
             finish(in_flight)
+        if os.environ.get("PFANN_TIMELINE"):
+            print("timeline matcher: launch %.1f ms, finish of the previous group %.1f ms" % (1e3 * (_t1 - _t), 1e3 * (time.perf_counter() - _t1)), file=sys.stderr)
         in_flight = nxt
     if in_flight is not None:
         finish(in_flight)

@@ -10,6 +10,7 @@ import threading
 
 _thread = None
 _engine = None          # (handle, bytes of its pfann_config, device) built by the start-up thread, or None
+_pinned = []            # [(address, int16 elements)] pinned slabs allocated by the start-up thread for the file loader
 
 
 def _device():
@@ -50,6 +51,40 @@ def _engine_job(lib, job):
         lib.pfann_destroy(h)
 
 
+def slab_cap(n):
+    """size class of a launch group's PCM slab (int16 elements): the next multiple of 8 M samples (builder._PinnedPool)"""
+    return -(-int(n) // (1 << 23)) * (1 << 23)
+
+
+def _pinned_job(hiplib, job, count):
+    """`count` pinned slabs of the size a full launch group's PCM takes, allocated here -- while torch imports -- because a
+    pinned allocation of 84 MB takes 10-40 ms under a lock of the HIP runtime that stalls every launch of the process:
+    taken by the loader thread in the middle of the first groups, it cost a run 35-45 ms (PFANN_TIMELINE=1)."""
+    import json
+    configs_json, _model, max_batch = job
+    params = json.load(open(configs_json))
+    hop = int(params["sample_rate"] * params["hop_size"]) // max(1, int(params["indexer"].get("frame_shift_mul", 1)))
+    seg = int(params["sample_rate"] * params["segment_size"])
+    n = slab_cap(int(max_batch * hop * 1.06) + seg)
+    hiplib.hipHostMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_uint]
+    hiplib.hipHostMalloc.restype = ctypes.c_int
+    for _ in range(count):
+        ptr = ctypes.c_void_p()
+        if hiplib.hipHostMalloc(ctypes.byref(ptr), n * 2, 0) != 0 or not ptr.value:
+            break
+        _pinned.append((ptr.value, n))
+
+
+def take_pinned():
+    """-> [(address, int16 elements)] of the slabs the start-up thread allocated (waits for it); the caller owns them."""
+    if _thread is None:
+        return []
+    _thread.join()
+    got = list(_pinned)
+    del _pinned[:]
+    return got
+
+
 def take_engine(cfg, device):
     """-> the handle of the context the start-up thread built, if it built one for exactly this pfann_config on this
     device (waits for the thread); else None.  The caller owns the handle from then on."""
@@ -72,7 +107,7 @@ def take_engine(cfg, device):
     return None
 
 
-def _work(paths, job=None):
+def _work(paths, job=None, slabs=0):
     try:
         # torch ships its own HIP runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7): it has to be the one in the
         # process BEFORE libpfann_amd.so is loaded, or the library binds to /opt/rocm's copy and the process ends up with
@@ -82,7 +117,7 @@ def _work(paths, job=None):
         hip = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so") if spec else ""
         if not os.path.exists(hip):
             return                                    # an unknown torch layout: no prewarm rather than a second runtime
-        ctypes.CDLL(hip, mode=ctypes.RTLD_GLOBAL)
+        hiplib = ctypes.CDLL(hip, mode=ctypes.RTLD_GLOBAL)
         lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpfann_amd.so"))
         lib.pfann_prewarm.argtypes = [ctypes.c_int]
         lib.pfann_prewarm.restype = ctypes.c_int
@@ -91,6 +126,11 @@ def _work(paths, job=None):
             try:
                 _engine_job(lib, job)
             except Exception:                         # noqa: BLE001 -- any surprise: the ordinary path loads the model
+                pass
+            try:
+                if slabs > 0 and os.environ.get("PFANN_PREWARM_SLABS", "1") != "0":
+                    _pinned_job(hiplib, job, slabs)
+            except Exception:                         # noqa: BLE001 -- the loader then allocates its slabs itself
                 pass
     except (OSError, AttributeError, ImportError, ValueError):
         pass
@@ -121,15 +161,16 @@ def engine_job_for(tool, argv):
     return None
 
 
-def start(paths=(), engine=None):
+def start(paths=(), engine=None, slabs=3):
     """Idempotent; does nothing when this process is only going to launch ranks (PFANN_GPUS set, not yet a rank).
-    engine = (configs.json path, model.pt path, max_batch): also build the encoder context and load its weights."""
+    engine = (configs.json path, model.pt path, max_batch): also build the encoder context and load its weights, and
+    allocate `slabs` pinned PCM slabs for the file loader."""
     global _thread
     if _thread is not None or os.environ.get("PFANN_PREWARM", "1") == "0":
         return
     if os.environ.get("PFANN_GPUS") and "WORLD_SIZE" not in os.environ:
         return
-    _thread = threading.Thread(target=_work, args=(list(paths), engine), name="pfann-prewarm", daemon=True)
+    _thread = threading.Thread(target=_work, args=(list(paths), engine, slabs), name="pfann-prewarm", daemon=True)
     _thread.start()
 
 
