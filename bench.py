@@ -27,6 +27,7 @@ import argparse
 import json
 import os
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -44,6 +45,9 @@ PEAK_HBM = 8000.0            # GB/s
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+CLI_LEG_TIMEOUT_S = 1500            # per tool run of the CLI leg (tools/cli_bench.py) when bench.py starts it
 
 
 def cpu_baseline_leg(args, params, sd, shard, song_pos, q_pcm_mine, res, k, n_rows):
@@ -276,13 +280,17 @@ def main():
     if in_group:
         from pfann_amd.dist import quiet_stdout
         with quiet_stdout():                 # gloo announces its connections on stdout; stdout is the ONE JSON line
+            # the waits around rank 0's side legs (the CLI leg: two tool runs of up to CLI_LEG_TIMEOUT_S each) must outlast
+            # them: a barrier that gives up after the default 30 minutes would take the headline line with it
+            import datetime
+            long_wait = datetime.timedelta(seconds=2 * CLI_LEG_TIMEOUT_S + 1800)
             if backend == "nccl":
                 dist.init_process_group("nccl", device_id=dev)
             else:
-                dist.init_process_group(backend)
+                dist.init_process_group(backend, timeout=long_wait)
             # host-side waits that may last a minute (the CLI leg runs on rank 0 only) go through a gloo group: an RCCL
             # barrier would spin a kernel on the other ranks' GPUs for as long
-            meta_group = dist.new_group(backend="gloo") if backend != "gloo" else None
+            meta_group = dist.new_group(backend="gloo", timeout=long_wait) if backend != "gloo" else None
             dist.barrier(group=meta_group)   # (gloo connects lazily: make it talk now)
         seen = [None] * world
         dist.all_gather_object(seen, (rank, torch.cuda.current_device() if have_gpu else -1))
@@ -375,7 +383,7 @@ def main():
         builder_s += time.perf_counter() - tb
         builder_segs += len(ids) * SEG_PER_SONG
     index = DeviceIndex(d, local_rank)
-    index.load(shard, song_pos, r_lo)
+    index.load(shard, song_pos, r_lo, song_range=(s_lo, s_hi))
     use_sharded = world > 1 or emu > 1 or args.force_sharded
     if args.force_sharded and not in_group:
         log("bench.py: --force-sharded needs a process group (start with torch.distributed.run --nproc-per-node 1)")
@@ -438,8 +446,9 @@ def main():
             emb = emb.repeat(emu, 1)[: Q * QUERY_SEGS].contiguous()
             return sharded.query_batch(emb, w["qstart"], w["qlen"]), emb
         if use_sharded:
-            emb = sharded._timed("emb_allgather", all_gather_ragged, emb, w["q_counts"])
-            return sharded.query_batch(emb, w["qstart"], w["qlen"]), emb
+            with sharded.exchange(emb):             # (PFANN_EXCHANGE_STREAM=1: on the exchange stream; else a no-op)
+                emb = sharded._timed("emb_allgather", all_gather_ragged, emb, w["q_counts"])
+                return sharded.query_batch(emb, w["qstart"], w["qlen"]), emb
         D, I = cur_index[0].search(emb, k)
         res, _ = cur_index[0].match(emb, I, w["qstart"], w["qlen"])
         return res, emb
@@ -473,11 +482,21 @@ def main():
             self.used[i & 1].record()
             e = eng.embed_windows(wav, w["starts"])
             if use_sharded:
-                e = sharded._timed("emb_allgather", all_gather_ragged, e, w["q_counts"])
-                return sharded.query_batch(e, w["qstart"], w["qlen"], to_host=False), e
+                # the exchange of batch i (fingerprint all-gather, shard search, list exchange, merge, owner-side matcher,
+                # winner pick): with PFANN_EXCHANGE_STREAM=1 on a stream of its own, so that batch i+1's encoder -- issued
+                # on this stream by the next launch() -- does not queue behind the collectives
+                with sharded.exchange(e):
+                    e = sharded._timed("emb_allgather", all_gather_ragged, e, w["q_counts"])
+                    return sharded.query_batch(e, w["qstart"], w["qlen"], to_host=False), e
             D, I = cur_index[0].search(e, k)
             r, _ = cur_index[0].match(e, I, w["qstart"], w["qlen"], to_host=False)
             return r, e
+
+        def read_back(self, pend):
+            if use_sharded:
+                with sharded.on_exchange_stream():  # (the results were produced there; no wait for the next batch's encoder)
+                    return index.results_to_host(pend)
+            return index.results_to_host(pend)
 
         def run(self, n):
             self.upload(0)
@@ -489,10 +508,10 @@ def main():
                         self.cs.wait_event(self.used[(i + 1) & 1])   # batch i-1 has consumed the buffer batch i+1 lands in
                     self.upload(i + 1)
                 if pend is not None:
-                    res = index.results_to_host(pend)
+                    res = self.read_back(pend)
                 pend = r
             if pend is not None:
-                res = index.results_to_host(pend)
+                res = self.read_back(pend)
             return res, e
 
     def max_over_ranks(sec):
@@ -536,12 +555,14 @@ def main():
     n_seg = Q * QUERY_SEGS
     value = n_seg * args.steps / elapsed
     collectives = None
+    my_collectives = {}
     if use_sharded and prof:
         # event time of every collective of the exchange protocol (pfann_amd/dist.py: ShardedIndex._timed), per step,
         # the slowest rank's: bound all-gather, all-to-all of the shard lists, merge kernel, merged-slice all-gather,
         # winner-key all-gather, and the ragged all-gather of the step's fingerprints
         mine = sharded.timing_ms()
         sharded.timing = None
+        my_collectives = {nm: ms / args.steps for nm, ms in mine.items()}
         collectives = {nm: round(max_over_ranks(ms / args.steps), 4) for nm, ms in sorted(mine.items())}
         collectives["unit"] = "ms per step, max over ranks"
 
@@ -652,7 +673,7 @@ def main():
     alt = None
     if world == 1 and emu <= 1 and not use_sharded and not args.no_alt:
         idx16 = DeviceIndex(d, local_rank, storage="f16")
-        idx16.load(shard, song_pos, r_lo)
+        idx16.load(shard, song_pos, r_lo, song_range=(s_lo, s_hi))
         cur_index[0] = idx16
         step()
         torch.cuda.synchronize()
@@ -730,6 +751,42 @@ def main():
                                "db_rows": n_rows, "query_rows_per_step": Q * QUERY_SEGS,
                                "scan_ms_per_step_per_rank": [round(v, 4) for v in allms], "tags": sorted(SCAN_TAGS),
                                "TFLOPs_equivalent": float("%.4g" % (2.0 * d * n_rows * Q * QUERY_SEGS / (slowest * 1e-3) / 1e12))}
+    # ---- where a rank's step goes (N > 1: what to read off the first curve measured on real xGMI):
+    # event time of this rank's kernels by stage + event time of its collectives, against the step's wall time.  One
+    # stream (the default): the stages run back to back, so `unattributed` is launch gaps and waiting -- for the host, or
+    # inside a collective for a slower rank (a rank that arrives early at a collective sees its waiting as collective
+    # time: compare min and max over ranks).  PFANN_EXCHANGE_STREAM=1: the exchange overlaps the next batch's encoder
+    # and `unattributed` goes NEGATIVE by the overlap won.
+    critical_path = None
+    if prof:
+        def stage_of(tag):
+            if tag.startswith("scan_topk") or tag.startswith("topk_"):
+                return "scan"
+            if tag.startswith("seq_match") or tag.startswith("match_") or tag.startswith("song_scores"):
+                return "matcher"
+            return "encoder"
+        mine_cp = {"encoder": 0.0, "scan": 0.0, "matcher": 0.0}
+        for tag, kv in kernels.items():
+            mine_cp[stage_of(tag)] += kv["ms_per_step"]
+        mine_cp["collectives"] = sum(ms for nm, ms in my_collectives.items() if nm != "merge")    # (merge is a kernel: in `scan`)
+        step_ms = 1e3 * elapsed / args.steps
+        mine_cp["unattributed"] = step_ms - sum(mine_cp.values())
+        if in_group:
+            allcp = [None] * world
+            dist.all_gather_object(allcp, mine_cp)
+        else:
+            allcp = [mine_cp]
+        keys = ("encoder", "scan", "collectives", "matcher", "unattributed")
+        critical_path = {"unit": "ms per step", "step_ms": round(step_ms, 3),
+                         "max_over_ranks": {kk: round(max(c[kk] for c in allcp), 3) for kk in keys},
+                         "min_over_ranks": {kk: round(min(c[kk] for c in allcp), 3) for kk in keys},
+                         "per_rank": [{kk: round(c[kk], 3) for kk in keys} for c in allcp],
+                         "exchange_stream": bool(use_sharded and sharded.xs is not None),
+                         "what": "HIP-event time of each rank's kernels by stage (encoder = PCM conversion, log-mel, convs, head; "
+                                 "scan = every kernel of the exact top-k search incl. the sharded path's bound / merge kernels; "
+                                 "matcher = sequence match, key pack / pick) and of its collectives (fingerprint all-gather, bound "
+                                 "all-gather, list all-to-all, merged-slice all-gather, key all-gather), per step of the timed loop; "
+                                 "unattributed = step wall time minus their sum (negative when the exchange stream overlaps them)"}
     # roofline of the dominant kernel (most time in the timed region)
     ROOF = {"conv_gemm_ln_128": ("pfann::conv_gemm_ln_w22_kernel / conv_gemm_ln_kernel<128,128,64,32,...> (the 15 implicit-GEMM "
                                  "convs, 128x128 tiles, LayerNorm+ReLU of the input fused into the A-loader, LN statistics of the "
@@ -902,6 +959,31 @@ def main():
     parity = None
     if rank == 0 and world == 1 and not use_sharded and not args.no_cpu_baseline:
         cpu, parity = cpu_baseline_leg(args, params, sd, shard, song_pos, q_pcm_mine, res, k, n_rows)
+    # N > 1 lines carry the N = 1 run's cpu_baseline (the contract times it on rank 0 at N = 1 only: at N > 1 no rank holds the
+    # whole database): the driver runs N = 1, 2, 4, 8 back to back on one node, so the N = 1 run leaves its figure in the
+    # system temp dir; without one, the committed record of this round's N = 1 run is quoted, and says so
+    carry = os.path.join(tempfile.gettempdir(), "pfann_bench_cpu_baseline_n1.json")
+    job = {"db_songs": n_songs, "snr": args.snr}
+    if rank == 0 and cpu is not None and world == 1:
+        try:
+            json.dump({"job": job, "cpu_baseline": cpu}, open(carry, "w"))
+        except OSError:
+            pass
+    elif rank == 0 and cpu is None and world > 1 and not args.no_cpu_baseline:
+        import glob
+        committed = sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "bench.json")), reverse=True)
+        for src, label in [(carry, "the N = 1 run of this series on this node")] + \
+                [(f, os.path.relpath(f, REPO) + " (committed N = 1 run of the default job, another box)") for f in committed]:
+            try:
+                got = json.load(open(src))
+                if src == carry and got.get("job") != job:
+                    continue                       # (a reduced-workload run left it: not this job's baseline)
+                got = got.get("cpu_baseline")
+                if got and "value" in got:
+                    cpu = dict(got, carried_from=label, measured_in_this_run=False)
+                    break
+            except (OSError, ValueError):
+                continue
     if seam_before is not None:
         seam_info = dict(seam_after, before_fp16_leg={kk: seam_before[kk] for kk in ("gpu_call_us_median", "gpu_call_us_p95")})
     else:
@@ -914,7 +996,11 @@ def main():
         sys.path.insert(0, os.path.join(REPO, "tools"))
         import cli_bench
         try:
-            cli = cli_bench.run(args.cli_songs, args.cli_queries, args.snr, device=local_rank, log=log, gpus=world)
+            cli = cli_bench.run(args.cli_songs, args.cli_queries, args.snr, device=local_rank, log=log, gpus=world,
+                                tool_timeout_s=CLI_LEG_TIMEOUT_S)
+            if world > 1:
+                cli["gpus_shared_with_the_bench_ranks"] = ("the tools' %d ranks ran on the GPUs where this job's ranks still held "
+                                                           "their workspaces and database shards (idle, waiting at a barrier)" % world)
             if "builder" in cli:
                 cli["cli_builder_segments_per_s"] = cli["builder"]["segments_per_s"]
                 cli["cli_matcher_segments_per_s"] = cli["matcher"]["segments_per_s"]
@@ -964,7 +1050,7 @@ def main():
                              "inside the timed region"),
             "serial": serial,
             "hbm_resident": pcie, "seq_score_seam": seam_info, "cli": cli,
-            "alt_modes": alt, "other_scaling_mode": other_mode, "scan_throughput": scan_throughput, "collectives": collectives,
+            "alt_modes": alt, "other_scaling_mode": other_mode, "scan_throughput": scan_throughput, "critical_path": critical_path, "collectives": collectives,
             "kernels": {t: {kk: (float("%.4g" % vv) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                         for t, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
         }

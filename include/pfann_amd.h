@@ -300,6 +300,13 @@ int pfann_match(pfann_db *db, const float *q_dev, const int64_t *labels_dev, int
 /* Songs whose rows all live in this shard: [*song_lo, *song_hi) (either pointer may be NULL); returns their number. */
 int pfann_db_owned_songs(pfann_db *db, int *song_lo, int *song_hi);
 
+/* pfann_db_load derives the owned songs from the shard's row range; songs WITHOUT rows (unreadable files: builder.py
+ * writes a 0 into landmarkKey) that sit at a shard boundary are then ambiguous.  A caller that cut the song list itself
+ * (pfann_amd/dist.py: shard_songs) states its cut here, after pfann_db_load: [song_lo, song_hi) must span exactly the
+ * shard's rows (-3 otherwise).  Owner-side matching (PFANN_MATCH_ONLY_OWNED) and the owned score block
+ * (PFANN_MATCH_OWNED_BLOCK) then use this range. */
+int pfann_db_set_owned_songs(pfann_db *db, int song_lo, int song_hi);
+
 /* In place, for n_pairs (score, alignment) pairs of a song_scores block written by pfann_match: the alignment slot
  * goes from fine frames (t * frame_shift_mul - shift) to seconds.  native_path 0: (t - shift / frame_shift_mul) * hop_size
  * computed in double and stored as float32 -- what database.py:148,160 leaves in song_score[:, 1]; native_path 1: the

@@ -39,17 +39,21 @@ def _act(x, name):
     return Fn.relu(x) if name == "ReLU" else Fn.elu(x)
 
 
-def encode(mel, sd, params, norm=True, taps=None):
+def encode(mel, sd, params, norm=True, taps=None, dtype=np.float32):
     """mel [B,F,T]; sd: name -> numpy/torch tensors (reference state_dict names).
     taps: optional list that receives each of the 16 post-(LN,act) activations (NCHW numpy).
+    dtype: np.float32 = the reference's arithmetic (torch CPU fp32, what parity is judged against);
+    np.float64 = the SAME op sequence carried out in double on the float32 weights -- the "exact" value
+    tools/embedding_error_budget.py triangulates the GPU path and the fp32 oracle against (neither is the truth:
+    both round; this says by how much each).  The result keeps that dtype.
     """
     m = params["model"]
     act = m.get("conv_activation", "ReLU")
     after_bn = m.get("relu_after_bn", True)
     d, h, u, _, _ = model_dims(params)
-    g = lambda k: torch.as_tensor(np.asarray(sd[k], dtype=np.float32))
+    g = lambda k: torch.as_tensor(np.asarray(np.asarray(sd[k], dtype=np.float32), dtype=dtype))
     with torch.no_grad():
-        x = torch.as_tensor(np.asarray(mel, dtype=np.float32)).unsqueeze(1)   # model.py:102
+        x = torch.as_tensor(np.asarray(mel, dtype=dtype)).unsqueeze(1)         # model.py:102
         for i, L in enumerate(layer_plan(params)):
             p = "f.convs.%d." % i
             x = Fn.pad(x, (L["pad1"][0], L["pad1"][1], 0, 0))                  # model.py:56

@@ -859,6 +859,24 @@ int pfann_song_scores_to_seconds(pfann_db *db, float *song_scores_dev, int64_t n
     return launch_song_scores_to_seconds(song_scores_dev, n_pairs, frame_shift_mul, hop_size, native_path, (hipStream_t)stream);
 }
 
+int pfann_db_set_owned_songs(pfann_db *db, int song_lo, int song_hi) {
+    // the caller's own cut (pfann_amd/dist.py: shard_songs): songs without rows at a shard boundary belong to whichever side
+    // the CUT says, which the row range alone cannot tell
+    if (song_lo < 0 || song_hi < song_lo || song_hi > db->n_songs || (size_t)db->n_songs + 1 != db->song_pos_h.size()) {
+        set_error("db_set_owned_songs: [%d,%d) outside 0..%d", song_lo, song_hi, db->n_songs);
+        return -1;
+    }
+    if (db->song_pos_h[song_lo] != db->label_base || db->song_pos_h[song_hi] != db->label_base + db->n) {
+        set_error("db_set_owned_songs: songs [%d,%d) are rows [%lld,%lld), the shard holds [%lld,%lld)", song_lo, song_hi,
+                  (long long)db->song_pos_h[song_lo], (long long)db->song_pos_h[song_hi], (long long)db->label_base,
+                  (long long)(db->label_base + db->n));
+        return -3;
+    }
+    db->song_lo = song_lo;
+    db->song_hi = song_hi;
+    return 0;
+}
+
 int pfann_db_owned_songs(pfann_db *db, int *song_lo, int *song_hi) {
     if (song_lo) *song_lo = db->song_lo;
     if (song_hi) *song_hi = db->song_hi;

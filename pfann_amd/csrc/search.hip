@@ -520,6 +520,7 @@ __global__ __launch_bounds__(256) void group_max_select_kernel(const float *__re
 
 int launch_group_max_select(SearchWorkspace &ws, int64_t nq, int G, int k, int ncnt, bool with_eps, float margin, hipStream_t s,
                             float *topm = nullptr, int mtop = 0, float margin_out = 0.f, int *zero_me = nullptr) {
+    if (G < 1 || G > 4096) { set_error("group select: %d groups (the kernel's LDS array holds 4096)", G); return -1; }
     ProfScope ps("topk_group_select", s);
     PF_LAUNCH(group_max_select_kernel, dim3((unsigned)nq), dim3(256), 0, s, reinterpret_cast<const float *>(ws.cl), G, k, ws.thr,
               ws.cnt, ncnt, with_eps ? ws.eps : nullptr, ws.thr_adj, margin, topm, mtop, margin_out, zero_me);

@@ -518,7 +518,7 @@ int launch_scan_f16_gmax(const void *dbh, int64_t n, int d, int64_t stride, cons
     const int s_cap = std::max(std::max(8, (5 * k + 63) / 64), (int)(1024 / p.n_tiles_m));
     if (S > s_cap) S = s_cap;
     static const int gs_env = getenv("PFANN_GMAX_S") ? atoi(getenv("PFANN_GMAX_S")) : 0;      // tuning aid: slices of the sampled pass
-    if (gs_env > 0) S = gs_env;
+    if (gs_env > 0) S = gs_env > 64 ? 64 : gs_env;       // (G = 64 S groups: the group select holds at most 4096 of them)
     if (S > db_tiles) S = (int)db_tiles;
     const int G = S * 64;                    // one group per (slice, row position in the 128-row tile up to the lane half)
     if (G < 4 * k || db_tiles < 4 * (int64_t)S) return 1;      // >= 4 rows per group

@@ -7,6 +7,7 @@ matcher run as HIP kernels (csrc/search.hip, csrc/rerank.hip).  `query_batch` ex
 batched form the CLIs and bench use; `query_embeddings` keeps the reference's per-query
 contract, python-path semantics (cpp_accelerate=False, database.py:12).
 """
+import contextlib
 import ctypes
 import json
 import os
@@ -52,8 +53,10 @@ class DeviceIndex:
         if h:
             self.lib.pfann_db_destroy(h)
 
-    def load(self, emb, song_pos, label_base=0):
-        """emb: float32 [n, d] numpy (host) or torch cuda tensor; song_pos: GLOBAL int64 prefix sums."""
+    def load(self, emb, song_pos, label_base=0, song_range=None):
+        """emb: float32 [n, d] numpy (host) or torch cuda tensor; song_pos: GLOBAL int64 prefix sums.  song_range: the
+        caller's own cut (song_lo, song_hi) of the song list when it made one (dist.shard_songs) -- songs without rows at
+        a shard boundary belong to the side the cut says; by default the library derives the songs from the rows."""
         song_pos = np.ascontiguousarray(song_pos, dtype=np.int64)
         self.song_pos = song_pos
         self.n_songs = song_pos.shape[0] - 1
@@ -69,6 +72,9 @@ class DeviceIndex:
                                         self.n_songs, label_base), "pfann_db_load")
         self.ntotal = n
         self.label_base = label_base
+        if song_range is not None:
+            _l.check(self.lib.pfann_db_set_owned_songs(self.handle, int(song_range[0]), int(song_range[1])),
+                     "pfann_db_set_owned_songs")
 
     def set_prefilter(self, on=True):
         """fp16 pre-filter of the batched scan (exact result either way) -> True if in use."""
@@ -268,6 +274,35 @@ def _fine_to_time(fine, fsm, hop_size):
 cpp_accelerate = os.environ.get("PFANN_CPP_ACCELERATE", "0") not in ("0", "")
 
 
+class LazyLaunches:
+    """[(j0, j1)] cuts + launch(j0, j1) -> iterable of (j0, j1, launch result) with the first launch made at once and
+    every later one made when its predecessor is handed out (so: one ahead of what the consumer is reading back)."""
+
+    def __init__(self, cuts, launch):
+        self._cuts, self._launch, self._next, self._ready = list(cuts), launch, 0, []
+        self.max_in_flight = 0                       # (for the tests: launched and not yet handed out + the one handed out)
+        if self._cuts:
+            self._start_one()
+
+    def _start_one(self):
+        j0, j1 = self._cuts[self._next]
+        self._next += 1
+        self._ready.append((j0, j1, self._launch(j0, j1)))
+
+    def __len__(self):
+        return len(self._cuts)
+
+    def __iter__(self):
+        while self._ready or self._next < len(self._cuts):
+            if not self._ready:
+                self._start_one()
+            cur = self._ready.pop(0)
+            if self._next < len(self._cuts):
+                self._start_one()                    # the successor is in flight before `cur` is read back
+            self.max_in_flight = max(self.max_in_flight, 1 + len(self._ready))
+            yield cur
+
+
 class Database:
     def __init__(self, dir_for_db, indexer_params, hop_size, device=0, d=None, storage=None, ranks=None):
         """ranks: a pfann_amd.dist.Ranks (one process per GPU).  With more than one rank (or PFANN_FORCE_SHARDED=1) the
@@ -323,7 +358,11 @@ class Database:
         if storage is None:
             storage = os.environ.get("PFANN_DB_STORAGE") or ("f16" if self.params.get("use_float16", False) else "f32")
         self.index = DeviceIndex(self.d, device, storage)
-        self.index.load(emb, self.song_pos, r_lo)
+        # ONE statement of which songs this process owns: the cut made above (0-row songs at a shard boundary cannot be
+        # told from the row range), handed to the library and read back
+        self.index.load(emb, self.song_pos, r_lo, song_range=self.song_range if self.ranks is not None else None)
+        if self.ranks is not None:
+            assert self.index.owned_songs() == tuple(self.song_range), (self.index.owned_songs(), self.song_range)
         self.sharded = None
         if self.ranks is not None:
             from .dist import ShardedIndex
@@ -353,41 +392,49 @@ class Database:
         dev = self.index.device
         if mode is None:
             mode = 1 if cpp_accelerate else 0
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        ev[0].record()
-        if self.sharded is not None:
-            # song-sharded: two-phase shard search + all-to-all merge (`search`), owner-side match + 128-bit key
-            # all-gather + device pick (`rerank`); `res` are the winners over ALL shards, `ss` this shard's columns
-            D, I = self.sharded.search_global(emb)
-            ev[1].record()
-            res, ss = self.sharded.match_global(emb, I, qstart, qlen, want_song_scores, mode)
-        else:
-            D, I = self.index.search(emb, self.top_k)
-            ev[1].record()
-            res, ss = self.index.match(emb, I, qstart, qlen, self.frame_shift_mul, self.score_alpha, mode,
-                                       False, want_song_scores, to_host=False)
-        ev[2].record()
-        # frames -> seconds where the block lives (database.py:148,193 do it on the host): (t - shift/fsm) * hop_size
-        # with fine = t*fsm - shift, in double like the reference's Python floats, stored as float32
-        self.index.song_scores_to_seconds(ss, self.frame_shift_mul, self.hop_size, native_path=mode == 1)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] + [torch.cuda.Event()]
+        # song-sharded, PFANN_EXCHANGE_STREAM=1: search, collectives, matcher and winner pick run on the exchange stream
+        # (dist.ShardedIndex.exchange), so the next group's encoder does not queue behind the collectives
+        with (self.sharded.exchange(emb) if self.sharded is not None else contextlib.nullcontext()):
+            ev[0].record()
+            if self.sharded is not None:
+                # two-phase shard search + all-to-all merge (`search`), owner-side match + 128-bit key all-gather +
+                # device pick (`rerank`); `res` are the winners over ALL shards, `ss` this shard's columns
+                D, I = self.sharded.search_global(emb)
+                ev[1].record()
+                res, ss = self.sharded.match_global(emb, I, qstart, qlen, want_song_scores, mode)
+            else:
+                D, I = self.index.search(emb, self.top_k)
+                ev[1].record()
+                res, ss = self.index.match(emb, I, qstart, qlen, self.frame_shift_mul, self.score_alpha, mode,
+                                           False, want_song_scores, to_host=False)
+            ev[2].record()
+            # frames -> seconds where the block lives (database.py:148,193 do it on the host): (t - shift/fsm) * hop_size
+            # with fine = t*fsm - shift, in double like the reference's Python floats, stored as float32
+            self.index.song_scores_to_seconds(ss, self.frame_shift_mul, self.hop_size, native_path=mode == 1)
+            ev[3].record()              # (the block is complete HERE, not at ev[2]: query_finish copies it after this one)
         return {"res": res, "ss": ss, "ev": ev, "nq": len(qlen), "keep": (emb, I), "dev": dev, "mode": mode}
 
     def query_launch_chunks(self, emb, qstart, qlen, want_song_scores=False, mode=None):
         """query_launch over as many sub-launches as the score-block budget asks for (PFANN_SCORE_BLOCK_MB, default
         1024: one-segment queries against a 100 k-song database would otherwise want 7.8 GB of HBM and as much pinned
-        host memory per launch group).  -> [(first query, one past the last, launch)]"""
+        host memory per launch group).  -> an iterable of (first query, one past the last, launch), LAZY beyond its first
+        element: sub-launch 0 is in flight when this returns (the CLIs launch group g+1 before they read group g back),
+        sub-launch i+1 is launched when the consumer asks for sub-launch i, i.e. just before it reads i back.  At most
+        three score blocks of max_score_pairs pairs therefore exist at any time -- the one being read back, its
+        successor, and the first one of the next launch group -- whatever the number of sub-launches (all of them at
+        once until round 5: the budget then bounded only the pinned landing buffer)."""
         nq = len(qlen)
         width = max(getattr(self, "_widest_shard", self.song_range[1] - self.song_range[0]), 1)
-        step = nq if not want_song_scores else max(1, min(nq, self.max_score_pairs // width))
+        step = max(1, nq) if not want_song_scores else max(1, min(nq, self.max_score_pairs // width))
         qstart = np.asarray(qstart, dtype=np.int64)
-        out = []
-        for j0 in range(0, nq, step):
-            j1 = min(j0 + step, nq)
+
+        def launch(j0, j1):
             r0 = int(qstart[j0])
             r1 = int(qstart[j1 - 1]) + int(qlen[j1 - 1])
             sub = emb if (j0 == 0 and j1 == nq) else emb[r0:r1]
-            out.append((j0, j1, self.query_launch(sub, qstart[j0:j1] - r0, qlen[j0:j1], want_song_scores, mode)))
-        return out
+            return self.query_launch(sub, qstart[j0:j1] - r0, qlen[j0:j1], want_song_scores, mode)
+        return LazyLaunches([(j0, min(j0 + step, nq)) for j0 in range(0, nq, step)], launch)
 
     def _pinned(self, shape, dtype):
         """one reusable pinned landing buffer per result kind (a pinned allocation costs milliseconds)"""
@@ -407,7 +454,7 @@ class Database:
             self._copy_stream = torch.cuda.Stream(p["dev"])
             self._pin = {}
         with torch.cuda.stream(self._copy_stream):
-            self._copy_stream.wait_event(p["ev"][2])
+            self._copy_stream.wait_event(p["ev"][-1])
             ss_np = None
             if p["ss"] is not None:
                 land = self._pinned(p["ss"].shape, torch.float32)
@@ -455,7 +502,8 @@ class Database:
             from .dist import all_gather_ragged, shard_songs
             p = self.query_launch(q, [0], [q.shape[0]], want_song_scores=True)
             counts = [hi - lo for lo, hi in shard_songs(self.song_pos, self.ranks.world)]
-            full = all_gather_ragged(p["ss"][0], counts, self.ranks.group).cpu().numpy()
+            with self.sharded.on_exchange_stream():         # (the block was produced there when the exchange stream is on)
+                full = all_gather_ragged(p["ss"][0], counts, self.ranks.group).cpu().numpy()
             p["ss"] = None
             (score, best_song_t, _), = self.query_finish(p)
             return score, best_song_t, full

@@ -169,6 +169,30 @@ def all_gather_ragged(x, counts, group=None):
     return torch.cat([g[r, : counts[r]] for r in range(world)], dim=0)
 
 
+class _ExchangeScope:
+    def __init__(self, stream, tensors, join):
+        self.stream, self.tensors, self.join, self.ctx = stream, tensors, join, None
+
+    def __enter__(self):
+        if self.stream is None:
+            return self
+        if self.join:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.stream.wait_event(ev)
+            for t in self.tensors:
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(self.stream)
+        self.ctx = torch.cuda.stream(self.stream)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
+        return False
+
+
 class ShardedIndex:
     def __init__(self, backend, song_pos, top_k, frame_shift_mul=1, score_alpha=0.0, group=None, always_exchange=False):
         """always_exchange: run the whole exchange protocol (bound all-gather, all-to-all, merge, all-gathers) even when
@@ -183,6 +207,26 @@ class ShardedIndex:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.timing = None          # a dict: every collective of the protocol is then bracketed by a pair of timing events
+        # PFANN_EXCHANGE_STREAM=1 (round 5; default off until it has been measured on xGMI): the exchange of batch i --
+        # shard search, collectives, merge, owner-side matcher, winner pick -- runs on a stream of its own, so that the
+        # encoder of batch i+1 (issued on the caller's stream) does not queue behind the collectives.  Callers bracket the
+        # exchange with `with sharded.exchange(emb):` and read its results under `with sharded.on_exchange_stream():`
+        # (or through events recorded inside the block).  Same kernels, same order within the exchange: same bytes out.
+        self.xs = None
+        if os.environ.get("PFANN_EXCHANGE_STREAM", "0") not in ("0", "") and torch.cuda.is_available() and hasattr(backend, "device"):
+            self.xs = torch.cuda.Stream(device=backend.device)
+
+    def exchange(self, *tensors):
+        """Context: what is launched inside belongs to the exchange of one batch.  With the exchange stream on, that stream
+        first waits for everything the current stream has queued so far (the fingerprints `tensors` were produced there:
+        they are marked as in use on the exchange stream), then becomes the current stream.  Nothing joins back at the
+        end: consumers wait on events recorded inside, or read under on_exchange_stream()."""
+        return _ExchangeScope(self.xs, tensors, join=True)
+
+    def on_exchange_stream(self):
+        """Context: the exchange stream is current (no wait on the caller's stream) -- for reading an exchange's results
+        back without queueing the copy behind the NEXT batch's encoder."""
+        return _ExchangeScope(self.xs, (), join=False)
 
     def _timed(self, name, fn, *a):
         """runs one collective; with self.timing set, between two events on the current stream (the collective's own

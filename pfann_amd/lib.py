@@ -79,6 +79,7 @@ SYMBOLS = {
     "pfann_match": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int,
                             c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pfann_db_owned_songs": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
+    "pfann_db_set_owned_songs": (c_int, [c_void_p, c_int, c_int]),
     "pfann_song_scores_to_seconds": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_double, c_int, c_void_p]),
     "pfann_match_pack": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "pfann_match_pick": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
@@ -151,11 +152,15 @@ def pinned_int16(n):
             _hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
             _hip.hipHostMalloc.argtypes = [POINTER(c_void_p), ctypes.c_size_t, ctypes.c_uint]
             _hip.hipHostMalloc.restype = c_int
+            _hip.hipHostFree.argtypes = [c_void_p]
+            _hip.hipHostFree.restype = c_int
         ptr = c_void_p()
         if _hip.hipHostMalloc(ctypes.byref(ptr), int(n) * 2, 0) != 0 or not ptr.value:
             raise OSError("hipHostMalloc failed")
         t = torch.frombuffer((c_int16 * int(n)).from_address(ptr.value), dtype=torch.int16)
         if not t.is_pinned():
+            del t
+            _hip.hipHostFree(ptr)              # (the fallback below allocates its own block: this one must not leak)
             raise OSError("the runtime does not report the block as pinned")
         return t
     except (OSError, AttributeError):

@@ -105,7 +105,7 @@ def test_two_rank_default_is_the_same_job_strong_scaling_with_scan_throughput_an
     of every collective of the exchange protocol, the weak-scaling figure as the side key, and a CLI leg run by the
     tools' own 2 ranks.  2 ranks on this box's one GPU (gloo-staged collectives)."""
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--queries", "48", "--db-songs", "600", "--no-cpu-baseline", "--max-batch", "512", "--cli-songs", "60",
+                        "--queries", "48", "--db-songs", "600", "--max-batch", "512", "--cli-songs", "60",
                         "--cli-queries", "12"],
                        capture_output=True, text=True, timeout=1200, cwd=REPO,
                        env=_clean_env(PFANN_DIST_BACKEND="gloo", PFANN_FORCE_DEVICE="0", PFANN_MAX_BATCH="512"))
@@ -119,6 +119,18 @@ def test_two_rank_default_is_the_same_job_strong_scaling_with_scan_throughput_an
     col = out["collectives"]
     for name in ("emb_allgather", "bound_allgather", "all_to_all", "merge", "slice_allgather", "key_allgather"):
         assert col[name] > 0, name
+    # round 5: where each rank's step goes (what the first curve on real xGMI is to be read with), max and min over ranks
+    cp = out["critical_path"]
+    assert len(cp["per_rank"]) == 2 and cp["exchange_stream"] is False and cp["step_ms"] == out["ms_per_step"]
+    for side in ("max_over_ranks", "min_over_ranks"):
+        assert set(cp[side]) == {"encoder", "scan", "collectives", "matcher", "unattributed"}
+        assert cp[side]["encoder"] > 0 and cp[side]["scan"] > 0 and cp[side]["collectives"] > 0 and cp[side]["matcher"] > 0
+    assert all(cp["max_over_ranks"][kk] >= cp["min_over_ranks"][kk] for kk in cp["max_over_ranks"])
+    assert abs(sum(cp["per_rank"][0].values()) - cp["step_ms"]) < 0.01
+    # ... and the N = 1 CPU baseline travels with the N > 1 line (timed at N = 1 only: no rank holds the whole db here)
+    cb = out["cpu_baseline"]
+    assert cb is not None and cb["measured_in_this_run"] is False and cb["value"] > 0 and cb["carried_from"]
+    assert "gpus_shared_with_the_bench_ranks" in out["cli"]
     om = out["other_scaling_mode"]
     assert om["scaling"] == "weak" and om["queries_per_step"] == 12 and om["value"] > 0
     cli = out["cli"]
@@ -181,3 +193,17 @@ def test_rccl_collectives_of_the_sharded_path_on_one_gpu(tmp_path):
     assert out["backend"] == "nccl" and out["ranks_seen"] == 1 and out["n_gpus"] == 1
     a, b = np.load(one), np.load(two)
     assert np.array_equal(a[:, :2], b[:, :2]) and np.abs(a[:, 2] - b[:, 2]).max() < 1e-6
+    # PFANN_EXCHANGE_STREAM=1 (round 5): the same exchange on a stream of its own, three batches two deep, so that batch
+    # i+1's encoder really runs beside batch i's collectives -- the same bytes out as with the flag off
+    xs_on, xs_off = str(tmp_path / "xs_on.npy"), str(tmp_path / "xs_off.npy")
+    for flag, path in (("1", xs_on), ("0", xs_off)):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                            "--master-addr", "127.0.0.1", "--master-port", "29743", os.path.join(REPO, "bench.py"),
+                            "--gpus", "1", "--force-sharded", "--steps", "3", "--warmup", "1", "--db-songs", "600", "--queries", "24",
+                            "--no-cpu-baseline", "--no-cli", "--no-alt", "--max-batch", "512", "--dump-decisions", path],
+                           capture_output=True, text=True, timeout=900, cwd=REPO,
+                           env=_clean_env(MASTER_ADDR="127.0.0.1", PFANN_EXCHANGE_STREAM=flag))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+        assert line["critical_path"]["exchange_stream"] is (flag == "1")
+    assert np.array_equal(np.load(xs_on), np.load(xs_off)) and np.array_equal(np.load(xs_on), b)

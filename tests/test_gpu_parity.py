@@ -1027,3 +1027,39 @@ def test_sharded_search_wave_reductions_vs_the_sorting_kernel(G, m, k):
     Do, Io = ix.merge_topk(S, L, k)
     assert torch.equal(Dn, Do) and torch.equal(In, Io)
     assert bool((In[3] == -1).all())
+
+
+def test_owned_songs_follow_the_callers_cut_at_a_rowless_boundary_song(torch_cuda):
+    """song_pos = [0, 10, 10, 20] cut for two ranks by dist.shard_songs gives rank 0 the songs (0, 1) and
+    rank 1 the ROWLESS song 1 with song 2 -- while the library, deriving the songs from the row range [0, 10), used to
+    claim (0, 2) for rank 0: its owned score block was then one column wider than Database.song_range.  The cut is now
+    stated once (pfann_db_set_owned_songs) and used by the owner-side matcher and the owned block alike."""
+    torch = torch_cuda
+    from pfann_amd import lib as L
+    from pfann_amd.database import DeviceIndex
+    from pfann_amd.dist import shard_songs
+    pos = np.array([0, 10, 10, 20], np.int64)
+    cut = shard_songs(pos, 2)
+    assert cut == [(0, 1), (1, 3)]
+    z = synth.unit_rows(3, "rows", 20, 128)
+    shards = []
+    for lo, hi in cut:
+        ix = DeviceIndex(128, 0)
+        ix.load(z[pos[lo]:pos[hi]], pos, int(pos[lo]))
+        derived = ix.owned_songs()
+        ix.load(z[pos[lo]:pos[hi]], pos, int(pos[lo]), song_range=(lo, hi))
+        assert ix.owned_songs() == (lo, hi)
+        shards.append((ix, derived))
+    assert shards[0][1] == (0, 2)                                   # what the row range alone says: the ambiguity
+    q = torch.as_tensor(z[12:17]).cuda()                            # song 2, offset 2
+    I = torch.arange(10, 20, dtype=torch.int64).repeat(5, 1).cuda()
+    for (ix, _), (lo, hi) in zip(shards, cut):
+        res, ss = ix.match(q, I, [0], [5], 1, 0.0, 0, True, True, owned_block=True)
+        assert ss.shape == (1, hi - lo, 2)
+        if lo == 1:
+            assert int(res[0]["song"]) == 2 and int(res[0]["offset"]) == 2 and abs(float(ss[0, 1, 0]) - 1.0) < 1e-6
+            assert float(ss[0, 0].abs().sum()) == 0.0             # the rowless song's column
+        else:
+            assert int(res[0]["song"]) == -1
+    with pytest.raises(L.PfannError):                               # a cut that does not span the shard's rows
+        shards[0][0].load(z[0:10], pos, 0, song_range=(0, 3))

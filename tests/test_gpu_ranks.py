@@ -15,7 +15,8 @@ from pfann_amd import synth
 
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DROP = ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PFANN_DIST_BACKEND", "PFANN_FORCE_DEVICE", "PFANN_GPUS", "PFANN_FORCE_SHARDED")
+DROP = ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PFANN_DIST_BACKEND", "PFANN_FORCE_DEVICE", "PFANN_GPUS", "PFANN_FORCE_SHARDED",
+        "PFANN_EXCHANGE_STREAM")
 
 
 def _env(**kw):
@@ -189,6 +190,13 @@ def test_600_songs_two_ranks_byte_identical_and_rccl_world1(tmp_path):
            "--master-port", "29761", os.path.join(REPO, "matcher.py"), qlist, db1, r3]
     _run(cmd, tmp, env)
     _results_equal(r1, r3)
+    # PFANN_EXCHANGE_STREAM=1 (round 5): search, collectives, matcher and winner pick of a launch group on a stream of their
+    # own (the next group's encoder then runs beside them) -- flag on == flag off, under 2 gloo ranks and through RCCL
+    r4, r5 = os.path.join(tmp, "r4.txt"), os.path.join(tmp, "r5.txt")
+    _run(_tool("matcher.py") + [qlist, db1, r4], tmp, _two_ranks(PFANN_EXCHANGE_STREAM="1", **common))
+    _results_equal(r1, r4)
+    _run(cmd[:-1] + [r5], tmp, dict(env, PFANN_EXCHANGE_STREAM="1"))
+    _results_equal(r1, r5)
     # Database's per-query contract under ranks: the reference's tuple, whole [n_songs, 2] block, on every rank
     worker = os.path.join(tmp, "dbworker.py")
     open(worker, "w").write(DB_WORKER)

@@ -699,3 +699,28 @@ def test_ptfile_reads_a_state_dict_without_torch(tmp_path):
                         "pfann_amd.prewarm, pfann_amd.launch; print('torch' in sys.modules)" % REPO],
                        capture_output=True, text=True, timeout=120)
     assert r.stdout.strip() == "False", r.stdout + r.stderr
+
+
+def test_lazy_launches_keep_at_most_one_sub_launch_ahead():
+    """query_launch_chunks used to launch every sub-launch of a group before any was finished, so all
+    their score blocks existed at once.  LazyLaunches makes the first launch at construction (the CLIs launch group g+1
+    before reading group g back) and each later one when its predecessor is handed out."""
+    from pfann_amd.database import LazyLaunches
+    live, log = [], []
+
+    def launch(j0, j1):
+        live.append((j0, j1))
+        log.append(("launch", j0, len(live)))
+        return "p%d" % j0
+    cuts = [(0, 4), (4, 8), (8, 12), (12, 13)]
+    ll = LazyLaunches(cuts, launch)
+    assert len(ll) == 4 and live == [(0, 4)]                     # only the first is in flight
+    seen = []
+    for j0, j1, p in ll:
+        assert p == "p%d" % j0 and len(live) <= 2                # the one handed out + its successor
+        seen.append((j0, j1))
+        live.remove((j0, j1))                                    # "query_finish": read back, block released
+    assert seen == cuts and ll.max_in_flight == 2 and not live
+    assert list(LazyLaunches([], launch)) == []
+    one = LazyLaunches([(0, 3)], launch)
+    assert [c[:2] for c in one] == [(0, 3)] and one.max_in_flight == 1

@@ -83,7 +83,7 @@ def parse_stdout(text):
     return stages, total
 
 
-def run(n_songs=10000, n_queries=2000, snr=0.0, device=0, keep=False, workdir=None, log=print, gpus=1):
+def run(n_songs=10000, n_queries=2000, snr=0.0, device=0, keep=False, workdir=None, log=print, gpus=1, tool_timeout_s=3600):
     """gpus > 1: both tools are started with PFANN_GPUS=gpus and launch their own ranks, one per GPU (the database is
     then built by, and sharded over, all of them)."""
     import torch
@@ -154,7 +154,7 @@ def run(n_songs=10000, n_queries=2000, snr=0.0, device=0, keep=False, workdir=No
         # ---- builder
         t0 = time.time()
         r = subprocess.run([sys.executable, os.path.join(REPO, "builder.py"), mlist, db, mdir], capture_output=True,
-                           text=True, env=dict(env, PFANN_T0=repr(t0)), cwd=work, timeout=3600)
+                           text=True, env=dict(env, PFANN_T0=repr(t0)), cwd=work, timeout=tool_timeout_s)
         wall = time.time() - t0
         if r.returncode != 0:
             raise RuntimeError("builder.py failed:\n" + r.stdout[-2000:] + r.stderr[-3000:])
@@ -171,7 +171,7 @@ def run(n_songs=10000, n_queries=2000, snr=0.0, device=0, keep=False, workdir=No
         result = os.path.join(work, "result.txt")
         t0 = time.time()
         r = subprocess.run([sys.executable, os.path.join(REPO, "matcher.py"), qlist, db, result], capture_output=True,
-                           text=True, env=dict(env, PFANN_T0=repr(t0)), cwd=work, timeout=3600)
+                           text=True, env=dict(env, PFANN_T0=repr(t0)), cwd=work, timeout=tool_timeout_s)
         wall = time.time() - t0
         if r.returncode != 0:
             raise RuntimeError("matcher.py failed:\n" + r.stdout[-2000:] + r.stderr[-3000:])

@@ -80,7 +80,7 @@ def run(n_songs, n_queries, snr, workers=16, config="default", plan=9728, max_ba
     handles = []
     for lo, hi in (shard_songs(song_pos, shards) if shards > 1 else [(0, n_songs)]):
         ix = DeviceIndex(d, 0)
-        ix.load(shard[int(song_pos[lo]):int(song_pos[hi])], song_pos, int(song_pos[lo]))
+        ix.load(shard[int(song_pos[lo]):int(song_pos[hi])], song_pos, int(song_pos[lo]), song_range=(lo, hi))
         handles.append(ix)
     index = handles[0]
     per = max(1, max_batch // QSEG)

@@ -37,15 +37,21 @@ def worker(work, w, W):
     sd = dict(np.load(os.path.join(work, "weights.npz")))
     db = np.load(os.path.join(work, "db.npy"), mmap_mode="r")          # shared page cache: no per-process copy (3 GB at config 4)
     song_pos = np.load(os.path.join(work, "song_pos.npy"))
-    pcm = np.load(os.path.join(work, "q_pcm.npy"), mmap_mode="r")
+    files = json.load(open(os.path.join(work, "q_files.json"))) if os.path.exists(os.path.join(work, "q_files.json")) else None
+    pcm = np.load(os.path.join(work, "q_pcm.npy"), mmap_mode="r") if files is None else None
+    n_q = len(files) if files is not None else pcm.shape[0]
+    keep_ss = bool(meta.get("keep_song_scores"))
     emb_gpu = np.load(os.path.join(work, "q_emb_gpu.npy"), mmap_mode="r") if os.path.exists(os.path.join(work, "q_emb_gpu.npy")) else None
-    js = list(range(w, pcm.shape[0], W))
-    out = {"j": [], "song": [], "sec": [], "score": [], "emb_err": [], "kth": [], "next": [], "runner_up": [], "labels": []}
+    js = list(range(w, n_q, W))
+    out = {"j": [], "song": [], "sec": [], "score": [], "emb_err": [], "kth": [], "next": [], "runner_up": [], "labels": [], "ss": []}
     st = [0.0, 0.0, 0.0]
     t_begin = time.time()
     for j in js:
         t0 = time.perf_counter()
-        segs = osg.segment(osg.pcm_to_mono(np.asarray(pcm[j])[:, None]), 8000, HOP)
+        if files is not None:                             # the oracle reads the WAV file itself (oracle/segmenter.py)
+            segs = osg.load_segments(files[j], params)
+        else:
+            segs = osg.segment(osg.pcm_to_mono(np.asarray(pcm[j])[:, None]), 8000, HOP)
         e = oe.encode(om.melspec(segs, params), sd, params)
         t1 = time.perf_counter()
         D, I = osr.flat_ip_topk_blas(e, db, k + 1)
@@ -60,10 +66,173 @@ def worker(work, w, W):
         out["j"].append(j), out["song"].append(song), out["sec"].append(sec), out["score"].append(sc)
         out["kth"].append(D[:, k - 1].copy()), out["next"].append(D[:, k].copy()), out["runner_up"].append(float(two[0]))
         out["labels"].append(I[:, :k].copy())
+        if keep_ss:
+            out["ss"].append(ss)
+    if keep_ss:
+        np.save(os.path.join(work, "ss_%d.npy" % w), np.asarray(out["ss"], np.float32).reshape(len(js), -1, 2))
     np.savez(os.path.join(work, "res_%d.npz" % w), j=np.asarray(out["j"]), song=np.asarray(out["song"]), sec=np.asarray(out["sec"]),
              score=np.asarray(out["score"]), emb_err=np.asarray(out["emb_err"]), kth=np.asarray(out["kth"]),
              next=np.asarray(out["next"]), runner_up=np.asarray(out["runner_up"]), labels=np.asarray(out["labels"]),
              stages=np.asarray(st), span=np.asarray([t_begin, time.time()]))
+
+
+def embed_worker(work, w, W):
+    """Fingerprints only, three ways (tools/embedding_error_budget.py): fp32 oracle, the same op sequence in float64 from
+    the float64 log-mel, and float64 from the fp32 log-mel (separates the front-end's share)."""
+    import torch
+    torch.set_num_threads(int(os.environ.get("PFANN_ORACLE_THREADS", "8")))
+    from oracle import encoder as oe
+    from oracle import melspec as om
+    from oracle import segmenter as osg
+    meta = json.load(open(os.path.join(work, "meta.json")))
+    params = meta["params"]
+    sd = dict(np.load(os.path.join(work, "weights.npz")))
+    pcm = np.load(os.path.join(work, "q_pcm.npy"), mmap_mode="r")
+    js = list(range(w, pcm.shape[0], W))
+    e32, e64, e64m = [], [], []
+    for c0 in range(0, len(js), 8):                                     # 8 queries = 152 windows per call
+        segs = np.concatenate([osg.segment(osg.pcm_to_mono(np.asarray(pcm[j])[:, None]), 8000, HOP) for j in js[c0:c0 + 8]])
+        m32, m64 = om.melspec(segs, params), om.melspec_f64(segs, params)
+        e32.append(oe.encode(m32, sd, params))
+        e64.append(oe.encode(m64, sd, params, dtype=np.float64))
+        e64m.append(oe.encode(m32, sd, params, dtype=np.float64))
+    d = params["model"]["d"]
+    cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros((0, d), dt)
+    np.savez(os.path.join(work, "emb_%d.npz" % w), j=np.asarray(js, np.int64), emb32=cat(e32, np.float32), emb64=cat(e64, np.float64),
+             emb64_mel32=cat(e64m, np.float64))
+
+
+def run_embed(params, sd, q_pcm, workers=32):
+    """q_pcm int16 [nq, samples] -> {'emb32' f32, 'emb64' f64, 'emb64_mel32' f64} [nq * windows, d] in window order."""
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    work = tempfile.mkdtemp(prefix="pfann_oracle_", dir=base)
+    try:
+        np.save(os.path.join(work, "q_pcm.npy"), np.ascontiguousarray(q_pcm, np.int16))
+        np.savez(os.path.join(work, "weights.npz"), **{n: np.asarray(v) for n, v in sd.items()})
+        json.dump({"params": params}, open(os.path.join(work, "meta.json"), "w"))
+        workers = max(1, min(workers, q_pcm.shape[0]))
+        t1 = time.time()
+        env = dict(os.environ, PYTHONPATH=REPO, OMP_NUM_THREADS=os.environ.get("PFANN_ORACLE_THREADS", "8"))
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--embed-worker", work, str(w), str(workers)], env=env)
+                 for w in range(workers)]
+        rcs = [p.wait() for p in procs]
+        if any(rcs):
+            raise RuntimeError("oracle workers failed: %r" % rcs)
+        wall = time.time() - t1
+        parts = [np.load(os.path.join(work, "emb_%d.npz" % w)) for w in range(workers)]
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    nq = q_pcm.shape[0]
+    nwin = sum(p["emb32"].shape[0] for p in parts) // nq
+    out = {}
+    for name in ("emb32", "emb64", "emb64_mel32"):
+        full = np.empty((nq, nwin, parts[0][name].shape[1]), parts[0][name].dtype)
+        for p in parts:
+            full[p["j"]] = p[name].reshape(len(p["j"]), nwin, -1)
+        out[name] = full.reshape(nq * nwin, -1)
+    out.update(wall_s=wall, workers=workers)
+    return out
+
+
+def run_taps(params, sd, q_pcm, seg):
+    """The 16 sub-layer activations (fp32 and float64), both log-mels and fingerprints of the windows `seg` (global
+    window numbers query * QSEG + t), in this process."""
+    import torch
+    torch.set_num_threads(int(os.environ.get("PFANN_ORACLE_THREADS", "8")))
+    from oracle import encoder as oe
+    from oracle import melspec as om
+    from oracle import segmenter as osg
+    segs = np.stack([osg.segment(osg.pcm_to_mono(np.asarray(q_pcm[s // QSEG])[:, None]), 8000, HOP)[s % QSEG] for s in seg])
+    m32, m64 = om.melspec(segs, params), om.melspec_f64(segs, params)
+    t32, t64 = [], []
+    out = {"mel32": m32, "mel64": m64, "emb32": oe.encode(m32, sd, params, taps=t32),
+           "emb64": oe.encode(m64, sd, params, taps=t64, dtype=np.float64)}
+    for i in range(16):
+        out["tap32_%d" % i], out["tap64_%d" % i] = t32[i], t64[i]
+    return out
+
+
+def song_worker(work, w, W):
+    """The oracle as the BUILDER (reference builder.py:88-100): its share of the music list, file by file through the
+    oracle's own WAV reader, segmenter, log-mel and encoder; unreadable files give 0 rows (musicdata.py:95-101)."""
+    import torch
+    torch.set_num_threads(int(os.environ.get("PFANN_ORACLE_THREADS", "8")))
+    from oracle import encoder as oe
+    from oracle import melspec as om
+    from oracle import segmenter as osg
+    meta = json.load(open(os.path.join(work, "meta.json")))
+    params = meta["params"]
+    sd = dict(np.load(os.path.join(work, "weights.npz")))
+    music = json.load(open(os.path.join(work, "music.json")))
+    ids = list(range(w, len(music), W))
+    counts, rows = [], []
+    for c0 in range(0, len(ids), 4):                                  # 4 songs = 236 windows per call
+        segs = [osg.load_segments(music[i], params) for i in ids[c0:c0 + 4]]
+        counts += [x.shape[0] for x in segs]
+        cat = np.concatenate(segs)
+        if cat.shape[0]:
+            rows.append(oe.encode(om.melspec(cat, params), sd, params))
+    d = params["model"]["d"]
+    np.savez(os.path.join(work, "songs_%d.npz" % w), ids=np.asarray(ids, np.int64), counts=np.asarray(counts, np.int64),
+             rows=np.concatenate(rows) if rows else np.zeros((0, d), np.float32))
+
+
+def _spawn(mode, work, workers):
+    env = dict(os.environ, PYTHONPATH=REPO, OMP_NUM_THREADS=os.environ.get("PFANN_ORACLE_THREADS", "8"))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), mode, work, str(w), str(workers)], env=env)
+             for w in range(workers)]
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        raise RuntimeError("oracle workers (%s) failed: %r" % (mode, rcs))
+
+
+def run_files(params, sd, music, queries, k, workers=32, keep_song_scores=False):
+    """The whole reference pipeline from FILES, nothing shared with the product but the WAVs and the weights: the oracle
+    builds its own database from `music` (list of WAV paths, list order = song ids), then answers `queries` (WAV paths)
+    against it.  -> dict: 'db' f32 [N, d], 'key' int64 [n_songs] (rows per song), per-query arrays as run(), and
+    'ss' f32 [n_queries, n_songs, 2] when keep_song_scores."""
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    work = tempfile.mkdtemp(prefix="pfann_oracle_", dir=base)
+    try:
+        np.savez(os.path.join(work, "weights.npz"), **{n: np.asarray(v) for n, v in sd.items()})
+        json.dump({"params": params, "k": k, "hop_s": params["hop_size"], "keep_song_scores": bool(keep_song_scores)},
+                  open(os.path.join(work, "meta.json"), "w"))
+        json.dump(list(music), open(os.path.join(work, "music.json"), "w"))
+        json.dump(list(queries), open(os.path.join(work, "q_files.json"), "w"))
+        t0 = time.time()
+        W = max(1, min(workers, len(music)))
+        _spawn("--song-worker", work, W)
+        d = params["model"]["d"]
+        key = np.zeros(len(music), np.int64)
+        parts = [np.load(os.path.join(work, "songs_%d.npz" % w)) for w in range(W)]
+        for p in parts:
+            key[p["ids"]] = p["counts"]
+        song_pos = np.pad(np.cumsum(key), (1, 0))
+        db = np.empty((int(song_pos[-1]), d), np.float32)
+        for p in parts:
+            r0 = 0
+            for i, c in zip(p["ids"], p["counts"]):
+                db[song_pos[i]:song_pos[i] + c] = p["rows"][r0:r0 + c]
+                r0 += c
+        t_build = time.time() - t0
+        np.save(os.path.join(work, "db.npy"), db)
+        np.save(os.path.join(work, "song_pos.npy"), song_pos)
+        t1 = time.time()
+        W = max(1, min(workers, len(queries)))
+        _spawn("--worker", work, W)
+        t_query = time.time() - t1
+        parts = [np.load(os.path.join(work, "res_%d.npz" % w)) for w in range(W)]
+        order = np.argsort(np.concatenate([p["j"] for p in parts]))
+        # (all queries of a population have the same length here, so the per-row arrays stack)
+        out = {name: np.concatenate([p[name] for p in parts])[order]
+               for name in ("song", "sec", "score", "runner_up", "kth", "next", "labels")}
+        if keep_song_scores:
+            ss = np.concatenate([np.load(os.path.join(work, "ss_%d.npy" % w)) for w in range(W)])
+            out["ss"] = ss[order]
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    out.update(db=db, key=key, song_pos=song_pos, build_s=t_build, query_s=t_query, workers=workers)
+    return out
 
 
 def run(params, sd, db, song_pos, q_pcm, k, workers=16, q_emb_gpu=None, keep=False):
@@ -107,3 +276,7 @@ def run(params, sd, db, song_pos, q_pcm, k, workers=16, q_emb_gpu=None, keep=Fal
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--worker":
         worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
+    elif len(sys.argv) > 1 and sys.argv[1] == "--song-worker":
+        song_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
+    elif len(sys.argv) > 1 and sys.argv[1] == "--embed-worker":
+        embed_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
