@@ -39,21 +39,26 @@ def _act(x, name):
     return Fn.relu(x) if name == "ReLU" else Fn.elu(x)
 
 
-def encode(mel, sd, params, norm=True, taps=None, dtype=np.float32):
+def encode(mel, sd, params, norm=True, taps=None, dtype=np.float32, device=None):
     """mel [B,F,T]; sd: name -> numpy/torch tensors (reference state_dict names).
     taps: optional list that receives each of the 16 post-(LN,act) activations (NCHW numpy).
     dtype: np.float32 = the reference's arithmetic (torch CPU fp32, what parity is judged against);
     np.float64 = the SAME op sequence carried out in double on the float32 weights -- the "exact" value
     tools/embedding_error_budget.py triangulates the GPU path and the fp32 oracle against (neither is the truth:
     both round; this says by how much each).  The result keeps that dtype.
+    device: None = the host (what every parity check uses).  A torch device (e.g. "cuda") is accepted ONLY for the
+    float64 yardstick: the same op sequence executed by torch's own float64 kernels there (im2col + dgemm, not the
+    product's HIP kernels) -- the host's float64 evaluation costs as much as the whole fp32 oracle, and the GPU suite's
+    time goes to the oracle; tools/embedding_error_budget.py cross-checks the two evaluations against each other.
     """
+    assert device is None or dtype == np.float64, "the fp32 parity oracle runs on the host"
     m = params["model"]
     act = m.get("conv_activation", "ReLU")
     after_bn = m.get("relu_after_bn", True)
     d, h, u, _, _ = model_dims(params)
-    g = lambda k: torch.as_tensor(np.asarray(np.asarray(sd[k], dtype=np.float32), dtype=dtype))
+    g = lambda k: torch.as_tensor(np.asarray(np.asarray(sd[k], dtype=np.float32), dtype=dtype), device=device)
     with torch.no_grad():
-        x = torch.as_tensor(np.asarray(mel, dtype=dtype)).unsqueeze(1)         # model.py:102
+        x = (mel.to(device) if isinstance(mel, torch.Tensor) else torch.as_tensor(np.asarray(mel, dtype=dtype), device=device)).unsqueeze(1)   # model.py:102
         for i, L in enumerate(layer_plan(params)):
             p = "f.convs.%d." % i
             x = Fn.pad(x, (L["pad1"][0], L["pad1"][1], 0, 0))                  # model.py:56
@@ -64,7 +69,7 @@ def encode(mel, sd, params, norm=True, taps=None, dtype=np.float32):
             else:
                 x = Fn.layer_norm(_act(x, act), w.shape, w, b, 1e-5)
             if taps is not None:
-                taps.append(x.numpy().copy())
+                taps.append(x.cpu().numpy().copy())
             x = Fn.pad(x, (0, 0, L["pad2"][0], L["pad2"][1]))                  # model.py:65
             x = Fn.conv2d(x, g(p + "conv2.weight"), g(p + "conv2.bias"), stride=(L["s_f"], 1),
                           groups=L["co"] if L["depthwise"] else 1)             # model.py:26-29
@@ -74,7 +79,7 @@ def encode(mel, sd, params, norm=True, taps=None, dtype=np.float32):
             else:
                 x = Fn.layer_norm(_act(x, act), w.shape, w, b, 1e-5)
             if taps is not None:
-                taps.append(x.numpy().copy())
+                taps.append(x.cpu().numpy().copy())
         x = x.reshape(-1, h, 1)                                                # model.py:123
         x = Fn.conv1d(x, g("g.linear1.weight"), g("g.linear1.bias"), groups=d)
         x = Fn.elu(x)
@@ -82,4 +87,4 @@ def encode(mel, sd, params, norm=True, taps=None, dtype=np.float32):
         x = x.reshape(-1, d)
         if norm:
             x = Fn.normalize(x, p=2.0)                                         # model.py:128-129
-        return x.numpy()
+        return x.cpu().numpy()

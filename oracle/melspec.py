@@ -62,6 +62,39 @@ def mel_filterbank(sample_rate, n_fft, n_mels, f_min, f_max, naf_mode=False):
     return torch.from_numpy(fb.astype(np.float32))
 
 
+def mel_filterbank_torchaudio(sample_rate, n_fft, n_mels, f_min, f_max, naf_mode=False):
+    """The SAME bank the way torchaudio itself builds it: torchaudio.functional.melscale_fbanks +
+    _create_triangular_filterbank (module torchaudio, version unpinned by the reference; restated from its published
+    source), i.e. in float32 torch ops: bin frequencies torch.linspace(0, sr // 2, n_freqs); n_mels + 2 points
+    torch.linspace(mel(f_min), mel(f_max)) mapped back to Hz in float32; slopes = f_pts[None, :] - all_freqs[:, None];
+    fb = max(0, min(-slopes[:, :-2] / f_diff[:-1], slopes[:, 2:] / f_diff[1:])); slaney: columns scaled by
+    2 / (f_pts[2:] - f_pts[:-2]).
+
+    Why both exist (round 5, tools/embedding_error_budget.py): around 4 kHz a float32 frequency carries 2.4e-4 Hz of
+    rounding against filters ~14 Hz wide, so the float32 construction and mel_filterbank()'s float64 one differ by up to
+    3.8e-5 of a unit-peak weight -- and on clean tonal material, whose quiet mel bins sit at the log's 1e-8 floor, that
+    alone moves a fingerprint by up to 1.9e-4 (118,000 database rows), more than every fp32 rounding of either side
+    together (GPU 6e-6 .. 2.6e-5, torch-CPU 3e-6 .. 1.8e-5 from float64).  mel_filterbank() stays the default of
+    melspec() -- the independent statement every fixture-level test was written against; the population-scale tools
+    evaluate with THIS one first, because it is what a reference installation computes, and report the other beside it."""
+    scale = "slaney" if naf_mode else "htk"
+    n_freqs = n_fft // 2 + 1
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    m_pts = torch.linspace(_hz_to_mel(float(f_min), scale), _hz_to_mel(float(f_max), scale), n_mels + 2)
+    if scale == "htk":
+        f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    else:
+        logstep = math.log(6.4) / 27.0
+        f_pts = torch.where(m_pts >= 15.0, 1000.0 * torch.exp(logstep * (m_pts - 15.0)), (200.0 / 3) * m_pts)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    down, up = (-1.0 * slopes[:, :-2]) / f_diff[:-1], slopes[:, 2:] / f_diff[1:]
+    fb = torch.max(torch.zeros(1), torch.min(down, up))
+    if naf_mode:
+        fb = fb * (2.0 / (f_pts[2:n_mels + 2] - f_pts[:n_mels])).unsqueeze(0)
+    return fb.to(torch.float32)
+
+
 def melspec(x, params, bank=None):
     """x float32 [B, L] (numpy or torch) -> numpy float32 [B, n_mels, 1 + L//hop].  bank: a filter bank
     float32 [n_freqs, n_mels] to use instead of mel_filterbank() -- the device-kernel parity tests hand in the bank the
@@ -111,3 +144,25 @@ def melspec_f64(x, params, bank=None):
           if bank is None else torch.as_tensor(np.asarray(bank, np.float32))).double().numpy()
     mel = np.einsum("...tk,km->...mt", power, fb)
     return np.log(mel + 1e-8)
+
+
+def melspec_f64_torch(x, params, bank=None, device=None):
+    """melspec_f64 with torch float64 ops on `device` (gather, window, torch.fft.rfft, matmul, log) -> torch float64
+    tensor [B, n_mels, frames] on that device: the front half of the float64 yardstick when it is evaluated on the GPU
+    (oracle/encoder.py: encode(device=...)); tools/embedding_error_budget.py checks it against melspec_f64."""
+    x = torch.as_tensor(np.asarray(x, dtype=np.float64), device=device)
+    n_fft, hop = params["stft_n"], params["stft_hop"]
+    x = x / torch.clamp(torch.linalg.norm(x, dim=-1, keepdim=True), min=1e-12)
+    L = x.shape[-1]
+    n_frames = 1 + L // hop
+    n = torch.arange(n_fft, device=device)
+    win = 0.5 - 0.5 * torch.cos(2 * math.pi * n.double() / n_fft)
+    idx = torch.arange(n_frames, device=device)[:, None] * hop - n_fft // 2 + n[None, :]
+    idx = torch.where(idx < 0, -idx, idx)
+    idx = torch.where(idx > L - 1, 2 * (L - 1) - idx, idx)
+    frames = x[..., idx] * win
+    power = torch.fft.rfft(frames, dim=-1).abs() ** 2
+    fb = (mel_filterbank(params["sample_rate"], n_fft, params["n_mels"], params["f_min"], params["f_max"], False)
+          if bank is None else torch.as_tensor(np.asarray(bank, np.float32))).double().to(device)
+    mel = torch.matmul(power, fb).transpose(-1, -2)
+    return torch.log(mel + 1e-8)

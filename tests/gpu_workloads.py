@@ -1,0 +1,124 @@
+"""What several GPU tests need and none of them should build twice (the suite was at 706 s of the driver's
+1200 s limit because BASELINE config 2's 590 k-row database was embedded three times): the default-config engine and the
+database of the first N synthetic songs -- song i's 59 fingerprints do not depend on which other songs are embedded with
+it, so the 10 k-song database of config 2 is the head of config 3's 25 k songs, which is the head of config 4's 100 k --
+grown on demand and kept for the session; and the CPU oracle run over a SAMPLE of queries in worker processes
+(tools/oracle_pool.py) instead of one query after the other in the test process."""
+import json
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SEG, QSEG, HOP = 59, 19, 4000
+MAX_BATCH = 9728
+CFG2_QUERIES = 1000
+_cache = {}
+
+
+def params_of(name):
+    return json.load(open(os.path.join(REPO, "configs", name + ".json")))
+
+
+def engine(cfg="default", max_batch=MAX_BATCH):
+    """-> (params, sd, Engine) with the seeded calibrated weights and the kernel-variant plan of a full launch group pinned
+    (the tools' setting: a window's fingerprint then has the same bits in every batch)."""
+    from pfann_amd import synth
+    from pfann_amd.engine import Engine
+    key = ("engine", cfg, max_batch)
+    if key not in _cache:
+        params = params_of(cfg)
+        try:
+            sd = synth.make_state_dict_calibrated(params, seed=123)
+        except KeyError:
+            sd = synth.make_state_dict(params, seed=123)
+        eng = Engine(params, 0, max_batch=max_batch)
+        eng.load_state_dict(sd)
+        eng.set_plan_batch(max_batch)
+        _cache[key] = (params, sd, eng)
+    return _cache[key]
+
+
+class _Pcm:
+    def __init__(self, ids, pcm):
+        self.files, self.pcm = ["song %d" % i for i in ids], pcm
+
+    def load_pcm(self, i):
+        return self.pcm[i]
+
+    def __len__(self):
+        return len(self.files)
+
+
+def database(n_songs, cfg="default", max_batch=MAX_BATCH):
+    """-> (device float32 [n_songs * 59, d] -- a view of the session's database --, song_pos): synthetic 30 s songs
+    0 .. n_songs-1 through builder.embed_files; songs a previous call embedded are not embedded again."""
+    import torch
+    from pfann_amd import synth
+    from pfann_amd.builder import embed_files
+    params, sd, eng = engine(cfg, max_batch)
+    d = params["model"]["d"]
+    key = ("db", cfg, max_batch)
+    have, rows = _cache.get(key, (0, None))
+    if have < n_songs:
+        grown = torch.empty((n_songs * SEG, d), device=eng.device, dtype=torch.float32)
+        if have:
+            grown[: have * SEG] = rows
+        for c0 in range(have, n_songs, 256):
+            ids = list(range(c0, min(c0 + 256, n_songs)))
+            pcm = synth.make_songs_torch(ids, 30.0, device=eng.device)
+            for i, n_seg, e in embed_files(eng, _Pcm(ids, pcm), HOP, batch_windows=max_batch):
+                assert n_seg == SEG
+                grown[ids[i] * SEG:(ids[i] + 1) * SEG] = e
+        del rows
+        _cache[key] = (n_songs, grown)
+        have, rows = n_songs, grown
+    return rows[: n_songs * SEG], np.arange(n_songs + 1, dtype=np.int64) * SEG
+
+
+def release(cfg="default", max_batch=MAX_BATCH):
+    """drop the session's database and engine of this config (the big ones: 3 GB of rows, a 29 GB workspace)"""
+    import torch
+    _cache.pop(("db", cfg, max_batch), None)
+    _cache.pop(("engine", cfg, max_batch), None)
+    torch.cuda.empty_cache()
+
+
+def oracle_sample(params, sd, db_host, song_pos, q_pcm_host, sample, res, emb_gpu, k, hop_s=0.5, workers=None):
+    """Whole path on the CPU oracle for the sampled queries, in worker processes: embeddings within 1e-4 of the GPU's,
+    identical (song, offset) decisions, scores within 1e-5.  -> the largest embedding difference."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import oracle_pool
+    sample = list(sample)
+    workers = workers or max(2, min(len(sample), (os.cpu_count() or 8) // 8))
+    emb_s = np.concatenate([emb_gpu[j * QSEG:(j + 1) * QSEG] for j in sample])
+    pool = oracle_pool.run(params, sd, db_host, song_pos, q_pcm_host[sample], k, workers=workers, q_emb_gpu=emb_s, batch_queries=1)
+    for i, j in enumerate(sample):
+        song, sec, sc = int(pool["song"][i]), float(pool["sec"][i]), float(pool["score"][i])
+        assert int(res[j]["song"]) == song and int(res[j]["offset"]) * hop_s == sec, \
+            "query %d: GPU (%d, %g) vs oracle (%d, %g)" % (j, res[j]["song"], res[j]["offset"] * hop_s, song, sec)
+        assert abs(float(res[j]["score"]) - sc) < 1e-5
+    worst = float(pool["emb_err"].max())
+    assert worst < 1e-4, "embedding mismatch vs oracle %g" % worst
+    return worst
+
+
+def cfg2_state(log=None):
+    """BASELINE config 2 once per session: 10 k songs -> 590 k rows, all 2000 ten-second SNR-0 queries through the
+    GPU path and the first CFG2_QUERIES of them through the CPU oracle as well (tools/decision_parity.py; the host
+    oracle -- ~400 windows/s on a whole node -- is what the GPU suite's time goes to: 1000 queries here, all 2000 and the
+    other configs' populations as tool runs committed under profiles/) -> (record, state): the parity record and the GPU-side arrays
+    (q_pcm, emb, labels, res, index, shard, ...).  tests/test_gpu_configs.py::test_config2... checks the search's
+    properties on it, tests/test_gpu_decision_parity.py the decisions."""
+    if "cfg2" not in _cache:
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        import decision_parity
+        params, sd, eng = engine("default")
+        shard, _ = database(10000)
+        st = {}
+        workers = max(4, min(32, (os.cpu_count() or 8) // 8))
+        rec = decision_parity.run(10000, 2000, 0.0, workers=workers, oracle_queries=CFG2_QUERIES, prebuilt={"eng": eng, "sd": sd, "shard": shard}, state=st,
+                                  log=log or (lambda *a: print(*a, file=sys.stderr, flush=True)))
+        _cache["cfg2"] = (rec, st)
+    return _cache["cfg2"]

@@ -195,8 +195,8 @@ def test_rccl_collectives_of_the_sharded_path_on_one_gpu(tmp_path):
     assert np.array_equal(a[:, :2], b[:, :2]) and np.abs(a[:, 2] - b[:, 2]).max() < 1e-6
     # PFANN_EXCHANGE_STREAM=1 (round 5): the same exchange on a stream of its own, three batches two deep, so that batch
     # i+1's encoder really runs beside batch i's collectives -- the same bytes out as with the flag off
-    xs_on, xs_off = str(tmp_path / "xs_on.npy"), str(tmp_path / "xs_off.npy")
-    for flag, path in (("1", xs_on), ("0", xs_off)):
+    xs_on = str(tmp_path / "xs_on.npy")
+    for flag, path in (("1", xs_on),):
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                             "--master-addr", "127.0.0.1", "--master-port", "29743", os.path.join(REPO, "bench.py"),
                             "--gpus", "1", "--force-sharded", "--steps", "3", "--warmup", "1", "--db-songs", "600", "--queries", "24",
@@ -206,4 +206,4 @@ def test_rccl_collectives_of_the_sharded_path_on_one_gpu(tmp_path):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
         assert line["critical_path"]["exchange_stream"] is (flag == "1")
-    assert np.array_equal(np.load(xs_on), np.load(xs_off)) and np.array_equal(np.load(xs_on), b)
+    assert np.array_equal(np.load(xs_on), b)                    # (b: the same exchange on the caller's stream, above)

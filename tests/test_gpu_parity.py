@@ -352,7 +352,8 @@ def _check_topk(torch, db, q, k, prefilter=True):
     idx.set_prefilter(prefilter)        # fp16 pre-filter + exact re-scoring vs all-fp32 scan: same answer
     D, I = idx.search(torch.as_tensor(q).cuda(), k)
     D, I = D.cpu().numpy(), I.cpu().numpy()
-    Dr, Ir = osr.flat_ip_topk(q, db, k)
+    # (big cases: the argpartition form of the same definition -- a full stable argsort of 2100 x 150,000 scores took 20 s)
+    Dr, Ir = (osr.flat_ip_topk_blas if q.shape[0] * db.shape[0] > (1 << 24) else osr.flat_ip_topk)(q, db, k)
     n = min(k, db.shape[0])
     assert (I[:, n:] == -1).all() and (I[:, :n] >= 0).all()
     assert (D[:, n:] == -np.finfo(np.float32).max).all()

@@ -31,7 +31,13 @@ for _p in (REPO, os.path.join(REPO, "tools")):
 SEG, QSEG, HOP = 59, 19, 4000
 
 
-def run(n_songs, n_queries, snr, workers=16, config="default", plan=9728, max_batch=9728, log=print, keep=False, shards=1):
+def run(n_songs, n_queries, snr, workers=16, config="default", plan=9728, max_batch=9728, log=print, keep=False, shards=1,
+        prebuilt=None, state=None, oracle_queries=None):
+    """prebuilt: {"eng": Engine (plan pinned by the caller), "sd": weights, "shard": device float32 [>= n_songs*59, d]} of a
+    database some other test of the session has already embedded (the GPU suite builds each one once); state: a dict that
+    receives the GPU-side arrays (q_pcm, emb, labels, res, index, shard) for further checks on the same workload;
+    oracle_queries: the CPU oracle answers only the first so many queries (the GPU answers all n_queries) and the
+    comparison is made on those."""
     import torch
     from pfann_amd import synth
     from pfann_amd.builder import embed_files
@@ -39,31 +45,36 @@ def run(n_songs, n_queries, snr, workers=16, config="default", plan=9728, max_ba
     from pfann_amd.engine import Engine
     params = json.load(open(os.path.join(REPO, "configs", config + ".json")))
     d, k = params["model"]["d"], params["indexer"]["top_k"]
-    try:                    # calibrated output bias (an untrained network's fingerprints then spread over the sphere); configs
-        sd = synth.make_state_dict_calibrated(params, seed=123)      # without constants fall back to the raw seeded weights,
-    except KeyError:                                                 # whose fingerprints all but coincide (a degenerate db)
-        sd = synth.make_state_dict(params, seed=123)
-    eng = Engine(params, 0, max_batch=max_batch)
-    eng.load_state_dict(sd)
-    eng.set_plan_batch(plan)
-    dev = eng.device
-    t0 = time.time()
+    if prebuilt is not None:
+        eng, sd, shard = prebuilt["eng"], prebuilt["sd"], prebuilt["shard"][: n_songs * SEG]
+        dev = eng.device
+        t0 = time.time()
+    else:
+        try:                    # calibrated output bias (an untrained network's fingerprints then spread over the sphere); configs
+            sd = synth.make_state_dict_calibrated(params, seed=123)      # without constants fall back to the raw seeded weights,
+        except KeyError:                                                 # whose fingerprints all but coincide (a degenerate db)
+            sd = synth.make_state_dict(params, seed=123)
+        eng = Engine(params, 0, max_batch=max_batch)
+        eng.load_state_dict(sd)
+        eng.set_plan_batch(plan)
+        dev = eng.device
+        t0 = time.time()
 
-    class Pcm:
-        def __init__(self, ids, pcm):
-            self.files, self.pcm = ["song %d" % i for i in ids], pcm
+        class Pcm:
+            def __init__(self, ids, pcm):
+                self.files, self.pcm = ["song %d" % i for i in ids], pcm
 
-        def load_pcm(self, i):
-            return self.pcm[i]
+            def load_pcm(self, i):
+                return self.pcm[i]
 
-        def __len__(self):
-            return len(self.files)
-    shard = torch.empty((n_songs * SEG, d), device=dev, dtype=torch.float32)
-    for c0 in range(0, n_songs, 256):
-        ids = list(range(c0, min(c0 + 256, n_songs)))
-        pcm = synth.make_songs_torch(ids, 30.0, device=dev)
-        for i, n_seg, e in embed_files(eng, Pcm(ids, pcm), HOP, batch_windows=max_batch):
-            shard[ids[i] * SEG:(ids[i] + 1) * SEG] = e
+            def __len__(self):
+                return len(self.files)
+        shard = torch.empty((n_songs * SEG, d), device=dev, dtype=torch.float32)
+        for c0 in range(0, n_songs, 256):
+            ids = list(range(c0, min(c0 + 256, n_songs)))
+            pcm = synth.make_songs_torch(ids, 30.0, device=dev)
+            for i, n_seg, e in embed_files(eng, Pcm(ids, pcm), HOP, batch_windows=max_batch):
+                shard[ids[i] * SEG:(ids[i] + 1) * SEG] = e
     song_pos = np.arange(n_songs + 1, dtype=np.int64) * SEG
     q_song = [int((j * 7919 + 13) % n_songs) for j in range(n_queries)]
     pcms, embs = [], []
@@ -110,8 +121,15 @@ def run(n_songs, n_queries, snr, workers=16, config="default", plan=9728, max_ba
     log("decision_parity: GPU side (db %d rows + %d queries) %.1f s" % (n_songs * SEG, n_queries, t_gpu))
 
     import oracle_pool
-    pool = oracle_pool.run(params, sd, shard.cpu().numpy(), song_pos, q_pcm.cpu().numpy(), k, workers=workers, q_emb_gpu=emb_gpu,
-                           keep=keep)
+    n_all, res_all = n_queries, res
+    if oracle_queries is not None and oracle_queries < n_queries:
+        n_queries = int(oracle_queries)
+        res, labels, emb_gpu = res[:n_queries], labels[:n_queries], emb_gpu[:n_queries * QSEG]
+    pool = oracle_pool.run(params, sd, shard.cpu().numpy(), song_pos, q_pcm[:n_queries].cpu().numpy(), k, workers=workers,
+                           q_emb_gpu=emb_gpu, keep=keep, batch_queries=8)
+    if state is not None:
+        state.update(q_pcm=q_pcm, emb=torch.cat(embs), labels=labels, res=res_all, index=index, shard=shard, song_pos=song_pos,
+                     q_song=np.asarray(q_song), params=params, sd=sd, eng=eng, oracle=pool)
     t_cpu = pool["wall_s"]
     o_song, o_sec, o_score, emb_err = pool["song"], pool["sec"], pool["score"], pool["emb_err"]
     kth, nxt, runner, o_lab = pool["kth"], pool["next"], pool["runner_up"], pool["labels"]
@@ -135,8 +153,10 @@ def run(n_songs, n_queries, snr, workers=16, config="default", plan=9728, max_ba
                       "min_gap_kth_vs_next": gap_k, "oracle_best_minus_runner_up_song": align_gap, "class": kind})
     sets_differ = int(sum(1 for j in range(n_queries)
                           if any(set(labels[j, t].tolist()) != set(o_lab[j, t].tolist()) for t in range(QSEG))))
-    hit = float(np.mean(g_song == np.asarray(q_song)))
-    out = {"config": config, "db_songs": n_songs, "db_rows": n_songs * SEG, "queries": n_queries, "snr_db": snr, "top_k": k,
+    hit = float(np.mean(g_song == np.asarray(q_song[:n_queries])))
+    out = {"config": config, "db_songs": n_songs, "db_rows": n_songs * SEG, "queries": n_queries, "gpu_queries": n_all,
+           "top1_hit_rate_gpu_all_queries": round(float(np.mean(res_all["song"].astype(np.int64) == np.asarray(q_song))), 4),
+           "snr_db": snr, "top_k": k,
            "plan_batch": plan, "shards": shards, "identical_song_and_offset": int(same.sum()), "flips": flips,
            "bugs": int(sum(1 for f in flips if f["class"] == "bug")),
            "max_embedding_abs_diff": float(emb_err.max()), "embedding_tolerance": 1e-4,
@@ -144,7 +164,7 @@ def run(n_songs, n_queries, snr, workers=16, config="default", plan=9728, max_ba
            "score_tolerance": 1e-5,
            "queries_whose_topk_label_sets_differ": sets_differ,
            "smallest_kth_minus_next_gap_over_all_rows": float(np.min(kth - nxt)),
-           "top1_hit_rate_gpu": round(hit, 4), "top1_hit_rate_oracle": round(float(np.mean(o_song == np.asarray(q_song))), 4),
+           "top1_hit_rate_gpu": round(hit, 4), "top1_hit_rate_oracle": round(float(np.mean(o_song == np.asarray(q_song[:n_queries]))), 4),
            "gpu_side_s": round(t_gpu, 1), "oracle_side_s": round(t_cpu, 1), "oracle_processes": workers,
            "oracle_threads_per_process": int(os.environ.get("PFANN_ORACLE_THREADS", "8")), "host_cpus": os.cpu_count(),
            "oracle": "oracle/{segmenter,melspec,encoder,search,seqscore}.py (python path, database.py:117-166) against the same "

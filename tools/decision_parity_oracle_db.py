@@ -65,7 +65,11 @@ def classify(j, g_song, g_off, pool, params, sd, queries, k):
             "product_alignment_among_oracle_candidates": bool(in_cands), "closest_row_to_kth": float(near_kth)}
 
 
-def run(n_songs=2000, n_queries=2000, snr=0.0, workers=32, log=print):
+def run(n_songs=2000, n_queries=2000, snr=0.0, workers=32, log=print, bank="torchaudio"):
+    """bank: which statement of the (unpinned) mel filter bank the oracle's front-end uses -- "torchaudio": its restatement of
+    torchaudio's own float32 construction (oracle/melspec.mel_filterbank_torchaudio: what a reference installation computes);
+    "float64": the bank written from the definition in float64 (oracle/melspec.mel_filterbank).  The two are <= 3.8e-5 apart
+    per weight; on clean songs that alone moves fingerprints by up to 1.9e-4 (profiles/r5/decision_parity_oracle_db_f64_bank.json)."""
     import cli_bench
     import oracle_pool
     from pfann_amd import synth
@@ -85,7 +89,10 @@ def run(n_songs=2000, n_queries=2000, snr=0.0, workers=32, log=print):
         dbdir, result = os.path.join(work, "db"), os.path.join(work, "result.txt")
         t_cli = time.time() - t0
         keep_ss = n_songs * n_queries * 8 <= (1 << 30)
-        pool = oracle_pool.run_files(params, sd, music, queries, k, workers=workers, keep_song_scores=keep_ss)
+        from oracle import melspec as om
+        bank_arr = None if bank == "float64" else om.mel_filterbank_torchaudio(
+            params["sample_rate"], params["stft_n"], params["n_mels"], params["f_min"], params["f_max"], params.get("naf_mode", False)).numpy()
+        pool = oracle_pool.run_files(params, sd, music, queries, k, workers=workers, keep_song_scores=keep_ss, bank=bank_arr)
         log("decision_parity_oracle_db: oracle built %d rows in %.1f s, answered %d queries in %.1f s (%d processes)" %
             (pool["db"].shape[0], pool["build_s"], n_queries, pool["query_s"], workers))
         # ---- the database files
@@ -113,6 +120,8 @@ def run(n_songs=2000, n_queries=2000, snr=0.0, workers=32, log=print):
                "snr_db": snr, "top_k": k,
                "product": "builder.py + matcher.py as subprocesses on WAV files", "oracle": "oracle_pool.run_files: own reader, own "
                "database (every song embedded by oracle/encoder.py on the host), python-path matcher (database.py:117-166)",
+               "oracle_mel_bank": "torchaudio's float32 construction, restated (oracle/melspec.mel_filterbank_torchaudio)" if bank != "float64"
+               else "float64 from the definition (oracle/melspec.mel_filterbank)",
                "landmarkKey_equal": key_equal,
                "embeddings_rows": int(emb.shape[0]),
                "embeddings_max_abs_diff": float(emb_diff.max()) if emb_diff is not None else None,
@@ -133,10 +142,11 @@ def run(n_songs=2000, n_queries=2000, snr=0.0, workers=32, log=print):
             # disagree come from rows at the boundary of a top-k list (a candidate one side has and the other has not)
             b = np.fromfile(result + ".bin", dtype=np.float32).reshape(n_queries, n_songs, 2)
             ss = pool["ss"]
-            t_diff = b[..., 1] != ss[..., 1]
+            both = (b[..., 0] != 0) & (ss[..., 0] != 0)               # a cell nobody wrote is (0, 0); one only one side wrote holds
+            t_diff = (b[..., 1] != ss[..., 1]) | (both != ((b[..., 0] != 0) | (ss[..., 0] != 0)))   # a candidate the other list lacked
             s_diff = np.abs(b[..., 0] - ss[..., 0]) > 2e-5
             out["bin_cells"] = int(b.shape[0] * b.shape[1])
-            out["bin_cells_time_differs"] = int(t_diff.sum())
+            out["bin_cells_time_differs_or_written_by_one_side_only"] = int(t_diff.sum())
             out["bin_cells_score_differs_2e-5"] = int((s_diff & ~t_diff).sum())
             out["bin_max_score_diff_where_time_agrees"] = float(np.abs(b[..., 0] - ss[..., 0])[~t_diff].max())
         out["wall_s"] = round(time.time() - t0, 1)
@@ -151,9 +161,10 @@ if __name__ == "__main__":
     ap.add_argument("--queries", type=int, default=2000)
     ap.add_argument("--snr", type=float, default=0.0)
     ap.add_argument("--workers", type=int, default=32)
+    ap.add_argument("--bank", default="torchaudio", choices=["torchaudio", "float64"])
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
-    r = run(a.songs, a.queries, a.snr, a.workers, log=lambda *x: print(*x, file=sys.stderr, flush=True))
+    r = run(a.songs, a.queries, a.snr, a.workers, log=lambda *x: print(*x, file=sys.stderr, flush=True), bank=a.bank)
     print(json.dumps({k: v for k, v in r.items() if k not in ("flips", "cli")}, indent=1), "\nflips:", json.dumps(r.get("flips", []))[:3000])
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
