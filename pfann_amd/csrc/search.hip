@@ -518,10 +518,84 @@ __global__ __launch_bounds__(256) void group_max_select_kernel(const float *__re
     }
 }
 
+// The same selection with ONE WAVEFRONT per query row (round 5), for G <= 64 * VPL group maxima: the workgroup form above
+// spends its time in barriers -- four radix passes of three __syncthreads each for ~500-800 values -- and costs a rank of
+// an 8-way sharded search 0.47 of its 4.8 ms of scan kernels per 77,824-row step (the work per query row does not shrink
+// with the shard: tools/ubench/sharded_scan_model.py).  Here a lane keeps VPL values in registers and the k-th (and
+// mtop-th) largest comes from an MSB-first bisection on the orderable bit patterns, one ballot + popcount per value and
+// bit, no LDS, no barrier (the scheme of bound_reduce_kernel).  Same outputs: thr / thr_adj, the zeroed counters, topm.
+template <int VPL>
+__global__ __launch_bounds__(256) void group_max_select_wave_kernel(const float *__restrict__ gmax, int G, int k,
+                                                                    float *__restrict__ thr, int *__restrict__ cnt, int ncnt,
+                                                                    const float *__restrict__ eps, float *__restrict__ thr_adj,
+                                                                    float margin, float *__restrict__ topm, int mtop,
+                                                                    float margin_out, int *zero_me, int64_t nq) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= nq) return;
+    if (zero_me != nullptr && m == 0 && lane == 0) *zero_me = 0;
+    for (int i = lane; i < ncnt; i += 64) cnt[m * ncnt + i] = 0;
+    unsigned key[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int i = lane + 64 * j;
+        key[j] = i < G ? f2ord(gmax[m * G + i]) : 0u;           // 0: below every value (f2ord(x) > 0 for every non-NaN x)
+    }
+    auto kth_largest = [&](int kk) {                             // key of the kk-th largest of the G values, 1 <= kk <= G
+        unsigned prefix = 0u;
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned cand = prefix | (1u << bit);
+            int c = 0;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) c += __popcll(__ballot(key[j] >= cand));
+            if (c >= kk) prefix = cand;
+        }
+        return prefix;
+    };
+    const int mm = topm != nullptr ? (mtop < G ? mtop : G) : 0;
+    if (topm != nullptr) {
+        const float e = eps != nullptr ? margin_out * eps[m] : 0.f;
+        for (int i = mm + lane; i < mtop; i += 64) topm[m * mtop + i] = -INFINITY;
+        if (mm > 0) {
+            const unsigned tm = kth_largest(mm);
+            int base = 0;                                        // strictly better than the mm-th best: fewer than mm of them
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                const bool take = key[j] > tm;
+                const unsigned long long mask = __ballot(take);
+                if (take) topm[m * mtop + base + __popcll(mask & ((1ull << lane) - 1ull))] = ord2f(key[j]) - e;
+                base += __popcll(mask);
+            }
+            for (int i = base + lane; i < mm; i += 64) topm[m * mtop + i] = ord2f(tm) - e;      // the mm-th best and its ties
+        }
+    }
+    if (G < k) {
+        if (lane == 0) { thr[m] = -INFINITY; if (eps != nullptr) thr_adj[m] = -1000.f * eps[m]; }
+        return;
+    }
+    const unsigned pk = kth_largest(k);
+    if (lane == 0) {
+        const float t = ord2f(pk);
+        thr[m] = t;
+        if (eps != nullptr) thr_adj[m] = fmaxf(t - margin * eps[m], -1000.f * eps[m]);
+    }
+}
+
 int launch_group_max_select(SearchWorkspace &ws, int64_t nq, int G, int k, int ncnt, bool with_eps, float margin, hipStream_t s,
                             float *topm = nullptr, int mtop = 0, float margin_out = 0.f, int *zero_me = nullptr) {
     if (G < 1 || G > 4096) { set_error("group select: %d groups (the kernel's LDS array holds 4096)", G); return -1; }
     ProfScope ps("topk_group_select", s);
+    static const bool no_wave = getenv("PFANN_NO_WAVE_GROUP_SELECT") != nullptr;       // A/B aid: the workgroup form
+    const float *gm = reinterpret_cast<const float *>(ws.cl);
+    const float *ep = with_eps ? ws.eps : nullptr;
+    const dim3 wgrid((unsigned)cdiv(nq, 4));
+    if (!no_wave && G <= 64 * 8)
+        PF_LAUNCH(group_max_select_wave_kernel<8>, wgrid, dim3(256), 0, s, gm, G, k, ws.thr, ws.cnt, ncnt, ep, ws.thr_adj, margin, topm,
+                  mtop, margin_out, zero_me, nq);
+    else if (!no_wave && G <= 64 * 16)
+        PF_LAUNCH(group_max_select_wave_kernel<16>, wgrid, dim3(256), 0, s, gm, G, k, ws.thr, ws.cnt, ncnt, ep, ws.thr_adj, margin, topm,
+                  mtop, margin_out, zero_me, nq);
+    else
     PF_LAUNCH(group_max_select_kernel, dim3((unsigned)nq), dim3(256), 0, s, reinterpret_cast<const float *>(ws.cl), G, k, ws.thr,
               ws.cnt, ncnt, with_eps ? ws.eps : nullptr, ws.thr_adj, margin, topm, mtop, margin_out, zero_me);
     PF_HIP(hipGetLastError());
@@ -873,7 +947,7 @@ int search_topk(const float *db, const void *dbh, float xnorm_max, int64_t n, in
                 }
                 int nsub = 1;
                 if (launch_scan_f16(dbh, n, d, 1, ws.qh, nq, ws.thr_adj, ws, true, &nsub, s)) return -1;
-                if (launch_select_rescore(ws, nq, k, 1, D, I, label_base, q, db, d, nsub, rescore, s)) return -1;
+                if (launch_select_rescore(ws, nq, k, 1, D, I, label_base, q, db, d, nsub, rescore, s, resume && lb != nullptr)) return -1;
                 return launch_topk_fallback(ws, q, db, dbh, n, d, nq, k, D, I, label_base, s);
             }
             if (phase == 1) return no_bound();

@@ -139,7 +139,8 @@ int launch_scan_f16(const void *dbh, int64_t n, int d, int64_t stride, const voi
 // rescore = 1: survivors within 2 eps of the k-th best approximate score are re-scored in exact fp32 from db32;
 // rescore = 0: the keys' scores are final (eps is not read)
 int launch_select_rescore(SearchWorkspace &ws, int64_t nq, int k, int mode, float *D, int64_t *I, int64_t label_base,
-                          const float *q32, const float *db32, int d, int nsub, int rescore, hipStream_t s);
+                          const float *q32, const float *db32, int d, int nsub, int rescore, hipStream_t s,
+                          bool few_survivors = false);
 // small-batch path (search_small): the 256-thread select alone, then big select (rows with > SMALL_N survivors) + exact
 // fallback of flagged rows in ONE launch
 int launch_select_rescore_small(SearchWorkspace &ws, int64_t nq, int k, float *D, int64_t *I, int64_t label_base,

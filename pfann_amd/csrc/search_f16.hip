@@ -607,8 +607,9 @@ __global__ __launch_bounds__(256) void select_rescore_small_kernel(const unsigne
                                                                    int *overflow, int *__restrict__ row_ovf,
                                                                    const float *__restrict__ q32,
                                                                    const float *__restrict__ db32, int d, int nsub,
-                                                                   int rescore) {
+                                                                   int rescore, int skip_le) {
     constexpr int NT = 256, KPT = SMALL_N / NT;
+    if (skip_le && overflow[2] == 0) return;          // every row was handled by select_rescore_wave_kernel
     __shared__ __attribute__((aligned(16))) unsigned long long skeys[SMALL_N];
     __shared__ int s_n2, s_bin, s_kk;
     __shared__ int s_off[66];
@@ -638,6 +639,7 @@ __global__ __launch_bounds__(256) void select_rescore_small_kernel(const unsigne
         return;
     }
     const bool over = s_off[65] != 0;
+    if (skip_le && n <= skip_le && !over) return;     // done by select_rescore_wave_kernel
     if (over && mode == 1 && tid == 0) row_ovf[m] = 1;           // topk_fallback_kernel recomputes this row
     if (nsub == 1) {
         for (int i = tid; i < n; i += NT) skeys[i] = keys[m * CAP + i];
@@ -772,6 +774,136 @@ __global__ __launch_bounds__(256) void select_rescore_small_kernel(const unsigne
                 D[m * k + i] = -3.4028234663852886e38f;
                 I[m * k + i] = -1;
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// The same select for rows with at most WAVE_N survivors, ONE WAVEFRONT per row, four rows per workgroup (round 5): the
+// second phase of a sharded search -- every shard emits only rows that can reach the GLOBAL k-th bound, a few dozen per
+// query row at 8 shards -- left select_rescore_small_kernel with 256 threads, 32 KB of LDS and a dozen workgroup
+// barriers around ~30 keys: 0.70 of a rank's 4.8 ms of scan kernels per 77,824-row step, a cost per query row that does not
+// shrink with the shard (tools/ubench/sharded_scan_model.py).  Same steps, same summation order of the exact scores (four
+// lanes per candidate), same outputs; rows with more survivors or an overflowed sub-list are counted in overflow[2] and
+// left to select_rescore_small_kernel / select_rescore_kernel / the fallback.  mode 1 only (D, I out).
+// ------------------------------------------------------------------------------------
+constexpr int WAVE_N = 256;
+__global__ __launch_bounds__(256) void select_rescore_wave_kernel(const unsigned long long *__restrict__ keys,
+                                                                  const int *__restrict__ cnt, int k,
+                                                                  const float *__restrict__ eps, float *__restrict__ D,
+                                                                  int64_t *__restrict__ I, int64_t label_base, int *overflow,
+                                                                  const float *__restrict__ q32, const float *__restrict__ db32,
+                                                                  int d, int nsub, int rescore, int64_t nq) {
+    constexpr int KPL = WAVE_N / 64;
+    __shared__ __attribute__((aligned(16))) unsigned long long wk[4][WAVE_N];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t m = (int64_t)blockIdx.x * 4 + w;
+    if (m >= nq) return;
+    unsigned long long *sk = wk[w];
+    const int subcap = CAP / nsub;
+    int c = lane < nsub ? cnt[m * nsub + lane] : 0;
+    const bool ov = c > subcap;
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    const int n = __shfl(incl, 63, 64);
+    if (__any(ov) || n > WAVE_N) {
+        if (lane == 0) atomicAdd(overflow + 2, 1);
+        return;
+    }
+    // gather the sub-lists (sub-list g holds its keys at keys[m*CAP + g*subcap])
+    for (int g = 0; g < nsub; ++g) {
+        const int cg = __shfl(c, g, 64), og = __shfl(incl, g, 64) - cg;
+        if (lane < cg) sk[og + lane] = keys[m * CAP + (int64_t)g * subcap + lane];
+        for (int i = 64 + lane; i < cg; i += 64) sk[og + i] = keys[m * CAP + (int64_t)g * subcap + i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const float e2 = rescore ? 2.0f * eps[m] : 0.f;
+    int n2 = n;
+    if (n > k) {
+        // k-th best approximate score: the k-th smallest high word, by MSB-first bisection (largest P with fewer than k
+        // high words below it), then everything within 2 eps of it is a candidate
+        unsigned hi[KPL];
+        unsigned long long mine[KPL];
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+            const int i = lane + 64 * j;
+            mine[j] = i < n ? sk[i] : ~0ull;
+            hi[j] = (unsigned)(mine[j] >> 32);
+        }
+        unsigned prefix = 0u;
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned cand = prefix | (1u << bit);
+            int cl = 0;
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) cl += __popcll(__ballot(lane + 64 * j < n && hi[j] < cand));
+            if (cl < k) prefix = cand;
+        }
+        const float cut = ord2f(~prefix) - e2;
+        const unsigned cut_hi = ~f2ord(cut);
+        int base = 0;                                       // (every key is in registers: the list may be overwritten)
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+            const bool take = lane + 64 * j < n && hi[j] <= cut_hi;
+            const unsigned long long mask = __ballot(take);
+            if (take) sk[base + __popcll(mask & ((1ull << lane) - 1ull))] = mine[j];
+            base += __popcll(mask);
+        }
+        n2 = base;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    // exact fp32 scores: 4 lanes per candidate, 16 candidates per pass, select_rescore_small_kernel's summation order
+    const float *qv = q32 + m * d;
+    if (rescore)
+        for (int c0 = 0; c0 < n2; c0 += 16) {
+            const int ci = c0 + (lane >> 2), sub = lane & 3;
+            float part = 0.f;
+            unsigned row = 0u;
+            if (ci < n2) {
+                row = (unsigned)(sk[ci] & 0xFFFFFFFFull);
+                const float *xv = db32 + (int64_t)row * d;
+                for (int e = sub * 4; e < d; e += 16) {
+                    const float4 x4 = *reinterpret_cast<const float4 *>(xv + e);
+                    const float4 q4 = *reinterpret_cast<const float4 *>(qv + e);
+                    part = fmaf(x4.x, q4.x, part); part = fmaf(x4.y, q4.y, part);
+                    part = fmaf(x4.z, q4.z, part); part = fmaf(x4.w, q4.w, part);
+                }
+            }
+            part += __shfl_xor(part, 1, 64);
+            part += __shfl_xor(part, 2, 64);
+            if (ci < n2 && sub == 0) sk[ci] = pack_key(part, row);
+        }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // rank sort (keys are unique: they contain the row)
+    {
+        unsigned long long mine[KPL];
+        int rank[KPL];
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+            const int i = lane + 64 * j;
+            mine[j] = ~0ull; rank[j] = 0;
+            if (i < n2) {
+                mine[j] = sk[i];
+                for (int t = 0; t < n2; ++t) rank[j] += sk[t] < mine[j] ? 1 : 0;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int j = 0; j < KPL; ++j)
+            if (lane + 64 * j < n2) sk[rank[j]] = mine[j];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    for (int i = lane; i < k; i += 64) {
+        if (i < n2) {
+            const unsigned long long key = sk[i];
+            D[m * k + i] = ord2f(~(unsigned)(key >> 32));
+            I[m * k + i] = (int64_t)(unsigned)(key & 0xFFFFFFFFu) + label_base;
+        } else {
+            D[m * k + i] = -3.4028234663852886e38f;
+            I[m * k + i] = -1;
         }
     }
 }
@@ -1009,19 +1141,27 @@ int launch_select_rescore_small(SearchWorkspace &ws, int64_t nq, int k, float *D
     ProfScope ps(rescore ? "topk_select_rescore" : "topk_select_radix", s);
     PF_LAUNCH(select_rescore_small_kernel, dim3((unsigned)nq), dim3(256), 0, s,
               reinterpret_cast<const unsigned long long *>(ws.cl), ws.cnt, k, 1, ws.thr, ws.thr_adj, ws.eps, D,
-              I, label_base, ws.overflow, ws.row_ovf, q32, db32, d, nsub, rescore);
+              I, label_base, ws.overflow, ws.row_ovf, q32, db32, d, nsub, rescore, 0);
     PF_HIP(hipGetLastError());
     return 0;
 }
 
+// few_survivors: the caller expects a few dozen survivors per row (second phase of a sharded search): the wave-per-row
+// tier runs first and the workgroup kernels only see the rows it left
 int launch_select_rescore(SearchWorkspace &ws, int64_t nq, int k, int mode, float *D, int64_t *I, int64_t label_base,
-                          const float *q32, const float *db32, int d, int nsub, int rescore, hipStream_t s) {
+                          const float *q32, const float *db32, int d, int nsub, int rescore, hipStream_t s, bool few_survivors) {
     if (ensure_dyn_lds((const void *)select_rescore_kernel, CAP * 8)) return -1;
     ProfScope ps(rescore ? "topk_select_rescore" : "topk_select_radix", s);
-    PF_HIP(hipMemsetAsync(ws.overflow + 1, 0, sizeof(int), s));
+    PF_HIP(hipMemsetAsync(ws.overflow + 1, 0, 2 * sizeof(int), s));
+    static const bool no_wave = getenv("PFANN_NO_WAVE_SELECT") != nullptr;       // A/B aid
+    const int skip_le = (few_survivors && mode == 1 && nsub <= 64 && k <= WAVE_N && !no_wave) ? WAVE_N : 0;
+    if (skip_le)
+        PF_LAUNCH(select_rescore_wave_kernel, dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, s,
+                  reinterpret_cast<const unsigned long long *>(ws.cl), ws.cnt, k, ws.eps, D, I, label_base, ws.overflow, q32, db32, d,
+                  nsub, rescore, nq);
     PF_LAUNCH(select_rescore_small_kernel, dim3((unsigned)nq), dim3(256), 0, s,
               reinterpret_cast<const unsigned long long *>(ws.cl), ws.cnt, k, mode, ws.thr, ws.thr_adj, ws.eps, D,
-              I, label_base, ws.overflow, ws.row_ovf, q32, db32, d, nsub, rescore);
+              I, label_base, ws.overflow, ws.row_ovf, q32, db32, d, nsub, rescore, skip_le);
     PF_LAUNCH(select_rescore_kernel, dim3((unsigned)nq), dim3(1024), CAP * 8, s,
                        reinterpret_cast<const unsigned long long *>(ws.cl), ws.cnt, k, mode, ws.thr, ws.thr_adj, ws.eps, D,
                        I, label_base, ws.overflow, ws.row_ovf, q32, db32, d, nsub, 1, rescore);
