@@ -390,6 +390,8 @@ def main():
         sys.exit(2)
     if use_sharded:
         sharded = ShardedIndex(index, song_pos, k, 1, 0.0, always_exchange=args.force_sharded)
+        if sharded.xs is not None:               # (exchange stream on: the next batch's log-mel front end starts behind the
+            eng.before_front_end = sharded.hold_front_end     # shard scan in flight -- pfann_amd/dist.py: hold_front_end)
 
     # ----------------------------------------------------------------- queries (untimed)
     Q = args.queries * ((emu if emu > 1 else world) if args.scaling == "weak" else 1)      # queries per step, whole job

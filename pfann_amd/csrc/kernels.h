@@ -63,7 +63,8 @@ struct SearchWorkspace {
     int *cnt = nullptr;     // [cap_q]
     float *cs = nullptr;    // [cap_q][cap_c]
     int64_t *cl = nullptr;  // [cap_q][cap_c]
-    int *overflow = nullptr;   // [0] unused, [1] rows left to the big select kernel, [2..3] spare
+    int *overflow = nullptr;   // [0] unused, [1] rows left to the big select kernel, [2] rows the wave-per-row select left, [3] spare
+    int *left = nullptr;       // [cap_q] the rows counted in overflow[2]: the workgroup selects then walk THIS list with a small grid
     int *row_ovf = nullptr;    // [cap_q] set by a select kernel whose row lost survivors (a sub-list overflowed);
                                // topk_fallback_kernel recomputes those rows exactly ON DEVICE and clears the flag:
                                // no host round trip, no retry loop (allocated zeroed)

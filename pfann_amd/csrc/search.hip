@@ -541,9 +541,21 @@ __global__ __launch_bounds__(256) void group_max_select_wave_kernel(const float 
         const int i = lane + 64 * j;
         key[j] = i < G ? f2ord(gmax[m * G + i]) : 0u;           // 0: below every value (f2ord(x) > 0 for every non-NaN x)
     }
-    auto kth_largest = [&](int kk) {                             // key of the kk-th largest of the G values, 1 <= kk <= G
-        unsigned prefix = 0u;
-        for (int bit = 31; bit >= 0; --bit) {
+    // the bits every value shares need no bisection: scores of one query row lie in a narrow band (sign, exponent and the
+    // first mantissa bits agree)
+    unsigned diff = 0u;
+    const unsigned key0 = __shfl(key[0], 0, 64);
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) diff |= (lane + 64 * j < G) ? (key[j] ^ key0) : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) diff |= __shfl_xor(diff, o, 64);
+    const int top_bit = diff ? 31 - __clz(diff) : -1;            // highest bit in which two values differ
+    const unsigned common = top_bit >= 31 ? 0u : (top_bit < 0 ? key0 : (key0 & ~((2u << top_bit) - 1u)));
+    // key of the kk-th largest of the G values, 1 <= kk <= G; stop_bit > 0 leaves the lowest bits zero: a value BELOW the
+    // kk-th largest by less than 2^stop_bit ulps -- fine for a threshold (any lower value is a valid bound), not for topm
+    auto kth_largest = [&](int kk, int stop_bit) {
+        unsigned prefix = common;
+        for (int bit = top_bit; bit >= stop_bit; --bit) {
             const unsigned cand = prefix | (1u << bit);
             int c = 0;
 #pragma unroll
@@ -557,7 +569,7 @@ __global__ __launch_bounds__(256) void group_max_select_wave_kernel(const float 
         const float e = eps != nullptr ? margin_out * eps[m] : 0.f;
         for (int i = mm + lane; i < mtop; i += 64) topm[m * mtop + i] = -INFINITY;
         if (mm > 0) {
-            const unsigned tm = kth_largest(mm);
+            const unsigned tm = kth_largest(mm, 0);
             int base = 0;                                        // strictly better than the mm-th best: fewer than mm of them
 #pragma unroll
             for (int j = 0; j < VPL; ++j) {
@@ -573,7 +585,10 @@ __global__ __launch_bounds__(256) void group_max_select_wave_kernel(const float 
         if (lane == 0) { thr[m] = -INFINITY; if (eps != nullptr) thr_adj[m] = -1000.f * eps[m]; }
         return;
     }
-    const unsigned pk = kth_largest(k);
+    // the threshold: 16 bits below the first differing one are plenty, and never more than the last 8 bits are dropped
+    // (2^-16 of a float's value: the survivor count is steep in the threshold; a sign or exponent difference among the
+    // maxima must not eat the precision)
+    const unsigned pk = kth_largest(k, top_bit > 16 ? (top_bit - 16 < 8 ? top_bit - 16 : 8) : 0);
     if (lane == 0) {
         const float t = ord2f(pk);
         thr[m] = t;
@@ -758,7 +773,7 @@ static int launch_select(SearchWorkspace &ws, int64_t nq, int k, int mode, float
 
 static int ensure_ws(SearchWorkspace &ws, int64_t nq) {
     if (ws.cap_q >= nq) return 0;
-    if (ws.thr) { (void)hipFree(ws.thr); (void)hipFree(ws.cnt); (void)hipFree(ws.cl); (void)hipFree(ws.row_ovf); }
+    if (ws.thr) { (void)hipFree(ws.thr); (void)hipFree(ws.cnt); (void)hipFree(ws.cl); (void)hipFree(ws.row_ovf); (void)hipFree(ws.left); }
     if (!ws.overflow) PF_HIP(hipMalloc(&ws.overflow, 4 * sizeof(int)));    // [1] rows left to the big select kernel
     const int64_t cap = nq < 64 ? 64 : nq;
     if (ws.thr_adj) { (void)hipFree(ws.thr_adj); (void)hipFree(ws.eps); }
@@ -767,6 +782,7 @@ static int ensure_ws(SearchWorkspace &ws, int64_t nq) {
     PF_HIP(hipMalloc(&ws.thr, sizeof(float) * cap));
     PF_HIP(hipMalloc(&ws.cnt, sizeof(int) * cap * 64));      // up to 64 sub-lists per row
     PF_HIP(hipMalloc(&ws.cl, sizeof(unsigned long long) * cap * CAP));
+    PF_HIP(hipMalloc(&ws.left, sizeof(int) * cap));
     PF_HIP(hipMalloc(&ws.row_ovf, sizeof(int) * cap));
     PF_HIP(hipMemset(ws.row_ovf, 0, sizeof(int) * cap));     // kept zero by topk_fallback_kernel afterwards
     ws.cap_q = cap;

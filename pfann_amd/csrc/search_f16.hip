@@ -599,22 +599,20 @@ int launch_scan_f16(const void *dbh, int64_t n, int d, int64_t stride, const voi
 // select_rescore_kernel below, which keeps the rows with more survivors.
 // ------------------------------------------------------------------------------------
 constexpr int SMALL_N = 4096;
-__global__ __launch_bounds__(256) void select_rescore_small_kernel(const unsigned long long *__restrict__ keys,
-                                                                   const int *__restrict__ cnt, int k, int mode,
-                                                                   float *__restrict__ thr, float *__restrict__ thr_adj,
-                                                                   const float *__restrict__ eps, float *__restrict__ D,
-                                                                   int64_t *__restrict__ I, int64_t label_base,
-                                                                   int *overflow, int *__restrict__ row_ovf,
-                                                                   const float *__restrict__ q32,
-                                                                   const float *__restrict__ db32, int d, int nsub,
-                                                                   int rescore, int skip_le) {
+__device__ __forceinline__ void select_rescore_small_row(const int64_t m, const unsigned long long *__restrict__ keys,
+                                                const int *__restrict__ cnt, int k, int mode,
+                                                float *__restrict__ thr, float *__restrict__ thr_adj,
+                                                const float *__restrict__ eps, float *__restrict__ D,
+                                                int64_t *__restrict__ I, int64_t label_base,
+                                                int *overflow, int *__restrict__ row_ovf,
+                                                const float *__restrict__ q32,
+                                                const float *__restrict__ db32, int d, int nsub,
+                                                int rescore) {
     constexpr int NT = 256, KPT = SMALL_N / NT;
-    if (skip_le && overflow[2] == 0) return;          // every row was handled by select_rescore_wave_kernel
     __shared__ __attribute__((aligned(16))) unsigned long long skeys[SMALL_N];
     __shared__ int s_n2, s_bin, s_kk;
     __shared__ int s_off[66];
     __shared__ int hist[256];
-    const int64_t m = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int subcap = CAP / nsub;
     if (tid < 64) {
@@ -639,7 +637,6 @@ __global__ __launch_bounds__(256) void select_rescore_small_kernel(const unsigne
         return;
     }
     const bool over = s_off[65] != 0;
-    if (skip_le && n <= skip_le && !over) return;     // done by select_rescore_wave_kernel
     if (over && mode == 1 && tid == 0) row_ovf[m] = 1;           // topk_fallback_kernel recomputes this row
     if (nsub == 1) {
         for (int i = tid; i < n; i += NT) skeys[i] = keys[m * CAP + i];
@@ -778,6 +775,37 @@ __global__ __launch_bounds__(256) void select_rescore_small_kernel(const unsigne
     }
 }
 
+__global__ __launch_bounds__(256) void select_rescore_small_kernel(const unsigned long long *__restrict__ keys,
+                                                                   const int *__restrict__ cnt, int k, int mode,
+                                                                   float *__restrict__ thr, float *__restrict__ thr_adj,
+                                                                   const float *__restrict__ eps, float *__restrict__ D,
+                                                                   int64_t *__restrict__ I, int64_t label_base,
+                                                                   int *overflow, int *__restrict__ row_ovf,
+                                                                   const float *__restrict__ q32,
+                                                                   const float *__restrict__ db32, int d, int nsub,
+                                                                   int rescore) {
+    select_rescore_small_row(blockIdx.x, keys, cnt, k, mode, thr, thr_adj, eps, D, I, label_base, overflow, row_ovf, q32, db32, d, nsub,
+                             rescore);
+}
+// the rows select_rescore_wave_kernel left (left[0 .. overflow[2])): a small grid walks the list -- normally empty, and an
+// empty launch of one workgroup per query row cost 13 us per 9728 rows
+__global__ __launch_bounds__(256) void select_rescore_small_list_kernel(const unsigned long long *__restrict__ keys,
+                                                                        const int *__restrict__ cnt, int k, int mode,
+                                                                        float *__restrict__ thr, float *__restrict__ thr_adj,
+                                                                        const float *__restrict__ eps, float *__restrict__ D,
+                                                                        int64_t *__restrict__ I, int64_t label_base,
+                                                                        int *overflow, int *__restrict__ row_ovf,
+                                                                        const float *__restrict__ q32,
+                                                                        const float *__restrict__ db32, int d, int nsub,
+                                                                        int rescore, const int *__restrict__ left) {
+    const int n_left = overflow[2];
+    for (int it = blockIdx.x; it < n_left; it += gridDim.x) {
+        select_rescore_small_row(left[it], keys, cnt, k, mode, thr, thr_adj, eps, D, I, label_base, overflow, row_ovf, q32, db32, d, nsub,
+                                 rescore);
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // The same select for rows with at most WAVE_N survivors, ONE WAVEFRONT per row, four rows per workgroup (round 5): the
 // second phase of a sharded search -- every shard emits only rows that can reach the GLOBAL k-th bound, a few dozen per
@@ -793,7 +821,7 @@ __global__ __launch_bounds__(256) void select_rescore_wave_kernel(const unsigned
                                                                   const float *__restrict__ eps, float *__restrict__ D,
                                                                   int64_t *__restrict__ I, int64_t label_base, int *overflow,
                                                                   const float *__restrict__ q32, const float *__restrict__ db32,
-                                                                  int d, int nsub, int rescore, int64_t nq) {
+                                                                  int d, int nsub, int rescore, int64_t nq, int *__restrict__ left) {
     constexpr int KPL = WAVE_N / 64;
     __shared__ __attribute__((aligned(16))) unsigned long long wk[4][WAVE_N];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -811,7 +839,7 @@ __global__ __launch_bounds__(256) void select_rescore_wave_kernel(const unsigned
     }
     const int n = __shfl(incl, 63, 64);
     if (__any(ov) || n > WAVE_N) {
-        if (lane == 0) atomicAdd(overflow + 2, 1);
+        if (lane == 0) left[atomicAdd(overflow + 2, 1)] = (int)m;
         return;
     }
     // gather the sub-lists (sub-list g holds its keys at keys[m*CAP + g*subcap])
@@ -913,7 +941,7 @@ __global__ __launch_bounds__(256) void select_rescore_wave_kernel(const unsigned
 //   mode 0: thr[m] = exact k-th best (or -inf), thr_adj[m] = thr[m] - eps[m]
 //   mode 1: D, I = exact top-k;  list overflow -> overflow flag (+ raised thresholds)
 // ------------------------------------------------------------------------------------
-__device__ inline void select_rescore_body(const unsigned long long *__restrict__ keys,
+__device__ __forceinline__ void select_rescore_body(const unsigned long long *__restrict__ keys,
                                            const int *__restrict__ cnt, int k, int mode,
                                            float *__restrict__ thr, float *__restrict__ thr_adj,
                                            const float *__restrict__ eps, float *__restrict__ D,
@@ -921,11 +949,11 @@ __device__ inline void select_rescore_body(const unsigned long long *__restrict_
                                            int *overflow, int *row_ovf,
                                            const float *__restrict__ q32,
                                            const float *__restrict__ db32, int d, int nsub,
-                                           int skip_small, int rescore) {
+                                           int skip_small, int rescore, int64_t m = -1) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
     __shared__ int s_n2;
     __shared__ int s_off[66];
-    const int64_t m = blockIdx.x;
+    if (m < 0) m = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (skip_small && overflow[1] == 0) return;       // every row was handled by select_rescore_small_kernel
     // gather the row's nsub sub-lists (sub-list g holds cnt[m*nsub+g] keys at keys[m*CAP + g*subcap])
@@ -1104,6 +1132,23 @@ __global__ __launch_bounds__(1024) void select_rescore_kernel(const unsigned lon
     select_rescore_body(keys, cnt, k, mode, thr, thr_adj, eps, D, I, label_base, overflow, row_ovf, q32, db32, d, nsub, skip_small, rescore);
 }
 
+__global__ __launch_bounds__(1024) void select_rescore_list_kernel(const unsigned long long *__restrict__ keys,
+                                                                   const int *__restrict__ cnt, int k, int mode,
+                                                                   float *__restrict__ thr, float *__restrict__ thr_adj,
+                                                                   const float *__restrict__ eps, float *__restrict__ D,
+                                                                   int64_t *__restrict__ I, int64_t label_base,
+                                                                   int *overflow, int *__restrict__ row_ovf,
+                                                                   const float *__restrict__ q32,
+                                                                   const float *__restrict__ db32, int d, int nsub,
+                                                                   int rescore, const int *__restrict__ left) {
+    if (overflow[1] == 0) return;                     // no row of the list had more than SMALL_N survivors
+    const int n_left = overflow[2];
+    for (int it = blockIdx.x; it < n_left; it += gridDim.x) {
+        select_rescore_body(keys, cnt, k, mode, thr, thr_adj, eps, D, I, label_base, overflow, row_ovf, q32, db32, d, nsub, 1, rescore, left[it]);
+        __syncthreads();
+    }
+}
+
 // Last launch of the small-batch search (search.hip, search_small): the rows select_rescore_small_kernel left (more than
 // SMALL_N survivors; normally none: returns after one 4-byte read) and, behind it, the exact fallback for flagged rows
 // (normally none either) -- two launches' worth of "nothing to do" in one.  FB_ELT: element size of the fallback's rows.
@@ -1141,7 +1186,7 @@ int launch_select_rescore_small(SearchWorkspace &ws, int64_t nq, int k, float *D
     ProfScope ps(rescore ? "topk_select_rescore" : "topk_select_radix", s);
     PF_LAUNCH(select_rescore_small_kernel, dim3((unsigned)nq), dim3(256), 0, s,
               reinterpret_cast<const unsigned long long *>(ws.cl), ws.cnt, k, 1, ws.thr, ws.thr_adj, ws.eps, D,
-              I, label_base, ws.overflow, ws.row_ovf, q32, db32, d, nsub, rescore, 0);
+              I, label_base, ws.overflow, ws.row_ovf, q32, db32, d, nsub, rescore);
     PF_HIP(hipGetLastError());
     return 0;
 }
@@ -1154,17 +1199,23 @@ int launch_select_rescore(SearchWorkspace &ws, int64_t nq, int k, int mode, floa
     ProfScope ps(rescore ? "topk_select_rescore" : "topk_select_radix", s);
     PF_HIP(hipMemsetAsync(ws.overflow + 1, 0, 2 * sizeof(int), s));
     static const bool no_wave = getenv("PFANN_NO_WAVE_SELECT") != nullptr;       // A/B aid
-    const int skip_le = (few_survivors && mode == 1 && nsub <= 64 && k <= WAVE_N && !no_wave) ? WAVE_N : 0;
-    if (skip_le)
-        PF_LAUNCH(select_rescore_wave_kernel, dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, s,
-                  reinterpret_cast<const unsigned long long *>(ws.cl), ws.cnt, k, ws.eps, D, I, label_base, ws.overflow, q32, db32, d,
-                  nsub, rescore, nq);
-    PF_LAUNCH(select_rescore_small_kernel, dim3((unsigned)nq), dim3(256), 0, s,
-              reinterpret_cast<const unsigned long long *>(ws.cl), ws.cnt, k, mode, ws.thr, ws.thr_adj, ws.eps, D,
-              I, label_base, ws.overflow, ws.row_ovf, q32, db32, d, nsub, rescore, skip_le);
-    PF_LAUNCH(select_rescore_kernel, dim3((unsigned)nq), dim3(1024), CAP * 8, s,
-                       reinterpret_cast<const unsigned long long *>(ws.cl), ws.cnt, k, mode, ws.thr, ws.thr_adj, ws.eps, D,
-                       I, label_base, ws.overflow, ws.row_ovf, q32, db32, d, nsub, 1, rescore);
+    const bool wave_tier = few_survivors && mode == 1 && nsub <= 64 && k <= WAVE_N && !no_wave;
+    const unsigned long long *keys = reinterpret_cast<const unsigned long long *>(ws.cl);
+    if (wave_tier) {
+        if (ensure_dyn_lds((const void *)select_rescore_list_kernel, CAP * 8)) return -1;
+        PF_LAUNCH(select_rescore_wave_kernel, dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, s, keys, ws.cnt, k, ws.eps, D, I, label_base,
+                  ws.overflow, q32, db32, d, nsub, rescore, nq, ws.left);
+        PF_LAUNCH(select_rescore_small_list_kernel, dim3((unsigned)std::min<int64_t>(nq, 2048)), dim3(256), 0, s, keys, ws.cnt, k, mode,
+                  ws.thr, ws.thr_adj, ws.eps, D, I, label_base, ws.overflow, ws.row_ovf, q32, db32, d, nsub, rescore, ws.left);
+        PF_LAUNCH(select_rescore_list_kernel, dim3((unsigned)std::min<int64_t>(nq, 512)), dim3(1024), CAP * 8, s, keys, ws.cnt, k, mode,
+                  ws.thr, ws.thr_adj, ws.eps, D, I, label_base, ws.overflow, ws.row_ovf, q32, db32, d, nsub, rescore, ws.left);
+        PF_HIP(hipGetLastError());
+        return 0;
+    }
+    PF_LAUNCH(select_rescore_small_kernel, dim3((unsigned)nq), dim3(256), 0, s, keys, ws.cnt, k, mode, ws.thr, ws.thr_adj, ws.eps, D,
+              I, label_base, ws.overflow, ws.row_ovf, q32, db32, d, nsub, rescore);
+    PF_LAUNCH(select_rescore_kernel, dim3((unsigned)nq), dim3(1024), CAP * 8, s, keys, ws.cnt, k, mode, ws.thr, ws.thr_adj, ws.eps, D,
+              I, label_base, ws.overflow, ws.row_ovf, q32, db32, d, nsub, 1, rescore);
     PF_HIP(hipGetLastError());
     return 0;
 }

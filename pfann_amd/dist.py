@@ -213,6 +213,7 @@ class ShardedIndex:
         # exchange with `with sharded.exchange(emb):` and read its results under `with sharded.on_exchange_stream():`
         # (or through events recorded inside the block).  Same kernels, same order within the exchange: same bytes out.
         self.xs = None
+        self.scan_done = None       # (exchange stream on) event: this rank's shard scan of the exchange in flight has run
         if os.environ.get("PFANN_EXCHANGE_STREAM", "0") not in ("0", "") and torch.cuda.is_available() and hasattr(backend, "device"):
             self.xs = torch.cuda.Stream(device=backend.device)
 
@@ -222,6 +223,22 @@ class ShardedIndex:
         they are marked as in use on the exchange stream), then becomes the current stream.  Nothing joins back at the
         end: consumers wait on events recorded inside, or read under on_exchange_stream()."""
         return _ExchangeScope(self.xs, tensors, join=True)
+
+    def hold_front_end(self):
+        """Exchange stream on: the CALLER's stream waits until the shard scan of the exchange in flight has run; call it
+        before launching the next batch's log-mel front end (the tools hang it on Engine.before_front_end).
+
+        Why (round 5, profiles/r5/NOTES.md, tools/ubench/xs_race_probe3.py / 5 / 6): the batched fp16 scan kernel
+        (scan_f16_qres_kernel) running on one stream PERTURBS an FFT kernel that stages through LDS running beside it on
+        another -- this library's melspec_kernel (a handful of windows per launch get one frame's FFT bins wrong: max
+        fingerprint error 3e-2) and rocFFT under torch.fft alike; the encoder's GEMMs, the matcher, sorts, softmax,
+        rocBLAS are not affected, the fp32 scan does not do it, and neither kernel touches memory it does not own (direct-
+        to-LDS loads, LDS ranges, scratch, descriptors and hazards were each ruled out; the trigger depends on the scan
+        kernel's code generation).  Unexplained, so it is AVOIDED: on one stream the two never overlap (the default), and
+        with the exchange stream on the next batch's front end waits the ~3 ms of the scan while the encoder's GEMMs -- 97 %
+        of its time -- still run beside the collectives, which is what the flag is for."""
+        if self.xs is not None and self.scan_done is not None:
+            torch.cuda.current_stream().wait_event(self.scan_done)
 
     def on_exchange_stream(self):
         """Context: the exchange stream is current (no wait on the caller's stream) -- for reading an exchange's results
@@ -283,6 +300,9 @@ class ShardedIndex:
             Dl.append(Dc)
             Il.append(Ic)
         D, I = torch.cat(Dl), torch.cat(Il)
+        if self.xs is not None:
+            self.scan_done = torch.cuda.Event()
+            self.scan_done.record()             # (hold_front_end: the next batch's log-mel kernel starts behind this)
         Qs = (Q + G - 1) // G
         pad = Qs * G - Q
         if pad:

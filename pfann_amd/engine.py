@@ -66,6 +66,9 @@ class Engine:
         if self.handle is None:
             self.handle = self.lib.pfann_create(ctypes.byref(self.cfg), self.device.index)
         self._resample_tables = {}
+        # a callable run (on the caller's stream) before every launch of the log-mel front end; the sharded tools hang
+        # dist.ShardedIndex.hold_front_end here when the exchange stream is on (see there for why)
+        self.before_front_end = None
         if not self.handle:
             raise _l.PfannError("pfann_create failed: " + _l.last_error())
         n_frames = 1 + self.seg_len // self.cfg.stft_hop
@@ -110,6 +113,8 @@ class Engine:
     def melspec(self, segs):
         """MelSpec.forward: [..., seg_len] -> [..., n_mels, T]."""
         self._need_front_end("melspec")
+        if self.before_front_end is not None:
+            self.before_front_end()
         x = self._prep(segs)
         lead = x.shape[:-1]
         x2 = x.reshape(-1, self.seg_len)
@@ -133,6 +138,8 @@ class Engine:
         """Fused path: mono float wav [L] on device -> [n_seg, d] embeddings of the windows
         wav[i*hop : i*hop+seg_len] (mean removal, mel, encoder, optional L2 norm)."""
         self._need_front_end("embed_wav")
+        if self.before_front_end is not None:
+            self.before_front_end()
         w = self._prep(wav).reshape(-1)
         if w.shape[0] < self.seg_len:                      # musicdata.py:82-84
             w = torch.nn.functional.pad(w, (0, self.seg_len - w.shape[0]))
@@ -149,6 +156,8 @@ class Engine:
         """wav: device float mono buffer (many recordings back to back); starts: int64 window
         start offsets (device tensor or array) -> [len(starts), d]."""
         self._need_front_end("embed_windows")
+        if self.before_front_end is not None:
+            self.before_front_end()
         w = self._prep(wav).reshape(-1)
         if isinstance(starts, torch.Tensor):
             st = starts.to(self.device, torch.int64).contiguous()

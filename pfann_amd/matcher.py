@@ -163,6 +163,7 @@ def main(argv=None):
     if isinstance(db_box[0], BaseException):
         raise db_box[0]
     db = db_box[0]
+    db.attach_engine(engine)
     clock.lap("database (rest of its load after the engine was ready)")
     db.warmup(rows=warm * (ranks.world if multi else 1))
     clock.lap("database warm-up")

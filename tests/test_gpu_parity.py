@@ -922,6 +922,16 @@ def test_two_phase_sharded_search_is_the_exact_global_topk(torch_cuda, storage):
     D1, I1 = shards[0].search_bounded(q_t, k, torch.full((nq,), float("-inf"), device="cuda"))
     D2, I2 = shards[0].search(q_t, k)
     assert torch.equal(I1, I2) and torch.equal(D1, D2)
+    # a PENDING bound that bounds nothing (-inf): the second phase runs with the shard's own threshold, i.e. with hundreds of
+    # survivors per row -- more than the wave-per-row select tier takes (round 5): every row goes through the list it leaves
+    # to the workgroup selects, and the answer is still the plain search's, score bits included
+    shards[0].search_bound(q_t, k, m)
+    D3, I3 = shards[0].search_bounded(q_t, k, torch.full((nq,), float("-inf"), device="cuda"))
+    assert torch.equal(I3, I2) and torch.equal(D3, D2)
+    # ... and a tight one (the shard's own exact k-th best): a few dozen survivors per row, the wave tier's own case
+    shards[0].search_bound(q_t, k, m)
+    D4, I4 = shards[0].search_bounded(q_t, k, D2[:, k - 1].contiguous())
+    assert torch.equal(torch.sort(I4, 1).values, torch.sort(I2, 1).values) and torch.equal(D4, D2)
 
 
 @pytest.mark.parametrize("file_sr,seconds,n_ch", [(44100, 125.3, 1), (44100, 61.0, 2), (16000, 7.3, 2), (11025, 0.4, 1),

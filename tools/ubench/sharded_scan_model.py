@@ -142,8 +142,8 @@ def main():
         print(rows[-1], flush=True)
         del shards, s0
         torch.cuda.empty_cache()
-    os.makedirs(os.path.join(REPO, "gpurun_out", "r4"), exist_ok=True)
-    open(os.path.join(REPO, "gpurun_out", "r4", "sharded_scan_model.txt"), "w").write("\n".join(rows) + "\n")
+    os.makedirs(os.path.join(REPO, "gpurun_out", "r5"), exist_ok=True)
+    open(os.path.join(REPO, "gpurun_out", "r5", os.environ.get("MODEL_OUT", "sharded_scan_model.txt")), "w").write("\n".join(rows) + "\n")
 
 
 if __name__ == "__main__":
