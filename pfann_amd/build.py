@@ -13,9 +13,16 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libpfann_amd.so")
 SOURCES = ["api.hip", "mel.hip", "encoder.hip", "encoder_fused.hip", "search.hip", "search_f16.hip", "rerank.hip", "wavio.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "search_common.h"),
+HEADERS = [os.path.abspath(__file__), os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "search_common.h"),
            os.path.join(HERE, "..", "include", "pfann_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"] + os.environ.get("PFANN_HIPCC_FLAGS", "").split()
+# mel.hip without the SLP vectoriser, i.e. without packed-fp32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32:
+# 125 -> 11 in melspec_kernel).  Round 5 (profiles/r5/NOTES.md, tools/ubench/xs_race_probe5.py): a melspec_kernel built WITH
+# them returns wrong FFT bins for a handful of windows per launch whenever the batched fp16 scan (v_mfma_f32_32x32x16_f16)
+# runs on another stream and shares compute units with it -- torch.fft (rocFFT, the same instruction mix) is perturbed the
+# same way, sorts / softmax / GEMMs are not; built without them it is bit-stable beside the scan, and 2 % FASTER alone
+# (1.167 vs 1.196 ms per 9728 windows).  tests/test_gpu_parity.py::test_melspec_is_bit_stable_beside_a_batched_search.
+UNIT_FLAGS = {"mel.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -40,7 +47,7 @@ def build(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + HEADERS):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([hipcc] + FLAGS + UNIT_FLAGS.get(src, []) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

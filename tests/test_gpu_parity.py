@@ -1074,3 +1074,36 @@ def test_owned_songs_follow_the_callers_cut_at_a_rowless_boundary_song(torch_cud
             assert int(res[0]["song"]) == -1
     with pytest.raises(L.PfannError):                               # a cut that does not span the shard's rows
         shards[0][0].load(z[0:10], pos, 0, song_range=(0, 3))
+
+
+def test_melspec_is_bit_stable_beside_a_batched_search(torch_cuda):
+    """Round 5 finding (profiles/r5/NOTES.md): with packed-fp32 VALU instructions in it, melspec_kernel returned wrong FFT
+    bins for a few windows per launch whenever the batched fp16 scan ran on ANOTHER stream at the same time (found through
+    PFANN_EXCHANGE_STREAM=1; two host threads driving an Engine and an index would have hit it too).  mel.hip is built
+    without the SLP vectoriser since (pfann_amd/build.py); this keeps it that way: 4085 windows, six launches, each beside
+    three searches of 4085 query rows on a side stream -- every bit of the log-mel must equal the quiet run's."""
+    torch = torch_cuda
+    from pfann_amd.database import DeviceIndex
+    from pfann_amd.engine import Engine
+    params = cfg("default")
+    eng = Engine(params, 0, max_batch=4096)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    segs = torch.randn((4085, 8000), device="cuda", generator=g) * 0.1
+    db = torch.nn.functional.normalize(torch.randn((120000, 128), device="cuda", generator=g), dim=1)
+    q = torch.nn.functional.normalize(db[:4085] + 0.3 * torch.randn((4085, 128), device="cuda", generator=g), dim=1).contiguous()
+    ix = DeviceIndex(128, 0)
+    ix.load(db, np.array([0, 120000], np.int64), 0)
+    quiet = eng.melspec(segs).clone()
+    ix.search(q, 100)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for rep in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                ix.search(q, 100)
+        got = eng.melspec(segs)
+        torch.cuda.synchronize()
+        bad = int((got != quiet).reshape(4085, -1).any(dim=1).sum())
+        assert bad == 0, "launch %d: %d windows of the log-mel differ from the quiet run (max %.3g)" % (
+            rep, bad, float((got - quiet).abs().max()))
