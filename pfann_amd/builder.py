@@ -43,6 +43,8 @@ class _PinnedPool:
             self.free.setdefault(n, []).append(t)
 
     def get(self, n):
+        # NOTE: the slab handed out holds AT LEAST n samples and may be larger than its own size class (a free larger slab
+        # is reused for a smaller group): callers go by the n they asked for, never by slab.numel()
         # per-file buffers: powers of two; a launch group's slab (tens of MB): the next multiple of 8 M samples -- a
         # 41 M-sample group took a 67 M-sample slab, and a slab's price is its size
         cap = 1 << max(12, int(n - 1).bit_length()) if n <= (1 << 22) else -(-n // (1 << 23)) * (1 << 23)
