@@ -1107,3 +1107,48 @@ def test_melspec_is_bit_stable_beside_a_batched_search(torch_cuda):
         bad = int((got != quiet).reshape(4085, -1).any(dim=1).sum())
         assert bad == 0, "launch %d: %d windows of the log-mel differ from the quiet run (max %.3g)" % (
             rep, bad, float((got - quiet).abs().max()))
+
+
+def test_other_kernels_are_bit_stable_beside_a_batched_search(torch_cuda):
+    """The same question for the rest of the path (profiles/r5/NOTES.md section 6): encoder, sequence matcher and the
+    small-batch search on the caller's stream while a batched fp16 search runs on a side stream -- outputs equal to the quiet
+    run's, bit for bit.  (They were never seen to move; this keeps watch.)"""
+    torch = torch_cuda
+    from pfann_amd.database import DeviceIndex
+    from pfann_amd.engine import Engine
+    params = cfg("default")
+    sd = synth.make_state_dict(params, seed=11)
+    eng = Engine(params, 0, max_batch=1024)
+    eng.load_state_dict(sd)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(6)
+    mel = torch.randn((1024, 256, 32), device="cuda", generator=g)
+    n_songs, seg = 3000, 40
+    db = torch.nn.functional.normalize(torch.randn((n_songs * seg, 128), device="cuda", generator=g), dim=1)
+    pos = np.arange(n_songs + 1, dtype=np.int64) * seg
+    q = torch.nn.functional.normalize(db[:4085] + 0.3 * torch.randn((4085, 128), device="cuda", generator=g), dim=1).contiguous()
+    ix, other = DeviceIndex(128, 0), DeviceIndex(128, 0)
+    ix.load(db, pos, 0)
+    other.load(db, pos, 0)                      # (a second handle: the side stream's search must not share a workspace)
+    nq = 215
+    qs, ql = np.arange(nq, dtype=np.int64) * 19, np.full(nq, 19, np.int32)
+    _, I = ix.search(q, 100)
+    quiet_emb = eng.encode(mel).clone()
+    quiet_res, quiet_ss = ix.match(q, I, qs, ql, 1, 0.0, 0, False, True, to_host=False)
+    quiet_res, quiet_ss = quiet_res.clone(), quiet_ss.clone()
+    quiet_D, quiet_I = ix.search(q[:19].contiguous(), 100)
+    quiet_D, quiet_I = quiet_D.clone(), quiet_I.clone()
+    other.search(q, 100)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for rep in range(4):
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                other.search(q, 100)
+        emb = eng.encode(mel)
+        res, ss = ix.match(q, I, qs, ql, 1, 0.0, 0, False, True, to_host=False)
+        D1, I1 = ix.search(q[:19].contiguous(), 100)
+        torch.cuda.synchronize()
+        assert torch.equal(emb, quiet_emb), "encoder output moved beside a search (launch %d)" % rep
+        assert torch.equal(res, quiet_res) and torch.equal(ss, quiet_ss), "matcher output moved beside a search (launch %d)" % rep
+        assert torch.equal(D1, quiet_D) and torch.equal(I1, quiet_I), "small-batch search moved beside a search (launch %d)" % rep
