@@ -368,15 +368,15 @@ class Database:
             from .dist import ShardedIndex
             self.sharded = ShardedIndex(self.index, self.song_pos, self.top_k, self.frame_shift_mul, self.score_alpha,
                                         group=self.ranks.group, always_exchange=self.ranks.world == 1)
+        # per-song score blocks of one launch: at most this many (score, alignment) pairs in HBM (and as many in the
+        # pinned landing buffer); the CLIs split a launch group's queries accordingly (query_launch_chunks)
+        self.max_score_pairs = int(float(os.environ.get("PFANN_SCORE_BLOCK_MB", "1024")) * (1 << 20)) // 8
 
     def attach_engine(self, engine):
         """The tools call this with the Engine that embeds their queries: with the exchange stream on, the engine's front
         end then starts behind the shard scan of the exchange in flight (dist.ShardedIndex.hold_front_end)."""
         if self.sharded is not None and self.sharded.xs is not None:
             engine.before_front_end = self.sharded.hold_front_end
-        # per-song score blocks of one launch: at most this many (score, alignment) pairs in HBM (and as many in the
-        # pinned landing buffer); the CLIs split a launch group's queries accordingly (query_launch_chunks)
-        self.max_score_pairs = int(float(os.environ.get("PFANN_SCORE_BLOCK_MB", "1024")) * (1 << 20)) // 8
 
     def warmup(self, rows=19 * 64):
         """throw-away queries through search + match: kernel code objects and scratch buffers exist afterwards.  rows: the
