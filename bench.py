@@ -227,6 +227,9 @@ def main():
     ap.add_argument("--no-alt", action="store_true", help="skip the informational fp16-storage run")
     ap.add_argument("--serial", action="store_true", help="time the K batches strictly one at a time instead of two deep")
     ap.add_argument("--no-prof", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic: keep the committed PMC figure instead of measuring it in this run (two short "
+                         "rocprofv3 --pmc passes of a child process, rank 0 at N = 1, after the timed loop)")
     ap.add_argument("--launch-check", action="store_true",
                     help="only start the ranks, meet in the process group, print who is there (n_gpus, ranks_seen, backend, "
                          "devices) and exit: the launcher's own test, runs without a GPU under PFANN_DIST_BACKEND=gloo")
@@ -865,6 +868,29 @@ def main():
                     break
         except (OSError, ValueError, KeyError):
             pass
+    # ... and MEASURED in this run where that is possible (rank 0, N = 1, the default workload's dominant kernel): two short
+    # rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) of a child that pushes one launch group through the encoder
+    # (tools/live_traffic.py).  The GPU is idle here: the timed loop is over.  Any failure keeps the committed figure.
+    if roofline is not None and dom == "conv_gemm_ln_128" and world == 1 and not in_group and have_gpu and not args.no_live_traffic \
+            and not args.encoder_precision:
+        roofline["traffic_live"] = False
+        try:
+            sys.path.insert(0, os.path.join(REPO, "tools"))
+            import live_traffic
+            lt = live_traffic.measure(windows=args.max_batch, device=local_rank)
+            if roofline.get("traffic") is not None:
+                roofline["traffic_committed_profile_value"] = roofline["traffic"]
+            roofline["traffic"] = lt["hbm_bytes_per_launch"]
+            roofline["traffic_live"] = True
+            roofline["traffic_from_committed_profile"] = False
+            roofline["traffic_source"] = "measured in this run: " + lt["command"] + "; " + lt["correction"]
+            roofline["traffic_measurement"] = {kk: lt[kk] for kk in ("fetch_size_kb_per_launch", "write_size_kb_per_launch", "dispatches",
+                                                                      "windows_per_group", "seconds")}
+            log("bench.py: live HBM traffic of the conv GEMMs: %.3f GB per launch (%d dispatches, %.0f s)"
+                % (lt["hbm_bytes_per_launch"] / 1e9, lt["dispatches"], lt["seconds"]))
+        except Exception as x:                       # noqa: BLE001 -- a side leg must never take the headline line with it
+            roofline["traffic_live_error"] = ("%s: %s" % (type(x).__name__, x))[:300]
+            log("bench.py: live traffic leg failed, committed figure kept:", roofline["traffic_live_error"])
     for stag in ("scan_topk", "scan_topk_f16"):
         if stag not in kernels:
             continue

@@ -52,6 +52,24 @@ def test_bench_json_contract_small():
     assert out["seq_score_seam"]["gpu_call_us_median"] <= out["seq_score_seam"]["gpu_call_us_p95"]
 
 
+def test_live_traffic_of_the_conv_gemms_is_measured_under_rocprofv3(tmp_path):
+    """bench.py's roofline.traffic leg (tools/live_traffic.py): two rocprofv3 --pmc passes of a child that pushes one launch
+    group (9728 windows) through the encoder.  Every one of the 15 conv GEMM launches of both repetitions is
+    counted in both passes, and the bytes per launch sit where the committed passes of the whole bench put them (3.76 GB; the
+    algorithmic figure is 3.22 GB), i.e. the counters, their x2 correction and the per-launch averaging are the ones the
+    committed profiles use."""
+    import shutil
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("rocprofv3 not on PATH")
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import live_traffic
+    W = 9728
+    lt = live_traffic.measure(windows=W, keep_dir=str(tmp_path))
+    assert lt["dispatches"] == 30 and lt["launches_per_group"] == 15 and lt["windows_per_group"] == W, lt
+    assert 3.22e9 < lt["hbm_bytes_per_launch"] < 4.3e9, lt
+    assert lt["fetch_size_kb_per_launch"] > 0 and lt["write_size_kb_per_launch"] > 0
+
+
 def test_two_deep_and_serial_loops_decide_alike(tmp_path):
     """bench.py times its batches two deep (H2D of batch i+1 under batch i's kernels, decisions read one batch late);
     --serial runs them one at a time.  Same decisions either way, and the JSON says which loop ran."""
