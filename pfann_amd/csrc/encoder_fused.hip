@@ -614,10 +614,18 @@ void conv_gemm_ln_kernel(FusedGemmParams p) {
 template <bool RELU_BN, bool FIRST>
 __global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParams p) {
     constexpr int BM = 128, BN = 128, BK = 32, LDK = BK + 4, NT = 512, WAVES_N = 4, NP = 64;
-    __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDK + 2 * BN * LDK];
+    // The weight tiles go straight into LDS (buffer_load_dwordx4 ... lds: no staging registers, no ds_write pass; round 5:
+    // all conv GEMMs -1.8 %, profiles/r5/NOTES.md section 8), one __shared__ object per buffer so that the compiler's
+    // LDS-DMA wait tracking tells them apart (alias scopes are per object).  The image is lane-linear, so rows cannot be
+    // padded: 16-byte chunk c of row r sits in slot c ^ ((r >> 1) & 7) and the fragment reads apply the same XOR (as in
+    // scan_f16_qres_kernel).  The activation tiles keep their padded rows (they are written from registers, after the
+    // LayerNorm).  The epilogue's C tile lies over all three objects (+ 640 floats so that it fits).
+    __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDK];
+    __shared__ __attribute__((aligned(16))) float s_b0[BN * BK];
+    __shared__ __attribute__((aligned(16))) float s_b1[BN * BK + 640];
+    float *const As = smem;
     __shared__ __attribute__((aligned(16))) float s_w1[FIRST ? 4 * 256 : 4];   // FIRST: w1[3][Ci], b1[Ci]; Ci <= 256
     __shared__ float s_ml[FIRST ? NP * 16 : 1];          // FIRST: the 5 x 3 log-mel values of every pair of the tile
-    float *const As = smem, *const Bs = smem + 2 * BM * LDK;
     asm volatile("" :: "s"(p.x), "s"(p.w), "s"(p.in_stats), "s"(p.ln_w), "s"(p.ln_b), "s"(p.in_elems), "s"(p.tap_stride),
                  "s"(p.M), "s"(p.N), "s"(p.Ci), "s"(p.rows_per_sample), "s"(p.To), "s"(p.F), "s"(p.T));
     asm volatile("" :: "s"(p.rps_shift), "s"(p.To_shift), "s"(p.axis), "s"(p.in_len), "s"(p.n_tiles_n), "s"(p.n_samples),
@@ -663,7 +671,11 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParam
     const __amdgpu_buffer_rsrc_t srd_st = make_srd(p.in_stats, (unsigned long long)p.n_samples * 8ull);
     // the five input positions of this thread's pair: byte offsets of the activation (relative to sample b_first) and of
     // the LayerNorm affine rows (sample-relative); out-of-range positions (zero padding, rows >= M) read 0 everywhere
-    unsigned va[FIRST ? 1 : 5], vr[5];
+    // positions 0 .. 3 of a pair are in range whenever its rows are (in_len >= 2 * out_len: launcher), position 4 is the
+    // right / bottom zero pad for the last pair of a line: two offsets per operand, the position's j * tap_stride rides in
+    // the loads' scalar offset (not part of the range check: an out-of-range voffset stays out of range)
+    unsigned va[FIRST ? 1 : 2], vr[2];
+    const int ts4 = (int)p.tap_stride * 4;
     float amu, ars;
     {
         const int m = m0 + pair_row0(rowq);
@@ -677,13 +689,10 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParam
         if (p.axis == 0) { a0 = 2 * to; rel = (fo * p.T + a0) * p.Ci; }
         else { a0 = 2 * fo; rel = (a0 * p.T + to) * p.Ci; }
         const int aoff = (b - b_first) * (int)p.in_elems + rel;
-        const int ts = (int)p.tap_stride;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const bool ok = mok && (a0 + j) < p.in_len;
-            if (!FIRST) va[j] = ok ? (unsigned)(aoff + j * ts + col4 * 4) * 4u : BUF_OOB;
-            vr[j] = ok ? (unsigned)(rel + j * ts + col4 * 4) * 4u : BUF_OOB;
-        }
+        const bool ok4 = mok && (a0 + 4) < p.in_len;
+        if (!FIRST) { va[0] = mok ? (unsigned)(aoff + col4 * 4) * 4u : BUF_OOB; va[1] = ok4 ? va[0] : BUF_OOB; }
+        vr[0] = mok ? (unsigned)(rel + col4 * 4) * 4u : BUF_OOB;
+        vr[1] = ok4 ? vr[0] : BUF_OOB;
         if (FIRST) {
             va[0] = 0;
             // the pair's 5 x 3 log-mel values (they do not depend on the channel) -> LDS, two per loader thread:
@@ -700,12 +709,14 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParam
     }
     if (FIRST) __syncthreads();
     unsigned vb[2];
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int n = n0 + rowq + 64 * j;
-        vb[j] = n < p.N ? (unsigned)n * (unsigned)(4 * p.Ci) * 4u + (unsigned)col4 * 16u : BUF_OOB;
+        // LDS chunk (wave * 2 + j) * 64 + lane = (row r, slot cs) fetches chunk cs ^ key(r) of weight row n0 + r (N % 128 == 0)
+        const int ci = (wave * 2 + j) * 64 + lane, r = ci >> 3, cs = ci & 7;
+        vb[j] = (unsigned)(n0 + r) * (unsigned)(4 * p.Ci) * 4u + (unsigned)((cs ^ ((r >> 1) & 7)) * 16);
     }
-    f32x4 px[2], pw[2], pb[2], rb[2], fe1;
+    f32x4 px[2], pw[2], pb[2], fe1;
     const f32x2 mu2 = {amu, amu}, rs2 = {ars, ars};
     // v = POST((z - mean) * rstd * W + B); out-of-range positions: W = B = 0 -> +-0 -> 0 (as in conv_gemm_ln_kernel)
     auto fx = [&](const f32x4 &z4, const f32x4 &w4, const f32x4 &b4) {
@@ -725,21 +736,28 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParam
     };
     int cc_st = 0;                                       // channel chunk of the sub-step whose operands sit in the registers
     // positions of sub-step KIND's operands: {o0, o1}, {e0, e1}, {e2}
-    auto issue = [&](auto kindc, int cc) {               // global loads of sub-step (kind, channel chunk cc)
+    auto issue = [&](auto kindc, int cc, float *Bd) {    // global loads of sub-step (kind, channel chunk cc)
         constexpr int KIND = decltype(kindc)::value;
         constexpr int J0 = KIND == 0 ? 1 : (KIND == 1 ? 0 : 4), J1 = KIND == 0 ? 3 : 2;
         const int so = cc * 4;
         cc_st = cc;
+        // the weight tile first (the buffer form of the LDS load: one offset register per chunk, and vmcnt stays in order
+        // beside the other buffer loads -- the global_load_lds form is a FLAT instruction, after which the compiler waits
+        // for vmcnt(0) at every use of a loaded register)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_b, (__attribute__((address_space(3))) void *)&Bd[(wave_u * 2 + j) * 256], 16,
+                                                     (int)vb[j], (KIND * p.Ci + cc) * 4, 0, 0);
         if (KIND <= 2) {
-            if (!FIRST) px[0] = buf_load4(srd_a, va[FIRST ? 0 : J0], so);
-            pw[0] = buf_load4(srd_w, vr[J0], so); pb[0] = buf_load4(srd_lb, vr[J0], so);
+            const int s0 = so + J0 * ts4;
+            if (!FIRST) px[0] = buf_load4(srd_a, va[FIRST ? 0 : (J0 == 4)], s0);
+            pw[0] = buf_load4(srd_w, vr[J0 == 4], s0); pb[0] = buf_load4(srd_lb, vr[J0 == 4], s0);
         }
         if (KIND <= 1) {
-            if (!FIRST) px[1] = buf_load4(srd_a, va[FIRST ? 0 : J1], so);
-            pw[1] = buf_load4(srd_w, vr[J1], so); pb[1] = buf_load4(srd_lb, vr[J1], so);
+            const int s1 = so + J1 * ts4;
+            if (!FIRST) px[1] = buf_load4(srd_a, va[0], s1);
+            pw[1] = buf_load4(srd_w, vr[0], s1); pb[1] = buf_load4(srd_lb, vr[0], s1);
         }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) rb[j] = buf_load4(srd_b, vb[j], (KIND * p.Ci + cc) * 4);
     };
     // FIRST: z = b1 + sum_t1 w1[t1] * mel[t1] for this thread's four channels of input row J (same FMA order as
     // conv_first_stats_kernel: bias, then taps 0, 1, 2)
@@ -759,7 +777,7 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParam
         }
         return z;
     };
-    auto stash = [&](auto kindc, float *Ad, float *Bd) {  // transform + LDS refill of that sub-step
+    auto stash = [&](auto kindc, float *Ad) {             // transform + LDS refill (activation operand) of that sub-step
         constexpr int KIND = decltype(kindc)::value;
         if (FIRST) {
             if (KIND == 0) { px[0] = first_z(1); px[1] = first_z(3); }
@@ -778,8 +796,6 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParam
         } else {
             *reinterpret_cast<f32x4 *>(&Ad[rowq * LDK + col4 * 4]) = fe1;
         }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4 *>(&Bd[(rowq + 64 * j) * LDK + col4 * 4]) = rb[j];
     };
     f32x16 acc[3];
 #pragma unroll
@@ -790,14 +806,16 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParam
     using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
     const int nch = p.Ci / BK;
     const int l31 = lane & 31, lhalf = lane >> 5;
-    issue(K0{}, 0);
-    stash(K0{}, As, Bs);
+    issue(K0{}, 0, s_b0);
+    stash(K0{}, As);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the weight tile has landed in LDS (the barrier's fence does not wait for it)
     __syncthreads();
+    const int bfrag = (wn * 32 + l31) * BK + ((lhalf ^ ((l31 >> 1) & 7)) * 4);   // this lane's weight chunk of K step 0; step kk: ^ 8 kk
     // one sub-step: MFMAs on LDS buffer PB while the next sub-step goes global -> registers -> buffer PB ^ 1
     auto substep = [&](int ch, auto kindc, auto nextc) {
         constexpr int KIND = decltype(kindc)::value, PB = KIND & 1;
-        const float *Ac = As + PB * (BM * LDK), *Bc = Bs + PB * (BN * LDK);
-        float *An = As + (PB ^ 1) * (BM * LDK), *Bn = Bs + (PB ^ 1) * (BN * LDK);
+        const float *Ac = As + PB * (BM * LDK), *Bc = PB ? s_b1 : s_b0;
+        float *An = As + (PB ^ 1) * (BM * LDK), *Bn = PB ? s_b0 : s_b1;
         const bool more = KIND < 3 || ch + 1 < nch;
         const int cc_next = (KIND < 3 ? ch : ch + 1) * BK;
 #pragma unroll
@@ -805,14 +823,14 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParam
             const f32x4 a0 = *reinterpret_cast<const f32x4 *>(&Ac[(wm * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
             f32x4 a1 = a0;
             if (KIND == 0) a1 = *reinterpret_cast<const f32x4 *>(&Ac[(NP + wm * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
-            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(&Bc[(wn * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(&Bc[bfrag ^ (kk * 8)]);
             if (kk == 0) {
-                if (more) issue(nextc, cc_next);
+                if (more) issue(nextc, cc_next, Bn);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (kk == BK / 8 - 1) {
                 __builtin_amdgcn_sched_barrier(0);
-                if (more) stash(nextc, An, Bn);
+                if (more) stash(nextc, An);
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -824,6 +842,7 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParam
                 else acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[s], a0[s], acc[1], 0, 0, 0);
             }
         }
+        if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next weight tile has landed in LDS before anyone reads it
         __syncthreads();
     };
     for (int ch = 0; ch < nch; ++ch) {
@@ -838,8 +857,16 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParam
     const __amdgpu_buffer_rsrc_t srd_y = make_srd(p.y + (int64_t)m0 * p.N, (unsigned long long)(p.M - m0) * p.N * 4ull);
     const __amdgpu_buffer_rsrc_t srd_bias = make_srd(p.bias, (unsigned long long)p.N * 4ull);
     constexpr int LDC = BN + 4;
-    float *Cs = smem;                                   // [BM][LDC]
-    float *red1 = smem + BM * LDC;                      // [BM][WAVES_N]
+    // the C tile [BM][LDC] lies over the activation buffers and both weight buffers: the three objects must be one contiguous
+    // range (their LDS addresses are constants after lowering: the test folds away; a layout that breaks it traps)
+    const unsigned a0_ = (unsigned)(size_t)(__attribute__((address_space(3))) float *)smem;
+    const unsigned b0_ = (unsigned)(size_t)(__attribute__((address_space(3))) float *)s_b0;
+    const unsigned b1_ = (unsigned)(size_t)(__attribute__((address_space(3))) float *)s_b1;
+    const unsigned lo_ = min(a0_, min(b0_, b1_));
+    const unsigned hi_ = max(a0_ + (unsigned)(2 * BM * LDK * 4), max(b0_ + (unsigned)(BN * BK * 4), b1_ + (unsigned)((BN * BK + 640) * 4)));
+    if (hi_ - lo_ != (unsigned)((2 * BM * LDK + 2 * BN * BK + 640) * 4)) __builtin_trap();
+    float *Cs = (float *)(__attribute__((address_space(3))) float *)(size_t)lo_;
+    float *red1 = Cs + BM * LDC;                        // [BM][WAVES_N]
     float *red2 = red1 + BM * WAVES_N;
     const int G = rps >= BM ? BM : rps;
     const unsigned rowbytes = (unsigned)p.N * 4u;
@@ -1080,7 +1107,8 @@ int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, 
         static const bool no_w22 = getenv("PFANN_NO_W22") != nullptr;
         const int out_len = L.axis == 0 ? L.To : L.Fo;
         if (!no_w22 && (!first || (L.axis == 1 && L.ci <= 256 && getenv("PFANN_NO_W22_FIRST") == nullptr)) && precision == 0 && L.w22 != nullptr && L.stride == 2 && L.pad_lo == 0 && p.k_begin == 0 &&
-            p.k_end == 3 * L.ci && out_len % 2 == 0 && p.M % 2 == 0 && (L.axis == 0 || (L.To <= 64 && 128 % (2 * L.To) == 0)) &&
+            p.k_end == 3 * L.ci && out_len % 2 == 0 && p.in_len >= 2 * out_len && p.M % 2 == 0 &&
+            p.N % 128 == 0 && (L.axis == 0 || (L.To <= 64 && 128 % (2 * L.To) == 0)) &&
             (int64_t)p.N * 4 * p.Ci * 4 < 0x7FFF0000ll) {
             p.w = L.w22;
             ProfScope ps(layer_tag(per_layer ? "conv_gemm_ln_128 w22" : "conv_gemm_ln_128"), s, flops);
