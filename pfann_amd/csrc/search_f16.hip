@@ -278,14 +278,10 @@ __global__ __launch_bounds__(256, DBR == 64 ? 3 : 2) void scan_f16_qres_kernel(S
     constexpr int CPR = ROWB / 16;                // 16-byte chunks per row
     constexpr int NLD = DBR * CPR / 256;          // direct-to-LDS loads per thread per db tile
     static_assert(!GMAX || DBR == 128, "the group-maximum pass assumes 64 groups per slice");
-#ifdef PF_SCAN_OLD
-    __shared__ __attribute__((aligned(1024))) float Bs[2][DBR * ROWB / 4];
-#else
     // one LDS object per db-tile buffer: the compiler's wait tracking for LDS loads works per object (alias scopes), so a
     // tile request into ONE buffer does not put `s_waitcnt vmcnt(0)` in front of the fragment reads of the OTHER
     __shared__ __attribute__((aligned(1024))) float Bs0[DBR * ROWB / 4];
     __shared__ __attribute__((aligned(1024))) float Bs1[DBR * ROWB / 4];
-#endif
     __shared__ int s_cnt[BM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -345,7 +341,6 @@ __global__ __launch_bounds__(256, DBR == 64 ? 3 : 2) void scan_f16_qres_kernel(S
     constexpr int RP = 256 / ROWB;                 // rows per 256 bytes of LDS (1 at d = 128, 2 at d = 64)
     auto key = [](int r) { return (r / RP) & (CPR - 1); };
     const int64_t last_row = (p.nrows - 1) * p.row_stride;
-#ifndef PF_SCAN_OLD
     // (the BUFFER form of the LDS load: one 32-bit offset per chunk against a per-tile descriptor, and -- unlike
     // global_load_lds, a FLAT instruction after which every wait becomes vmcnt(0) / lgkmcnt(0) -- it counts in order)
     unsigned goff[NLD];                            // byte offset of this lane's chunk inside a tile (stride folded in)
@@ -384,47 +379,6 @@ __global__ __launch_bounds__(256, DBR == 64 ? 3 : 2) void scan_f16_qres_kernel(S
     auto tile_step = [&](int64_t t, const float *Bc, float *Bn) {
         if (t + S < t_hi) load_tile(t + S, Bn);
         __builtin_amdgcn_sched_barrier(0);
-#else
-    unsigned long long goff[NLD];                  // byte offset of this lane's chunk inside a tile (stride folded in)
-    int lrow[NLD];
-#pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-        const int ci = (wave * NLD + u) * 64 + lane;
-        const int r = ci / CPR, cs = ci % CPR;
-        lrow[u] = r;
-        goff[u] = (unsigned long long)r * p.row_stride * ROWB + (unsigned)((cs ^ key(r)) * 16);
-    }
-    auto load_tile = [&](int64_t t, int bb) {
-        const int64_t r0 = t * DBR * p.row_stride;
-        const char *base = dbb + r0 * ROWB;
-        if ((t + 1) * DBR <= p.nrows) {      // whole tile in range (uniform): one 64-bit add per load
-#pragma unroll
-            for (int u = 0; u < NLD; ++u)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + goff[u]),
-                                                 (__attribute__((address_space(3))) void *)&Bs[bb][(wave * NLD + u) * 256],
-                                                 16, 0, 0);
-        } else {
-#pragma unroll
-            for (int u = 0; u < NLD; ++u) {
-                // rows past the end: fetch the last row instead (their columns are masked by `nok`)
-                const bool ok = t * DBR + lrow[u] < p.nrows;
-                const char *src = ok ? base + goff[u] : dbb + last_row * ROWB + (goff[u] & (ROWB - 1));
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)&Bs[bb][(wave * NLD + u) * 256],
-                                                 16, 0, 0);
-            }
-        }
-    };
-    if (t_lo < t_hi) load_tile(t_lo, 0);
-    __syncthreads();
-
-    int b = 0;
-#pragma unroll 1
-    for (int64_t t = t_lo; t < t_hi; t += S, b ^= 1) {
-        const float *Bc = &Bs[b][0];
-        if (t + S < t_hi) load_tile(t + S, b ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         f32x16 acc[TM][TN];
         // db fragments one K step ahead of the MFMAs that use them: with four 32-cycle MFMAs per step a wave that reads
         // its fragments only after issuing the previous step's MFMAs waits out the whole LDS latency every step
@@ -511,7 +465,6 @@ __global__ __launch_bounds__(256, DBR == 64 ? 3 : 2) void scan_f16_qres_kernel(S
                     }
                 }
             }
-#ifndef PF_SCAN_OLD
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile has landed (and this tile's survivor stores are out)
         __syncthreads();
     };
@@ -527,19 +480,11 @@ __global__ __launch_bounds__(256, DBR == 64 ? 3 : 2) void scan_f16_qres_kernel(S
             t += S;
         }
     }
-#else
-        __syncthreads();                 // (waits for the tile in flight: vmcnt(0) precedes the barrier)
-    }
-#endif
     if (GMAX) {
         // group maxima -> LDS [128 query rows][64 slots] (the two lane halves of a register are merged: 64 groups per
         // slice; XOR-swizzled by the row: lanes write 32 different rows at the same slot) -> one coalesced 256 B row per
         // query row: gmax[m][seg * 64 + slot]
-#ifdef PF_SCAN_OLD
-        float *Gs = &Bs[0][0];
-#else
         float *Gs = Bs0;
-#endif
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int ml = wm * WM + i * 32 + l31;
