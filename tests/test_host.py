@@ -724,3 +724,54 @@ def test_lazy_launches_keep_at_most_one_sub_launch_ahead():
     assert list(LazyLaunches([], launch)) == []
     one = LazyLaunches([(0, 3)], launch)
     assert [c[:2] for c in one] == [(0, 3)] and one.max_in_flight == 1
+
+
+def test_live_traffic_reads_a_rocpd_database_and_applies_the_gfx950_correction(tmp_path, monkeypatch):
+    """tools/live_traffic.py (bench.py's measured roofline.traffic): per-kernel averages out of a rocpd-shaped sqlite file,
+    counters summed over their hardware instances, FETCH_SIZE doubled / WRITE_SIZE as is, launch-weighted over the conv GEMM
+    kernels only; a run without a matching dispatch raises (bench.py then keeps the committed figure)."""
+    import sqlite3
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import live_traffic as lt
+
+    def make(path, counter, per_kernel):
+        c = sqlite3.connect(path)
+        c.execute("create table kernels (id integer, name text)")
+        c.execute("create table rocpd_info_pmc (id integer, name text)")
+        c.execute("create table rocpd_pmc_event (pmc_id integer, event_id integer, value real)")
+        c.execute("insert into rocpd_info_pmc values (1, ?)", (counter,))
+        c.execute("insert into rocpd_info_pmc values (2, 'OTHER')")
+        kid = 0
+        for name, vals in per_kernel.items():
+            for v in vals:                      # one dispatch; the counter arrives as 4 hardware instances
+                kid += 1
+                c.execute("insert into kernels values (?, ?)", (kid, name))
+                for inst in range(4):
+                    c.execute("insert into rocpd_pmc_event values (1, ?, ?)", (kid, v / 4.0))
+                c.execute("insert into rocpd_pmc_event values (2, ?, 1e9)", (kid,))
+        c.commit()
+        c.close()
+    w22 = "void pfann::conv_gemm_ln_w22_kernel<true, false>(pfann::FusedGemmParams)"
+    plain = "void pfann::conv_gemm_ln_kernel<128, 128, 64, 32, true, false, true, 32, false, false>(pfann::FusedGemmParams)"
+    small = "void pfann::conv_gemm_ln_kernel<64, 64, 32, 32, true, false, true, 32, false, false>(pfann::FusedGemmParams)"
+    fe, wr = str(tmp_path / "f.db"), str(tmp_path / "w.db")
+    make(fe, "FETCH_SIZE", {w22: [1000.0, 3000.0], plain: [100.0], small: [7.0], "pfann::melspec_kernel(pfann::MelArgs)": [5.0]})
+    make(wr, "WRITE_SIZE", {w22: [500.0, 700.0], plain: [50.0], small: [9.0], "pfann::melspec_kernel(pfann::MelArgs)": [5.0]})
+    got = lt.read_counter(fe, "FETCH_SIZE")
+    assert got[w22] == (2000.0, 2) and got[plain] == (100.0, 1)
+    assert lt.GEMM_RE.match(w22) and lt.GEMM_RE.match(plain) and not lt.GEMM_RE.match(small)
+    calls = []
+    monkeypatch.setattr(lt, "one_pass", lambda counter, *a, **k: calls.append(counter) or lt.read_counter(fe if counter == "FETCH_SIZE" else wr, counter))
+    monkeypatch.setattr(lt.shutil, "which", lambda name: "/usr/bin/" + name)
+    out = lt.measure(windows=9728, keep_dir=str(tmp_path))
+    assert calls == ["FETCH_SIZE", "WRITE_SIZE"] and out["dispatches"] == 3
+    f_kb, w_kb = (2000.0 * 2 + 100.0) / 3, (600.0 * 2 + 50.0) / 3
+    assert abs(out["fetch_size_kb_per_launch"] - f_kb) < 1e-9 and abs(out["write_size_kb_per_launch"] - w_kb) < 1e-9
+    assert abs(out["hbm_bytes_per_launch"] - (2 * f_kb + w_kb) * 1024) < 1e-6
+    make(str(tmp_path / "e.db"), "FETCH_SIZE", {small: [7.0]})
+    monkeypatch.setattr(lt, "one_pass", lambda counter, *a, **k: lt.read_counter(str(tmp_path / "e.db"), "FETCH_SIZE"))
+    with pytest.raises(RuntimeError):
+        lt.measure(windows=9728, keep_dir=str(tmp_path))
+    monkeypatch.setattr(lt.shutil, "which", lambda name: None)
+    with pytest.raises(RuntimeError):
+        lt.measure()
