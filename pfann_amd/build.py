@@ -22,7 +22,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"] 
 # runs on another stream and shares compute units with it -- torch.fft (rocFFT, the same instruction mix) is perturbed the
 # same way, sorts / softmax / GEMMs are not; built without them it is bit-stable beside the scan, and 2 % FASTER alone
 # (1.167 vs 1.196 ms per 9728 windows).  tests/test_gpu_parity.py::test_melspec_is_bit_stable_beside_a_batched_search.
-UNIT_FLAGS = {"mel.hip": ["-fno-slp-vectorize"]}
+# search_f16.hip with -fno-honor-nans: the batched scan tests every 32x32 score block with maxima of MFMA results; with NaNs
+# honoured each fmaxf operand is first canonicalised (v_max_f32 x, x): 18 instructions per block instead of 10.  Full pass
+# 2.607 -> 2.548 ms, sampled pass (a running maximum per register) 0.617 -> 0.545 ms per 9728 x 1 M rows, same results
+# (profiles/r5/scan_nnan_ab.txt).  Scores are inner products of finite fp16 rows; +-INFINITY (thresholds, initial maxima)
+# is still honoured.
+UNIT_FLAGS = {"mel.hip": ["-fno-slp-vectorize"], "search_f16.hip": ["-fno-honor-nans"]}
 
 
 def _hipcc():
