@@ -1255,17 +1255,29 @@ struct GramParams { float v[14]; };
 
 __global__ __launch_bounds__(256) void conv_first_gram_stats_kernel(const float *__restrict__ x, float *__restrict__ part,
                                                                     int64_t M, int To, int T, int stride, int pad_lo,
-                                                                    int rps, int P, GramParams g) {
+                                                                    int rps, int P, GramParams g, FastDiv dv_bps, FastDiv dv_to,
+                                                                    int F) {
     const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     float s1 = 0.f, s2 = 0.f;
     int64_t b = 0;
     int r = 0;
     if (m < M) {
-        b = m / rps;
-        r = (int)(m - b * rps);
-        const int f = r / To, to = r - f * To;
-        const int F = rps / To;
+        // sample and row of this position.  rps % 256 == 0 (dv_bps.d = workgroups per sample > 0): the sample is the
+        // workgroup's, by one 32-bit multiply-high; the generic 64-bit division per thread was most of this kernel
+        // (two emulated divisions against three loads and twenty flops)
+        int f, to;
+        if (dv_bps.d > 0) {
+            const int bb = fastdiv((int)blockIdx.x, dv_bps);
+            b = bb;
+            r = ((int)blockIdx.x - bb * dv_bps.d) * 256 + (int)threadIdx.x;
+            f = fastdiv(r, dv_to);
+            to = r - f * To;
+        } else {
+            b = m / rps;
+            r = (int)(m - b * rps);
+            f = r / To; to = r - f * To;
+        }
         const float *xs = x + (b * F + f) * (int64_t)T;
         float xt[3];
 #pragma unroll
@@ -1282,8 +1294,8 @@ __global__ __launch_bounds__(256) void conv_first_gram_stats_kernel(const float 
     s2 = wave_sum(s2);
     const int64_t m_wave = m - lane;                      // first row of this wave's 64-row slot
     if (lane == 0 && m_wave < M) {
-        const int64_t bw = m_wave / rps;
-        const int slot = (int)((m_wave - bw * rps) / 64);
+        const int64_t bw = dv_bps.d > 0 ? b : m_wave / rps;
+        const int slot = dv_bps.d > 0 ? r / 64 : (int)((m_wave - bw * rps) / 64);
         float *o = part + (bw * P + slot) * 2;
         o[0] = s1;
         o[1] = s2;
@@ -1297,8 +1309,11 @@ int launch_conv_first_gram_stats(const SubLayer &L, const float *x, float *part,
     GramParams g;
     for (int i = 0; i < 14; ++i) g.v[i] = gram14[i];
     ProfScope ps("conv_first_gram_stats", s, 4.0 * (double)B * L.F * L.T);
+    FastDiv dv_bps = make_fastdiv(1), dv_to = make_fastdiv(L.To);
+    dv_bps.d = 0;                                         // (0: the generic index arithmetic)
+    if (rps % 256 == 0 && cdiv(M, 256) < 0x7FFFFFFF) dv_bps = make_fastdiv(rps / 256);
     PF_LAUNCH(conv_first_gram_stats_kernel, dim3((unsigned)cdiv(M, 256)), dim3(256), 0, s, x, part, M, L.To, L.T,
-              L.stride, L.pad_lo, rps, fused_out_slots(L, B), g);
+              L.stride, L.pad_lo, rps, fused_out_slots(L, B), g, dv_bps, dv_to, L.Fo);
     PF_HIP(hipGetLastError());
     return 0;
 }
