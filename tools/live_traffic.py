@@ -70,7 +70,7 @@ def one_pass(counter, windows, device, out_dir, timeout_s):
     return read_counter(dbs[0], counter)
 
 
-def measure(windows=9728, device=0, timeout_s=240, keep_dir=None):
+def measure(windows=9728, device=0, timeout_s=90, keep_dir=None):
     """-> dict(hbm_bytes_per_launch, fetch_size_kb_per_launch, write_size_kb_per_launch, dispatches, kernels, seconds, ...).
     Raises on any failure (no rocprofv3, a pass that times out, no matching dispatch): the caller keeps its fallback."""
     if shutil.which("rocprofv3") is None:
