@@ -63,10 +63,21 @@ def one_pass(counter, windows, device, out_dir, timeout_s):
         env.pop(k, None)
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", out_dir, "-o", "pmc", "--",
            sys.executable, os.path.abspath(__file__), "--child", str(windows), str(device)]
-    r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+    # its own process group: a pass that has to be given up takes the profiler AND the child under it along
+    proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        _, err = proc.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        import signal
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        proc.communicate()
+        raise RuntimeError("rocprofv3 --pmc %s: no result within %d s" % (counter, timeout_s))
     dbs = glob.glob(os.path.join(out_dir, "**", "*_results.db"), recursive=True)
-    if r.returncode != 0 or not dbs:
-        raise RuntimeError("rocprofv3 --pmc %s: rc %d, %d result files: %s" % (counter, r.returncode, len(dbs), (r.stderr or "")[-400:]))
+    if proc.returncode != 0 or not dbs:
+        raise RuntimeError("rocprofv3 --pmc %s: rc %d, %d result files: %s" % (counter, proc.returncode, len(dbs), (err or "")[-400:]))
     return read_counter(dbs[0], counter)
 
 
