@@ -898,6 +898,73 @@ def main():
         gbs = (r_hi - r_lo) * d * 4 / (ks["avg_us"] * 1e-6) / 1e9
         ks.update({"db_GBps": gbs, "db_hbm_frac": gbs / PEAK_HBM})
 
+    # ---------------------------------- throughput vs launch-group size (round 6)
+    # the whole step -- PCM resident in HBM -> mono -> log-mel -> encoder -> exact top-k -> candidates -> sequence score ->
+    # decisions on the host -- for ONE launch group of n queries (19 n windows), with the plan the library picks for that
+    # batch on its own (no pfann_set_plan_batch), one group at a time (the host waits for each group's decisions: the
+    # latency a service with n concurrent queries sees).  Every figure elsewhere is at 9728-window groups or at one query.
+    batch_curve = None
+    if prof and world == 1 and emu <= 1 and not use_sharded and not args.no_alt:
+        import ctypes
+        batch_curve = {"what": "whole step for one launch group of n ten-second queries against the %d-row db, default plan of each "
+                               "batch size, PCM resident in HBM, decisions read back on the host after every group" % n_rows,
+                       "points": []}
+
+        def stage_of_tag(tag):
+            if tag.startswith("scan_topk") or tag.startswith("topk_"):
+                return "scan"
+            if tag.startswith("seq_match") or tag.startswith("match_") or tag.startswith("song_scores"):
+                return "matcher"
+            return "encoder"
+        max_q = min(Q, args.max_batch // QUERY_SEGS)
+        for nq_c in (1, 4, 16, 64, 256, 512):
+            if nq_c > max_q:
+                continue
+            nw = nq_c * QUERY_SEGS
+            pcm_c = pcm_dev[: nq_c * q_len].contiguous()
+            st_c = starts_dev[:nw].contiguous()
+            qs_c, ql_c = np.arange(nq_c, dtype=np.int64) * QUERY_SEGS, np.full(nq_c, QUERY_SEGS, np.int32)
+
+            def group():
+                e_c = eng.embed_windows(eng.pcm16_to_mono(pcm_c), st_c)
+                D_c, I_c = index.search(e_c, k)
+                return index.match(e_c, I_c, qs_c, ql_c)[0]
+            for _ in range(3):
+                r_c = group()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            group()
+            torch.cuda.synchronize()
+            reps = int(max(3, min(200, 0.4 / max(time.perf_counter() - t1, 1e-5))))
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                r_c = group()
+            torch.cuda.synchronize()
+            el_c = (time.perf_counter() - t1) / reps
+            lib.pfann_prof_reset()
+            lib.pfann_prof_enable(1)
+            for _ in range(3):
+                group()
+            torch.cuda.synchronize()
+            lib.pfann_prof_enable(0)
+            st_ms = {"encoder": 0.0, "scan": 0.0, "matcher": 0.0}
+            bufc = ctypes.create_string_buffer(4096)
+            lib.pfann_prof_tags(bufc, 4096)
+            for tag in bufc.value.decode().split(","):
+                if tag:
+                    cc = ctypes.c_int64(0)
+                    st_ms[stage_of_tag(tag)] += lib.pfann_prof_elapsed_ms(tag.encode(), ctypes.byref(cc)) / 3
+            same_c = int(np.sum((r_c["song"] == res["song"][:nq_c]) & (r_c["offset"] == res["offset"][:nq_c])))
+            batch_curve["points"].append({"queries": nq_c, "windows": nw, "ms_per_group": round(1e3 * el_c, 4),
+                                          "segments_per_s": round(nw / el_c, 1),
+                                          "kernel_ms_by_stage": {kk: round(v, 4) for kk, v in st_ms.items()},
+                                          "decisions_identical_to_the_timed_step": "%d/%d" % (same_c, nq_c)})
+        top = batch_curve["points"][-1]["segments_per_s"] if batch_curve["points"] else None
+        for pt in batch_curve["points"]:
+            pt["fraction_of_largest_group_rate"] = round(pt["segments_per_s"] / top, 4)
+        log("batch curve:", [(pt["windows"], pt["segments_per_s"]) for pt in batch_curve["points"]])
+        lib.pfann_prof_reset()
+
     # ---------------------------------- single-query scan regime (HBM-bound; SURVEY §8d note)
     single = None
     if prof and world == 1:
@@ -991,10 +1058,24 @@ def main():
     # whole database): the driver runs N = 1, 2, 4, 8 back to back on one node, so the N = 1 run leaves its figure in the
     # system temp dir; without one, the committed record of this round's N = 1 run is quoted, and says so
     carry = os.path.join(tempfile.gettempdir(), "pfann_bench_cpu_baseline_n1.json")
-    job = {"db_songs": n_songs, "snr": args.snr}
+    # the carry is only quoted by a run of the SAME bench.py and library (hashes), the same job and sample sizes, on the same
+    # host, and at most six hours later: a stale file from another commit / box / workload is skipped, not passed off
+    import hashlib
+    import socket
+
+    def _sha16(path):
+        try:
+            return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+        except OSError:
+            return None
+    job = {"db_songs": n_songs, "snr": args.snr, "queries": Q, "max_batch": args.max_batch,
+           "cpu_queries": args.cpu_queries, "cpu_pool_queries": args.cpu_pool_queries,
+           "bench_py_sha16": _sha16(os.path.abspath(__file__)),
+           "lib_sha16": _sha16(os.path.join(REPO, "pfann_amd", "libpfann_amd.so")), "host": socket.gethostname()}
+    CARRY_MAX_AGE_S = 6 * 3600
     if rank == 0 and cpu is not None and world == 1:
         try:
-            json.dump({"job": job, "cpu_baseline": cpu}, open(carry, "w"))
+            json.dump({"job": job, "written_unix": time.time(), "cpu_baseline": cpu}, open(carry, "w"))
         except OSError:
             pass
     elif rank == 0 and cpu is None and world > 1 and not args.no_cpu_baseline:
@@ -1004,8 +1085,8 @@ def main():
                 [(f, os.path.relpath(f, REPO) + " (committed N = 1 run of the default job, another box)") for f in committed]:
             try:
                 got = json.load(open(src))
-                if src == carry and got.get("job") != job:
-                    continue                       # (a reduced-workload run left it: not this job's baseline)
+                if src == carry and (got.get("job") != job or not (0 <= time.time() - float(got.get("written_unix", 0)) <= CARRY_MAX_AGE_S)):
+                    continue                       # (another commit, workload, host or day left it: not this series' baseline)
                 got = got.get("cpu_baseline")
                 if got and "value" in got:
                     cpu = dict(got, carried_from=label, measured_in_this_run=False)
@@ -1078,7 +1159,7 @@ def main():
                              "inside the timed region"),
             "serial": serial,
             "hbm_resident": pcie, "seq_score_seam": seam_info, "cli": cli,
-            "alt_modes": alt, "other_scaling_mode": other_mode, "scan_throughput": scan_throughput, "critical_path": critical_path, "collectives": collectives,
+            "alt_modes": alt, "batch_curve": batch_curve, "other_scaling_mode": other_mode, "scan_throughput": scan_throughput, "critical_path": critical_path, "collectives": collectives,
             "kernels": {t: {kk: (float("%.4g" % vv) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                         for t, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
         }

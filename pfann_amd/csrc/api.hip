@@ -670,6 +670,7 @@ void pfann_db_destroy(pfann_db *db) {
     if (db->ws.thr_adj) { (void)hipFree(db->ws.thr_adj); (void)hipFree(db->ws.eps); }
     if (db->ws.qh) (void)hipFree(db->ws.qh);
     if (db->ws.row_ovf) (void)hipFree(db->ws.row_ovf);
+    if (db->ws.left) (void)hipFree(db->ws.left);
     if (db->match_scratch) (void)hipFree(db->match_scratch);
     if (db->seq_scratch) (void)hipFree(db->seq_scratch);
     if (db->seq_host) (void)hipHostFree(db->seq_host);

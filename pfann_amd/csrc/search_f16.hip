@@ -280,8 +280,11 @@ __global__ __launch_bounds__(256, DBR == 64 ? 3 : 2) void scan_f16_qres_kernel(S
     static_assert(!GMAX || DBR == 128, "the group-maximum pass assumes 64 groups per slice");
     // one LDS object per db-tile buffer: the compiler's wait tracking for LDS loads works per object (alias scopes), so a
     // tile request into ONE buffer does not put `s_waitcnt vmcnt(0)` in front of the fragment reads of the OTHER
-    __shared__ __attribute__((aligned(1024))) float Bs0[DBR * ROWB / 4];
-    __shared__ __attribute__((aligned(1024))) float Bs1[DBR * ROWB / 4];
+    // (Bs0 doubles as the [128][64] group-maxima tile of the GMAX epilogue: sized for it on its own, never relying on Bs1
+    // lying behind it -- at d = 64 a db tile is only half that)
+    constexpr int TILE_F = DBR * ROWB / 4, GS_F = GMAX ? BM * 64 : 0;
+    __shared__ __attribute__((aligned(1024))) float Bs0[TILE_F > GS_F ? TILE_F : GS_F];
+    __shared__ __attribute__((aligned(1024))) float Bs1[TILE_F];
     __shared__ int s_cnt[BM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(256, DBR == 64 ? 3 : 2) void scan_f16_qres_kernel(S
         const int ci = (wave * NLD + u) * 64 + lane;
         const int r = ci / CPR, cs = ci % CPR;
         lrow[u] = r;
-        goff[u] = (unsigned)(r * (int)p.row_stride * ROWB) + (unsigned)((cs ^ key(r)) * 16);
+        goff[u] = (unsigned)((unsigned long long)r * (unsigned long long)p.row_stride * ROWB) + (unsigned)((cs ^ key(r)) * 16);   // (launchers: qres_stride_ok)
     }
     auto load_tile = [&](int64_t t, float *Bd) {
         const int64_t r0 = t * DBR * p.row_stride;
@@ -480,11 +483,12 @@ __global__ __launch_bounds__(256, DBR == 64 ? 3 : 2) void scan_f16_qres_kernel(S
             t += S;
         }
     }
-    if (GMAX) {
+    if constexpr (GMAX) {
         // group maxima -> LDS [128 query rows][64 slots] (the two lane halves of a register are merged: 64 groups per
         // slice; XOR-swizzled by the row: lanes write 32 different rows at the same slot) -> one coalesced 256 B row per
         // query row: gmax[m][seg * 64 + slot]
         float *Gs = Bs0;
+        static_assert(sizeof(Bs0) >= BM * 64 * sizeof(float), "group-maxima tile must fit its own LDS object");
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int ml = wm * WM + i * 32 + l31;
@@ -511,6 +515,13 @@ __global__ __launch_bounds__(256, DBR == 64 ? 3 : 2) void scan_f16_qres_kernel(S
     if (tid < BM && m0 + tid < p.nq) p.cnt[(m0 + tid) * S + seg] = s_cnt[tid];
 }
 
+// The query-stationary kernel addresses a db tile with 32-bit chunk offsets against a per-tile descriptor of 0x7FFFFFF0 bytes:
+// the last row of a strided 128-row tile must lie inside it (stride <= ~66 k, i.e. shards below ~268 M rows for the ladder's
+// largest stride); beyond that the launchers take the generic kernel / the survivor ladder.
+static inline bool qres_stride_ok(int64_t stride, int d) {
+    return 127ll * stride * (2ll * d) + 2ll * d <= 0x7FFFFFF0ll;
+}
+
 // Sampled group-maximum pass (every `stride`-th row): fills gmax[nq][*n_groups_out] for group_max_select.
 // Returns 1 (not applicable: use the survivor ladder) when the shapes do not give >= 4 k groups per row.
 int launch_scan_f16_gmax(const void *dbh, int64_t n, int d, int64_t stride, const void *qh, int64_t nq, int k,
@@ -523,7 +534,7 @@ int launch_scan_f16_gmax(const void *dbh, int64_t n, int d, int64_t stride, cons
     p.thr = nullptr; p.cnt = ws.cnt; p.keys = nullptr;
     p.n_tiles_m = cdiv(nq, 128);
     const int64_t db_tiles = cdiv(p.nrows, 128);
-    if (!(d == 128 || d == 64) || nq < 1024 || db_tiles < 16) return 1;
+    if (!(d == 128 || d == 64) || nq < 1024 || db_tiles < 16 || !qres_stride_ok(stride, d)) return 1;
     int S = (int)(2048 / p.n_tiles_m);
     S = S < 1 ? 1 : (S > 32 ? 32 : S);
     // no more groups than the threshold needs: 5 k of them (64 per slice) give the k-th best group maximum the same quality
@@ -576,7 +587,7 @@ int launch_scan_f16(const void *dbh, int64_t n, int d, int64_t stride, const voi
     p.n_tiles_m = cdiv(nq, 128);
     const int64_t db_tiles = cdiv(p.nrows, 128);
     static const bool no_qres = getenv("PFANN_NO_QRES") != nullptr;
-    if (thr_adj != nullptr && allow_sublists && !no_qres && (d == 128 || d == 64) && nq >= 1024 && db_tiles >= 16) {
+    if (thr_adj != nullptr && allow_sublists && !no_qres && (d == 128 || d == 64) && nq >= 1024 && db_tiles >= 16 && qres_stride_ok(stride, d)) {
         // S interleaved db slices: about four rounds of the 512 resident workgroups, sub-lists of >= 256
         int S = (int)(2048 / p.n_tiles_m);
         S = S < 1 ? 1 : (S > 32 ? 32 : S);

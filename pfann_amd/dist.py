@@ -240,6 +240,14 @@ class ShardedIndex:
         if self.xs is not None and self.scan_done is not None:
             torch.cuda.current_stream().wait_event(self.scan_done)
 
+    def _mark_scan_done(self):
+        """(exchange stream on) records the event hold_front_end waits for: every scan-class kernel of the exchange in
+        flight -- sampled pass, bound pass, full pass, selects -- has been queued in front of it, on every path of
+        search_global (the one-shard shortcut included)"""
+        if self.xs is not None:
+            self.scan_done = torch.cuda.Event()
+            self.scan_done.record()             # (hold_front_end: the next batch's log-mel kernel starts behind this)
+
     def on_exchange_stream(self):
         """Context: the exchange stream is current (no wait on the caller's stream) -- for reading an exchange's results
         back without queueing the copy behind the NEXT batch's encoder."""
@@ -282,7 +290,9 @@ class ShardedIndex:
         (an all-gather of everything was 93 MB per rank and step at 8 GPUs) and merges 1/G of the rows."""
         G, k, Q = self.world, self.k, q.shape[0]
         if G == 1 and not self.always_exchange:
-            return self.b.search(q, k)
+            out = self.b.search(q, k)
+            self._mark_scan_done()
+            return out
         # Two-phase shard search: every rank extracts from its sampled pass the m best scores of each row (m different
         # real rows of its shard, lowered to bounds of their exact scores), the values are all-gathered (4 m bytes per row
         # and rank) and the k-th largest of a row's union bounds its k-th best over ALL shards from below; the full pass
@@ -300,9 +310,7 @@ class ShardedIndex:
             Dl.append(Dc)
             Il.append(Ic)
         D, I = torch.cat(Dl), torch.cat(Il)
-        if self.xs is not None:
-            self.scan_done = torch.cuda.Event()
-            self.scan_done.record()             # (hold_front_end: the next batch's log-mel kernel starts behind this)
+        self._mark_scan_done()
         Qs = (Q + G - 1) // G
         pad = Qs * G - Q
         if pad:

@@ -1109,6 +1109,51 @@ def test_melspec_is_bit_stable_beside_a_batched_search(torch_cuda):
             rep, bad, float((got - quiet).abs().max()))
 
 
+AGGRESSORS = {
+    # name: (d, query rows, db rows) -> the scan-class kernels one search call of that shape launches (csrc/search.hip: search_topk)
+    "d64_qres": (64, 4085, 120000),         # scan_f16_qres_kernel<4,true> (sampled pass) + scan_f16_qres_kernel<4> (full pass)
+    "d128_generic": (128, 1000, 300000),    # < 1024 query rows: the survivor ladder on scan_f16_kernel<1> (sampled levels) and <4> (full pass)
+    "d128_f16_storage": (128, 4085, 120000),  # fp16-only storage: scan_f16_qres_kernel<8,true,128> + <8,false,64>, s16 scores final
+}
+
+
+@pytest.mark.parametrize("aggressor", sorted(AGGRESSORS))
+@pytest.mark.parametrize("victim", ["stft1024", "fft512"])
+def test_melspec_is_bit_stable_beside_every_scan_class_kernel(torch_cuda, aggressor, victim):
+    """Round 6: the guard above covers scan_f16_qres_kernel<8,true,128> + <8,false,64> (one d = 128 search
+    call runs both) beside the default log-mel.  The same watch for the other instantiations of the fp16-MFMA scan -- d = 64
+    (KS = 4), the generic scan_f16_kernel<1> / <4> of the survivor ladder, fp16-only storage -- and for the second FFT size
+    of melspec_kernel (stft_n = 512: a different radix plan): every bit of the log-mel equal to the quiet run's."""
+    torch = torch_cuda
+    from pfann_amd.database import DeviceIndex
+    from pfann_amd.engine import Engine
+    params = cfg("default")
+    if victim == "fft512":
+        params.update(stft_n=512, stft_hop=128, n_mels=96)
+    d, nq, n = AGGRESSORS[aggressor]
+    eng = Engine(params, 0, max_batch=4096)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(15)
+    segs = torch.randn((4085, 8000), device="cuda", generator=g) * 0.1
+    db = torch.nn.functional.normalize(torch.randn((n, d), device="cuda", generator=g), dim=1)
+    q = torch.nn.functional.normalize(db[:nq] + 0.3 * torch.randn((nq, d), device="cuda", generator=g), dim=1).contiguous()
+    ix = DeviceIndex(d, 0, storage="f16") if aggressor == "d128_f16_storage" else DeviceIndex(d, 0)
+    ix.load(db, np.array([0, n], np.int64), 0)
+    quiet = eng.melspec(segs).clone()
+    ix.search(q, 100)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for rep in range(4):
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                ix.search(q, 100)
+        got = eng.melspec(segs)
+        torch.cuda.synchronize()
+        bad = int((got != quiet).reshape(4085, -1).any(dim=1).sum())
+        assert bad == 0, "%s beside %s, launch %d: %d windows of the log-mel differ from the quiet run (max %.3g)" % (
+            victim, aggressor, rep, bad, float((got - quiet).abs().max()))
+
+
 def test_other_kernels_are_bit_stable_beside_a_batched_search(torch_cuda):
     """The same question for the rest of the path (profiles/r5/NOTES.md section 6): encoder, sequence matcher and the
     small-batch search on the caller's stream while a batched fp16 search runs on a side stream -- outputs equal to the quiet

@@ -83,14 +83,15 @@ def parse_stdout(text):
     return stages, total
 
 
-def run(n_songs=10000, n_queries=2000, snr=0.0, device=0, keep=False, workdir=None, log=print, gpus=1, tool_timeout_s=3600):
+def run(n_songs=10000, n_queries=2000, snr=0.0, device=0, keep=False, workdir=None, log=print, gpus=1, tool_timeout_s=3600, config="default"):
     """gpus > 1: both tools are started with PFANN_GPUS=gpus and launch their own ranks, one per GPU (the database is
     then built by, and sharded over, all of them)."""
     import torch
     from pfann_amd import synth
     from pfann_amd.utils import read_config
     dev = torch.device("cuda", device)
-    params = read_config(os.path.join(REPO, "configs", "default.json"))
+    params = read_config(os.path.join(REPO, "configs", config + ".json"))      # (default / seg / n640d64: same segment geometry)
+    d_emb = params["model"]["d"]
     need = n_songs * SEG_PER_SONG * 4000 * 2 * 1.02 + n_queries * 160000 + n_songs * SEG_PER_SONG * 128 * 4 * 2.2 + \
         n_queries * n_songs * 8
     work = workdir or pick_tmp(need)
@@ -147,7 +148,7 @@ def run(n_songs=10000, n_queries=2000, snr=0.0, device=0, keep=False, workdir=No
         if gpus > 1:
             env["PFANN_GPUS"] = str(gpus)
         db = os.path.join(work, "db")
-        out = {"songs": n_songs, "queries": n_queries, "snr_db": snr, "dir": os.path.dirname(work), "gpus": gpus,
+        out = {"config": config, "songs": n_songs, "queries": n_queries, "snr_db": snr, "dir": os.path.dirname(work), "gpus": gpus,
                "decode_workers": int(os.environ.get("PFANN_DECODE_WORKERS", "8")),
                "wav_bytes": int(n_songs * SEG_PER_SONG * 8000 + n_queries * 160000)}
         env["PFANN_STARTUP_TIMING"] = "1"
@@ -161,7 +162,7 @@ def run(n_songs=10000, n_queries=2000, snr=0.0, device=0, keep=False, workdir=No
         stages, total = parse_stdout(r.stdout)
         n_seg = n_songs * SEG_PER_SONG
         key = np.fromfile(os.path.join(db, "landmarkKey"), dtype=np.int32)
-        assert int(key.sum()) == n_seg and os.path.getsize(os.path.join(db, "embeddings")) == n_seg * 128 * 4
+        assert int(key.sum()) == n_seg and os.path.getsize(os.path.join(db, "embeddings")) == n_seg * d_emb * 4
         out["builder"] = {"segments": n_seg, "process_wall_s": round(wall, 3), "total_build_time_s": total,
                           "segments_per_s_process": round(n_seg / wall, 1),
                           "segments_per_s": round(n_seg / total, 1) if total else None, "stages_s": stages,
@@ -205,9 +206,10 @@ if __name__ == "__main__":
     ap.add_argument("--snr", type=float, default=0.0)
     ap.add_argument("--gpus", type=int, default=1, help="> 1: the tools start their own ranks (PFANN_GPUS)")
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--config", default="default", help="configs/<name>.json: default, seg, n640d64")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
-    res = run(a.songs, a.queries, a.snr, keep=a.keep, log=lambda *x: print(*x, file=sys.stderr, flush=True), gpus=a.gpus)
+    res = run(a.songs, a.queries, a.snr, keep=a.keep, log=lambda *x: print(*x, file=sys.stderr, flush=True), gpus=a.gpus, config=a.config)
     print(json.dumps(res))
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)

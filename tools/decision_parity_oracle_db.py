@@ -65,7 +65,7 @@ def classify(j, g_song, g_off, pool, params, sd, queries, k):
             "product_alignment_among_oracle_candidates": bool(in_cands), "closest_row_to_kth": float(near_kth)}
 
 
-def run(n_songs=2000, n_queries=2000, snr=0.0, workers=32, log=print, bank="torchaudio"):
+def run(n_songs=2000, n_queries=2000, snr=0.0, workers=32, log=print, bank="torchaudio", config="default"):
     """bank: which statement of the (unpinned) mel filter bank the oracle's front-end uses -- "torchaudio": its restatement of
     torchaudio's own float32 construction (oracle/melspec.mel_filterbank_torchaudio: what a reference installation computes);
     "float64": the bank written from the definition in float64 (oracle/melspec.mel_filterbank).  The two are <= 3.8e-5 apart
@@ -74,12 +74,12 @@ def run(n_songs=2000, n_queries=2000, snr=0.0, workers=32, log=print, bank="torc
     import oracle_pool
     from pfann_amd import synth
     from pfann_amd.utils import read_config
-    params = read_config(os.path.join(REPO, "configs", "default.json"))
+    params = read_config(os.path.join(REPO, "configs", config + ".json"))
     params["indexer"] = dict(params["indexer"], index_factory="Flat")
     k, d, hop_s = params["indexer"]["top_k"], params["model"]["d"], params["hop_size"]
     sd = synth.make_state_dict_calibrated(params, seed=123)
     t0 = time.time()
-    cb = cli_bench.run(n_songs, n_queries, snr, keep=True, log=log)
+    cb = cli_bench.run(n_songs, n_queries, snr, keep=True, log=log, config=config)
     if "skipped" in cb:
         return cb
     work = cb["workdir"]
@@ -116,7 +116,7 @@ def run(n_songs=2000, n_queries=2000, snr=0.0, workers=32, log=print, bank="torc
             c.update(query=int(j), product=[int(g_song[j]), float(g_sec[j]), float(g_score[j])],
                      oracle=[int(o_song[j]), float(o_sec[j]), float(o_score[j])])
             flips.append(c)
-        out = {"config": "default (index_factory Flat)", "db_songs": n_songs, "db_rows": int(pool["db"].shape[0]), "queries": n_queries,
+        out = {"config": config + " (index_factory Flat)", "db_songs": n_songs, "db_rows": int(pool["db"].shape[0]), "queries": n_queries,
                "snr_db": snr, "top_k": k,
                "product": "builder.py + matcher.py as subprocesses on WAV files", "oracle": "oracle_pool.run_files: own reader, own "
                "database (every song embedded by oracle/encoder.py on the host), python-path matcher (database.py:117-166)",
@@ -162,9 +162,10 @@ if __name__ == "__main__":
     ap.add_argument("--snr", type=float, default=0.0)
     ap.add_argument("--workers", type=int, default=32)
     ap.add_argument("--bank", default="torchaudio", choices=["torchaudio", "float64"])
+    ap.add_argument("--config", default="default", help="configs/<name>.json: default, seg, n640d64")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
-    r = run(a.songs, a.queries, a.snr, a.workers, log=lambda *x: print(*x, file=sys.stderr, flush=True), bank=a.bank)
+    r = run(a.songs, a.queries, a.snr, a.workers, log=lambda *x: print(*x, file=sys.stderr, flush=True), bank=a.bank, config=a.config)
     print(json.dumps({k: v for k, v in r.items() if k not in ("flips", "cli")}, indent=1), "\nflips:", json.dumps(r.get("flips", []))[:3000])
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
