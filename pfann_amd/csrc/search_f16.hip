@@ -285,6 +285,12 @@ __global__ __launch_bounds__(256, DBR == 64 ? 3 : 2) void scan_f16_qres_kernel(S
     constexpr int TILE_F = DBR * ROWB / 4, GS_F = GMAX ? BM * 64 : 0;
     __shared__ __attribute__((aligned(1024))) float Bs0[TILE_F > GS_F ? TILE_F : GS_F];
     __shared__ __attribute__((aligned(1024))) float Bs1[TILE_F];
+    // NBUF = 3 (the 64-row tiles of the full pass: 3 x 16 KB per workgroup, three workgroups per CU = 144 KB of LDS): tile
+    // t + 2S is requested at the top of the step of tile t, so a tile has TWO steps to arrive.  With two buffers it had one:
+    // a step is ~700 cycles of a wave's own work and the L2 round trip under this load is longer, so every workgroup
+    // stood at its `vmcnt(0)` for the rest and only the other two workgroups of the CU covered it (round 6).
+    constexpr int NBUF = (DBR == 64 && !GMAX) ? 3 : 2;
+    __shared__ __attribute__((aligned(1024))) float Bs2[NBUF == 3 ? TILE_F : 1];
     __shared__ int s_cnt[BM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -376,11 +382,17 @@ __global__ __launch_bounds__(256, DBR == 64 ? 3 : 2) void scan_f16_qres_kernel(S
         }
     };
     if (t_lo < t_hi) load_tile(t_lo, Bs0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the barrier's fence does not wait for an LDS load)
+    if (NBUF == 3 && t_lo + S < t_hi) {
+        load_tile(t_lo + S, Bs1);
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLD) : "memory");      // tile t_lo has landed; t_lo + S may still travel
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the barrier's fence does not wait for an LDS load)
+    }
     __syncthreads();
-    // one db tile: MFMAs on the tile in Bc while the next one travels into Bn
+    // one db tile: MFMAs on the tile in Bc while the next one (NBUF = 3: the one after the next) travels into Bn
     auto tile_step = [&](int64_t t, const float *Bc, float *Bn) {
-        if (t + S < t_hi) load_tile(t + S, Bn);
+        const bool req = t + (NBUF - 1) * S < t_hi;
+        if (req) load_tile(t + (NBUF - 1) * S, Bn);
         __builtin_amdgcn_sched_barrier(0);
         f32x16 acc[TM][TN];
         // db fragments one K step ahead of the MFMAs that use them: with four 32-cycle MFMAs per step a wave that reads
@@ -406,6 +418,13 @@ __global__ __launch_bounds__(256, DBR == 64 ? 3 : 2) void scan_f16_qres_kernel(S
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b8[kk % (FA + 1)][j], afr[i][kk], kk == 0 ? zero16 : acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if (NBUF == 3) {
+            // tile t + S (requested one step ago) must have landed before the barrier below; vmcnt is ONE in-order counter
+            // of loads and stores, so the wait goes HERE, before this step's survivor stores: everything older than the
+            // request of this step -- tile t + S and the previous step's stores -- is then complete
+            if (req) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLD) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         const int nvalid = (int)(p.nrows - t * DBR < DBR ? p.nrows - t * DBR : DBR);
         if (nvalid < DBR) {              // last tile (uniform): db rows past the end never count
@@ -468,10 +487,25 @@ __global__ __launch_bounds__(256, DBR == 64 ? 3 : 2) void scan_f16_qres_kernel(S
                     }
                 }
             }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile has landed (and this tile's survivor stores are out)
+        if (NBUF == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile has landed (and this tile's survivor stores are out)
         __syncthreads();
     };
-    {
+    if constexpr (NBUF == 3) {
+        int64_t t = t_lo;
+#pragma unroll 1
+        while (t < t_hi) {
+            tile_step(t, Bs0, Bs2);
+            t += S;
+            if (t >= t_hi) break;
+            __builtin_amdgcn_sched_barrier(0);
+            tile_step(t, Bs1, Bs0);
+            t += S;
+            if (t >= t_hi) break;
+            __builtin_amdgcn_sched_barrier(0);
+            tile_step(t, Bs2, Bs1);
+            t += S;
+        }
+    } else {
         int64_t t = t_lo;
 #pragma unroll 1
         while (t < t_hi) {

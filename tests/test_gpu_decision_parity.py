@@ -18,10 +18,10 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_cfg2_query_population_vs_oracle():
     import gpu_workloads as gw          # the session's config-2 workload: database, queries, GPU decisions, oracle decisions
     out, _ = gw.cfg2_state()
-    os.makedirs(os.path.join(REPO, "gpurun_out", "r5"), exist_ok=True)
-    json.dump(out, open(os.path.join(REPO, "gpurun_out", "r5", "decision_parity_cfg2_snr0_test.json"), "w"), indent=1)
+    os.makedirs(os.path.join(REPO, "gpurun_out", "r6"), exist_ok=True)
+    json.dump(out, open(os.path.join(REPO, "gpurun_out", "r6", "decision_parity_cfg2_snr0_test.json"), "w"), indent=1)
     nq = gw.CFG2_QUERIES
-    assert out["queries"] == nq >= 1000 and out["db_rows"] == 590000
+    assert out["queries"] == nq == 2000 and out["db_rows"] == 590000
     assert out["max_embedding_abs_diff"] < 1e-4, out["max_embedding_abs_diff"]
     assert out["max_score_abs_diff_where_decisions_agree"] < 1e-5
     assert out["bugs"] == 0, [f for f in out["flips"] if f["class"] == "bug"]
