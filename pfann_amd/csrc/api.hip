@@ -423,16 +423,20 @@ static int encode_chunk_fused(pfann_ctx *c, const float *mel, int64_t B, float *
     // only when verification taps are requested.
     const bool fold_first = !c->keep && c->sub[1].axis == 1 && c->sub[0].co <= 256 &&
                             getenv("PFANN_NO_FOLD_FIRST") == nullptr;
-    if (B <= 64 && c->splitk == nullptr) {       // 64 segments x the largest split layer's [n_splits][rows][N] partials
+    const int64_t Bp = c->plan_batch > 0 ? c->plan_batch : B;
+    {   // split-K scratch: the largest [n_splits][B rows][N] partial tensor among the layers the plan splits at this batch
+        // (grow-only; one query: ~5 MB, 304 windows: ~30 MB; layers whose partials would pass 256 MB are not split)
         size_t need = 0;
         for (int i = 1; i < 16; ++i) {
-            const SubLayer &L = c->sub[i];
-            if (!L.depthwise && L.ci % 32 == 0)
-                need = std::max(need, (size_t)((3 * L.ci / 32 + 3) / 4) * 64 * L.Fo * L.To * L.co * sizeof(float));
+            const size_t n_i = splitk_scratch_need(c->sub[i], B, Bp);
+            if (n_i <= ((size_t)256 << 20)) need = std::max(need, n_i);
         }
-        need = std::min<size_t>(need, (size_t)64 << 20);
-        if (need && hipMalloc(&c->splitk, need) == hipSuccess) c->splitk_bytes = need;
-        else c->splitk = nullptr;
+        if (need > c->splitk_bytes) {
+            if (c->splitk) { PF_HIP(hipStreamSynchronize(s)); (void)hipFree(c->splitk); }
+            c->splitk = nullptr; c->splitk_bytes = 0;
+            if (hipMalloc(&c->splitk, need) == hipSuccess) c->splitk_bytes = need;
+            else { c->splitk = nullptr; (void)hipGetLastError(); }
+        }
     }
     if (fold_first && g.relu_after_bn && (int)c->w1_host.size() == 3 * c->sub[0].co && (int)c->b1_host.size() == c->sub[0].co) {
         if (!c->gram_ready) build_gram(c);
@@ -440,7 +444,6 @@ static int encode_chunk_fused(pfann_ctx *c, const float *mel, int64_t B, float *
     } else if (launch_conv_first_stats(c->sub[0], mel, fold_first ? nullptr : buf[0], part[0], B, g.activation, g.relu_after_bn, s)) {
         return -1;
     }
-    const int64_t Bp = c->plan_batch > 0 ? c->plan_batch : B;
     int P = fused_out_slots(c->sub[0], Bp);
     if (c->keep && keep_tap_fused(c, 0, buf[0], part[0], P, B, s)) return -1;
     int stats_final = 0;             // c->stats already holds (mean, rstd) of the next layer's input (split-K reduction)

@@ -29,6 +29,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// -DPFANN_TILE_TRACE (tuning builds only, tools/ubench/tile_trace.py; never the shipped library): every workgroup of
+// conv_gemm_ln_w22_kernel leaves four 100 MHz timestamps (start, first MFMA sub-step, end of the K loop, end) and its
+// HW_ID / XCC_ID registers in a caller-provided buffer, from which the tool rebuilds each CU's timeline.
+#ifdef PFANN_TILE_TRACE
+__device__ unsigned long long *g_tile_trace = nullptr;
+__device__ unsigned g_tile_trace_cap = 0;
+__device__ int g_tile_trace_rps = 0;          // only launches with this many rows per sample leave stamps (0: all)
+#define TILE_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memrealtime()
+#else
+#define TILE_STAMP(var)
+#endif
+
 struct FusedGemmParams {
     const float *x, *w, *bias;
     const void *w_hi, *w_lo;     // SPLIT kernels: fp16 halves of w * 2^e, [N][K]
@@ -630,6 +642,7 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParam
                  "s"(p.M), "s"(p.N), "s"(p.Ci), "s"(p.rows_per_sample), "s"(p.To), "s"(p.F), "s"(p.T));
     asm volatile("" :: "s"(p.rps_shift), "s"(p.To_shift), "s"(p.axis), "s"(p.in_len), "s"(p.n_tiles_n), "s"(p.n_samples),
                  "s"(p.dv_group.mul), "s"(p.dv_group.shift), "s"(p.dv_tile.mul), "s"(p.dv_tile.shift), "s"(p.dv_n.mul), "s"(p.dv_n.shift));
+    TILE_STAMP(ts_start);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int L = xcd_remap(blockIdx.x, gridDim.x);
@@ -810,6 +823,7 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParam
     stash(K0{}, As);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the weight tile has landed in LDS (the barrier's fence does not wait for it)
     __syncthreads();
+    TILE_STAMP(ts_loop);
     const int bfrag = (wn * 32 + l31) * BK + ((lhalf ^ ((l31 >> 1) & 7)) * 4);   // this lane's weight chunk of K step 0; step kk: ^ 8 kk
     // one sub-step: MFMAs on LDS buffer PB while the next sub-step goes global -> registers -> buffer PB ^ 1
     auto substep = [&](int ch, auto kindc, auto nextc) {
@@ -852,6 +866,7 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParam
         substep(ch, K3{}, K0{});
     }
 
+    TILE_STAMP(ts_loop_end);
     // ---- epilogue: y0 = A0 + A1 + bias, y1 = A1 + A2 + bias -> LDS -> whole rows; per-sample partial statistics
     // (same scheme as conv_gemm_ln_kernel: a lane holds ONE pair (lane & 31) and four consecutive channels per register quad)
     const __amdgpu_buffer_rsrc_t srd_y = make_srd(p.y + (int64_t)m0 * p.N, (unsigned long long)(p.M - m0) * p.N * 4ull);
@@ -936,7 +951,25 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParam
             o[1] = t2;
         }
     }
+#ifdef PFANN_TILE_TRACE
+    if (tid == 0 && g_tile_trace != nullptr && blockIdx.x < g_tile_trace_cap && (g_tile_trace_rps == 0 || g_tile_trace_rps == rps)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (this wave's output stores have been acknowledged)
+        unsigned long long *o = g_tile_trace + (size_t)blockIdx.x * 6;
+        o[0] = ts_start; o[1] = ts_loop; o[2] = ts_loop_end; o[3] = __builtin_amdgcn_s_memrealtime();
+        o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);          // HW_REG_HW_ID
+        o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);         // HW_REG_XCC_ID
+    }
+#endif
 }
+
+#ifdef PFANN_TILE_TRACE
+extern "C" int pfann_debug_set_tile_trace(void *buf, unsigned cap_blocks, int rows_per_sample) {
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_tile_trace), &buf, sizeof(buf)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_tile_trace_rps), &rows_per_sample, sizeof(rows_per_sample)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_tile_trace_cap), &cap_blocks, sizeof(cap_blocks)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 
 // (mean, rstd) of every sample from its P partial (sum, sum of squares) pairs: one wave per sample,
 // fp64, fixed order.  Done once here rather than by every GEMM block that touches the sample.
@@ -1037,6 +1070,37 @@ bool fused_supported(const SubLayer *sub, int n) {
     return true;
 }
 
+// Split-K plan of sub-layer L (64x64 tiles only): number of K chunks, 0 = not split.  The cut is chunks of 8 K-tiles whatever
+// the batch -- it depends on the layer only -- so a window's bits do not depend on how many windows share the launch;
+// WHETHER a layer is split depends on the batch the plan is made for:
+//   * plans of at most 64 windows (the one-query regime; pfann_set_plan_batch never pins one): launches of < 192 tiles;
+//   * larger plans (round 6: the middle of the batch curve, 65 .. ~1000 windows): the layers whose launch at the PLAN's
+//     batch is < 512 tiles of a chip that holds ~1000 -- the deep layers, M = B * (1 .. 8) rows with K loops of 48-96
+//     K-tiles: at 76 windows `rows=2 K=3072` was 48 workgroups x 96 K-tiles, 71 us on a sixth of the chip.
+// The same predicate sizes the scratch (splitk_scratch_need) and picks the kernel (launch_conv_gemm_ln).
+static int splitk_plan(const SubLayer &L, int64_t B, int64_t Bp, bool first, int k_live) {
+    static const int chunk_kt = getenv("PFANN_SPLITK_CHUNK") ? atoi(getenv("PFANN_SPLITK_CHUNK")) : 8;
+    static const bool no_splitk = getenv("PFANN_NO_SPLITK") != nullptr;
+    static const int64_t mid_max = getenv("PFANN_SPLITK_MID_BLOCKS") ? atoll(getenv("PFANN_SPLITK_MID_BLOCKS")) : 512;
+    if (no_splitk || first || chunk_kt <= 0 || L.ci % 32 != 0 || k_live % 32 != 0) return 0;
+    const int nk = k_live / 32;
+    const int n_splits = (nk + chunk_kt - 1) / chunk_kt;
+    if (nk < 16 || n_splits <= 1) return 0;
+    const int64_t rps = (int64_t)L.Fo * L.To, ntn = cdiv(L.co, 64);
+    const int64_t blocks = (int64_t)cdiv(B * rps, 64) * ntn, blocks_p = (int64_t)cdiv(Bp * rps, 64) * ntn;
+    const bool small = B <= 64 && Bp <= 64;
+    if (small ? blocks >= 192 : (B > Bp || blocks_p >= mid_max)) return 0;
+    return n_splits;
+}
+
+size_t splitk_scratch_need(const SubLayer &L, int64_t B, int64_t Bp) {
+    if (L.depthwise || L.ci == 1 || gemm_tile(L, Bp) != 64) return 0;
+    int kb, ke;
+    live_taps(L, L.axis == 0 ? L.T : L.F, kb, ke);
+    const int n_splits = splitk_plan(L, B, Bp, false, ke - kb);
+    return (size_t)n_splits * (size_t)B * L.Fo * L.To * L.co * sizeof(float);
+}
+
 // Lfirst != nullptr: x is the log-mel batch and Lfirst (= Lin, the C_in = 1 conv) is folded into the A-loader
 static int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
 
@@ -1135,15 +1199,11 @@ int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, 
         p.dv_n = make_fastdiv(p.n_tiles_n); p.dv_tile = make_fastdiv(64 * p.n_tiles_n);
         p.dv_group = make_fastdiv(64 * (p.rows_per_sample >= 64 ? p.rows_per_sample / 64 : 1) * p.n_tiles_n);
         const int64_t blocks = (int64_t)cdiv(p.M, 64) * p.n_tiles_n;
-        // split-K for launches that cannot fill the chip and have a long K loop (the one-query regime): chunks of 8
-        // K-tiles (measured on one 19-segment query: 12 -> 344 us, 8 -> 323, 6 -> 323, 4 -> 331 for the whole embed).  The cut depends on the layer only, never on B, so results do not depend on the batch size as long as
-        // the batch stays in this regime.
-        const int nk = (p.k_end - p.k_begin) / 32;
+        // split-K for launches that cannot fill the chip and have a long K loop (splitk_plan above): chunks of 8 K-tiles
+        // (measured on one 19-segment query: 12 -> 344 us, 8 -> 323, 6 -> 323, 4 -> 331 for the whole embed)
         static const int chunk_kt = getenv("PFANN_SPLITK_CHUNK") ? atoi(getenv("PFANN_SPLITK_CHUNK")) : 8;
-        const int n_splits = (nk + chunk_kt - 1) / chunk_kt;
-        static const bool no_splitk = getenv("PFANN_NO_SPLITK") != nullptr;
-        if (uni && !first && !no_splitk && B <= 64 && Bp <= 64 && blocks < 192 && nk >= 16 && chunk_kt > 0 && (p.k_end - p.k_begin) % 32 == 0 && n_splits > 1 &&
-            splitk_scratch != nullptr && (size_t)n_splits * p.M * p.N * sizeof(float) <= splitk_bytes) {
+        const int n_splits = uni ? splitk_plan(L, B, Bp, first, p.k_end - p.k_begin) : 0;
+        if (n_splits > 1 && splitk_scratch != nullptr && (size_t)n_splits * p.M * p.N * sizeof(float) <= splitk_bytes) {
             p.blocks_mn = (int)blocks;
             p.k_chunk = chunk_kt * 32;
             p.y = splitk_scratch;

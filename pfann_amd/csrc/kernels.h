@@ -36,6 +36,8 @@ int launch_cl_to_nchw(const float *x, float *y, int64_t B, int C, int HW, hipStr
 // ---- encoder_fused.hip (LayerNorm fused into the GEMM; "fuller" models) -------------------
 bool fused_supported(const SubLayer *sub, int n);
 int fused_out_slots(const SubLayer &L, int64_t B);
+// bytes of split-K scratch sub-layer L needs at batch B under the plan for batch Bp (0: the layer is not split)
+size_t splitk_scratch_need(const SubLayer &L, int64_t B, int64_t Bp);
 int launch_conv_first_stats(const SubLayer &L, const float *x, float *y, float *part, int64_t B, int act,
                             int after_bn, hipStream_t s);
 int launch_conv_first_gram_stats(const SubLayer &L, const float *x, float *part, int64_t B, const float *gram14,

@@ -903,7 +903,7 @@ int search_topk(const float *db, const void *dbh, float xnorm_max, int64_t n, in
     static const bool small_f32 = getenv("PFANN_SMALL_F32") != nullptr;
     const bool small = nq <= 32 && (d == 128 || d == 64);
     const bool small_pre = small && !half_only && dbh != nullptr && n > CAP && !small_f32;
-    const bool need_qh = half_only || (dbh != nullptr && nq > 64) || small_pre;
+    const bool need_qh = half_only || (dbh != nullptr && nq > 32) || small_pre;      // (33 .. 64 rows took the fp32 ladder up to round 5)
     if (need_qh) {
         if (ws.qh_elems < nq * d) {
             if (ws.qh) { PF_HIP(hipStreamSynchronize(s)); (void)hipFree(ws.qh); }

@@ -271,8 +271,13 @@ __global__ __launch_bounds__(256, 2) void scan_f16_kernel(ScanParams p) {
 // DBR = db rows per tile: 128 (two workgroups per CU), or 64 for the full pass: half the LDS and fewer accumulators per
 // workgroup, THREE workgroups (12 waves) per CU -- more independent barrier domains to cover a workgroup's epilogue and
 // barrier waits with the others' MFMAs, at twice the barriers per MFMA.
-template <int KS, bool GMAX = false, int DBR = 128>
-__global__ __launch_bounds__(256, DBR == 64 ? 3 : 2) void scan_f16_qres_kernel(ScanParams p) {
+// NBUF = db-tile buffers in LDS: 2 (tile t + S travels during the step of tile t), or 3 for launches that leave most of
+// the chip's workgroup slots empty (the middle of the batch curve: 33 .. ~1000 query rows = 1 .. 8 query tiles): with
+// nobody else on the CU to cover it, a step was one full L2 / HBM round trip long (2400 cycles for 512 cycles of MFMA).
+// With every slot taken (the 9728-row launch groups) the third buffer measured +1.6 % (profiles/r6/scan_v3_abc.txt): there
+// the other two workgroups of the CU already cover the wait, and the pass is bound by its survivor epilogue.
+template <int KS, bool GMAX = false, int DBR = 128, int NBUF = 2>
+__global__ __launch_bounds__(256, (DBR == 64 && NBUF == 2) ? 3 : (NBUF == 3 && DBR == 128 ? 1 : 2)) void scan_f16_qres_kernel(ScanParams p) {
     constexpr int BM = 128, WM = 64, WN = DBR / 2, TM = 2, TN = WN / 32;
     constexpr int ROWB = KS * 32;                 // bytes of one fp16 row
     constexpr int CPR = ROWB / 16;                // 16-byte chunks per row
@@ -285,11 +290,8 @@ __global__ __launch_bounds__(256, DBR == 64 ? 3 : 2) void scan_f16_qres_kernel(S
     constexpr int TILE_F = DBR * ROWB / 4, GS_F = GMAX ? BM * 64 : 0;
     __shared__ __attribute__((aligned(1024))) float Bs0[TILE_F > GS_F ? TILE_F : GS_F];
     __shared__ __attribute__((aligned(1024))) float Bs1[TILE_F];
-    // NBUF = 3 (the 64-row tiles of the full pass: 3 x 16 KB per workgroup, three workgroups per CU = 144 KB of LDS): tile
-    // t + 2S is requested at the top of the step of tile t, so a tile has TWO steps to arrive.  With two buffers it had one:
-    // a step is ~700 cycles of a wave's own work and the L2 round trip under this load is longer, so every workgroup
-    // stood at its `vmcnt(0)` for the rest and only the other two workgroups of the CU covered it (round 6).
-    constexpr int NBUF = (DBR == 64 && !GMAX) ? 3 : 2;
+    // NBUF = 3: tile t + 2S is requested at the top of the step of tile t, so a tile has TWO steps to arrive
+    static_assert(NBUF == 2 || NBUF == 3, "two or three db-tile buffers");
     __shared__ __attribute__((aligned(1024))) float Bs2[NBUF == 3 ? TILE_F : 1];
     __shared__ int s_cnt[BM];
 
@@ -349,7 +351,10 @@ __global__ __launch_bounds__(256, DBR == 64 ? 3 : 2) void scan_f16_qres_kernel(S
     //   instruction (wave, u) covers LDS chunks [(wave*NLD + u)*64, +64)
     constexpr int RP = 256 / ROWB;                 // rows per 256 bytes of LDS (1 at d = 128, 2 at d = 64)
     auto key = [](int r) { return (r / RP) & (CPR - 1); };
-    const int64_t last_row = (p.nrows - 1) * p.row_stride;
+    // the 64-row-tile instantiation is the full pass: launched with stride 1 only (launch_scan_f16), so the row step is a
+    // compile-time 1 there and the sixteen (8 g + e) * stride products of the survivor path are immediates, not registers
+    const int64_t rstride = DBR == 64 ? 1 : p.row_stride;
+    const int64_t last_row = (p.nrows - 1) * rstride;
     // (the BUFFER form of the LDS load: one 32-bit offset per chunk against a per-tile descriptor, and -- unlike
     // global_load_lds, a FLAT instruction after which every wait becomes vmcnt(0) / lgkmcnt(0) -- it counts in order)
     unsigned goff[NLD];                            // byte offset of this lane's chunk inside a tile (stride folded in)
@@ -360,10 +365,10 @@ __global__ __launch_bounds__(256, DBR == 64 ? 3 : 2) void scan_f16_qres_kernel(S
         const int ci = (wave * NLD + u) * 64 + lane;
         const int r = ci / CPR, cs = ci % CPR;
         lrow[u] = r;
-        goff[u] = (unsigned)((unsigned long long)r * (unsigned long long)p.row_stride * ROWB) + (unsigned)((cs ^ key(r)) * 16);   // (launchers: qres_stride_ok)
+        goff[u] = (unsigned)((unsigned long long)r * (unsigned long long)rstride * ROWB) + (unsigned)((cs ^ key(r)) * 16);   // (launchers: qres_stride_ok)
     }
     auto load_tile = [&](int64_t t, float *Bd) {
-        const int64_t r0 = t * DBR * p.row_stride;
+        const int64_t r0 = t * DBR * rstride;
         const __amdgpu_buffer_rsrc_t srd_t = make_srd(dbb + r0 * ROWB, 0x7FFFFFF0ull);
         if ((t + 1) * DBR <= p.nrows) {      // whole tile in range (uniform)
 #pragma unroll
@@ -469,7 +474,7 @@ __global__ __launch_bounds__(256, DBR == 64 ? 3 : 2) void scan_f16_qres_kernel(S
                     }
                     int pos = 0;
                     if (c > 0) pos = atomicAdd(&s_cnt[ml], c);       // one reservation for all of the lane's survivors
-                    const unsigned row0 = (unsigned)((t * DBR + wn * WN + j * 32 + 4 * lhalf) * p.row_stride);
+                    const unsigned row0 = (unsigned)((t * DBR + wn * WN + j * 32 + 4 * lhalf) * rstride);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         if (anyg[g]) {
@@ -477,7 +482,7 @@ __global__ __launch_bounds__(256, DBR == 64 ? 3 : 2) void scan_f16_qres_kernel(S
                             for (int e = 0; e < 4; ++e) {
                                 const float v = acc[i][j][4 * g + e];
                                 const bool sv = v >= th[i];
-                                const unsigned long long key = pack_key(v, row0 + (unsigned)((8 * g + e) * p.row_stride));
+                                const unsigned long long key = pack_key(v, row0 + (unsigned)((8 * g + e) * rstride));
                                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, key), srd_k,
                                                                       (sv && pos < subcap) ? (unsigned)(ml * CAP + pos) * 8u : BUF_OOB, 0, 0);
@@ -556,6 +561,15 @@ static inline bool qres_stride_ok(int64_t stride, int d) {
     return 127ll * stride * (2ll * d) + 2ll * d <= 0x7FFFFFF0ll;
 }
 
+// Fewest query rows that take the query-stationary kernels (sampled group-maximum pass + full pass with sub-lists).  Up to
+// round 5 this was 1024: between the streaming small-batch kernel (<= 32 rows) and 1024 rows the survivor ladder ran on the
+// generic kernel with one to eight query tiles -- two sampled levels + full pass = 1.1-1.4 ms whatever the row count
+// (profiles/r6/scan_mid_before.txt), the hole in the middle of the batch curve.  PFANN_QRES_MIN_NQ=1024 restores it (A/B).
+static inline int64_t qres_min_nq() {
+    static const int64_t v = getenv("PFANN_QRES_MIN_NQ") ? atoll(getenv("PFANN_QRES_MIN_NQ")) : 33;
+    return v;
+}
+
 // Sampled group-maximum pass (every `stride`-th row): fills gmax[nq][*n_groups_out] for group_max_select.
 // Returns 1 (not applicable: use the survivor ladder) when the shapes do not give >= 4 k groups per row.
 int launch_scan_f16_gmax(const void *dbh, int64_t n, int d, int64_t stride, const void *qh, int64_t nq, int k,
@@ -568,9 +582,11 @@ int launch_scan_f16_gmax(const void *dbh, int64_t n, int d, int64_t stride, cons
     p.thr = nullptr; p.cnt = ws.cnt; p.keys = nullptr;
     p.n_tiles_m = cdiv(nq, 128);
     const int64_t db_tiles = cdiv(p.nrows, 128);
-    if (!(d == 128 || d == 64) || nq < 1024 || db_tiles < 16 || !qres_stride_ok(stride, d)) return 1;
+    if (!(d == 128 || d == 64) || nq < qres_min_nq() || db_tiles < 16 || !qres_stride_ok(stride, d)) return 1;
+    // few query tiles (the middle of the batch curve): up to 64 slices, so that one tile still becomes 64 workgroups
+    const int s_max = p.n_tiles_m * 32 < 512 ? 64 : 32;
     int S = (int)(2048 / p.n_tiles_m);
-    S = S < 1 ? 1 : (S > 32 ? 32 : S);
+    S = S < 1 ? 1 : (S > s_max ? s_max : S);
     // no more groups than the threshold needs: 5 k of them (64 per slice) give the k-th best group maximum the same quality
     // as 1000-1600 did -- the full pass that follows is not a microsecond slower -- while the group select, whose cost is
     // the number of groups, halves: 0.77 -> 0.45 ms per 77,824 rows at 8 shards, 0.48 -> 0.29 on one GPU
@@ -589,7 +605,9 @@ int launch_scan_f16_gmax(const void *dbh, int64_t n, int d, int64_t stride, cons
     p.gmax = reinterpret_cast<float *>(ws.cl);
     ProfScope ps("scan_topk_f16_sample", s, 2.0 * (double)nq * p.nrows * d);
     const dim3 grid((unsigned)(p.n_tiles_m * S));
-    if (d == 128) PF_LAUNCH((scan_f16_qres_kernel<8, true>), grid, dim3(256), 0, s, p);
+    // at most one workgroup per CU: nobody covers a tile's round trip -> three tile buffers (96 KB, one workgroup per CU)
+    if (d == 128 && p.n_tiles_m * S <= 256) PF_LAUNCH((scan_f16_qres_kernel<8, true, 128, 3>), grid, dim3(256), 0, s, p);
+    else if (d == 128) PF_LAUNCH((scan_f16_qres_kernel<8, true>), grid, dim3(256), 0, s, p);
     else PF_LAUNCH((scan_f16_qres_kernel<4, true>), grid, dim3(256), 0, s, p);
     PF_HIP(hipGetLastError());
     *n_groups_out = G;
@@ -621,17 +639,20 @@ int launch_scan_f16(const void *dbh, int64_t n, int d, int64_t stride, const voi
     p.n_tiles_m = cdiv(nq, 128);
     const int64_t db_tiles = cdiv(p.nrows, 128);
     static const bool no_qres = getenv("PFANN_NO_QRES") != nullptr;
-    if (thr_adj != nullptr && allow_sublists && !no_qres && (d == 128 || d == 64) && nq >= 1024 && db_tiles >= 16 && qres_stride_ok(stride, d)) {
-        // S interleaved db slices: about four rounds of the 512 resident workgroups, sub-lists of >= 256
+    if (thr_adj != nullptr && allow_sublists && !no_qres && (d == 128 || d == 64) && nq >= qres_min_nq() && db_tiles >= 16 && qres_stride_ok(stride, d)) {
+        // S interleaved db slices: about four rounds of the 512 resident workgroups, sub-lists of >= 256; with few query
+        // tiles up to 64 slices (sub-lists of 128: a row's ~330 survivors spread over them), so that one query tile still
+        // becomes 64 workgroups
+        const int s_max = p.n_tiles_m * 32 < 768 ? 64 : 32;
         int S = (int)(2048 / p.n_tiles_m);
-        S = S < 1 ? 1 : (S > 32 ? 32 : S);
+        S = S < 1 ? 1 : (S > s_max ? s_max : S);
         // whole rounds of the resident workgroups: with three per CU (64-row tiles) 76 query tiles x 26 slices are 2.57
         // rounds of 768; 30 slices (2.97 rounds) run the pass in 2.77 instead of 2.91 ms (20: 2.82, 32: 2.97)
         static const bool dbr64_s = getenv("PFANN_SCAN_DBR128") == nullptr;
         if (dbr64_s && d == 128 && stride == 1) {
             const int64_t slots = 768, rounds = (p.n_tiles_m * (int64_t)S + slots - 1) / slots;
             const int64_t s2 = rounds * slots / p.n_tiles_m;
-            if (s2 >= S && s2 <= 32) S = (int)s2;
+            if (s2 >= S && s2 <= s_max) S = (int)s2;
         }
         static const int s_env = getenv("PFANN_SCAN_S") ? atoi(getenv("PFANN_SCAN_S")) : 0;
         if (s_env > 0) S = s_env;
@@ -642,7 +663,9 @@ int launch_scan_f16(const void *dbh, int64_t n, int d, int64_t stride, const voi
         // 64-row db tiles, three workgroups per CU (168 VGPRs) for the full pass: 2.97 -> 2.86 ms on the bench's 9728 x 1 M
         // pass, back to back on one box (four per CU would need <= 128 VGPRs: 35 spilled); PFANN_SCAN_DBR128=1: the old tiles
         static const bool dbr64 = getenv("PFANN_SCAN_DBR128") == nullptr;
-        if (d == 128 && dbr64 && stride == 1) PF_LAUNCH((scan_f16_qres_kernel<8, false, 64>), grid, dim3(256), 0, s, p);
+        if (d == 128 && dbr64 && stride == 1 && p.n_tiles_m * S < 768)      // less than one round of the resident slots
+            PF_LAUNCH((scan_f16_qres_kernel<8, false, 64, 3>), grid, dim3(256), 0, s, p);
+        else if (d == 128 && dbr64 && stride == 1) PF_LAUNCH((scan_f16_qres_kernel<8, false, 64>), grid, dim3(256), 0, s, p);
         else
         if (d == 128) PF_LAUNCH((scan_f16_qres_kernel<8>), grid, dim3(256), 0, s, p);
         else PF_LAUNCH((scan_f16_qres_kernel<4>), grid, dim3(256), 0, s, p);

@@ -282,6 +282,38 @@ def test_encoder_five_block_kernel_vs_oracle(torch_cuda, variant):
     assert np.array_equal(e2, eng.encode(torch_cuda.as_tensor(x).cuda(), norm=True).cpu().numpy())
 
 
+def test_encoder_mid_batch_plan_vs_oracle(torch_cuda):
+    """Round 6: the middle of the batch curve.  At 304 windows the plan puts the five big stride-2
+    layers on the 128-tile five-block kernel, the layers with 16 .. 128 rows per window on 64x64 tiles, and SPLITS K on the
+    deep layers (1 .. 8 rows per window, K loops of 48-96 K-tiles: encoder_fused.hip splitk_plan) with the LayerNorm
+    statistics taken by the split-K reduction.  Embeddings against the CPU oracle (1e-4), run-to-run bit-reproducible, and
+    under pfann_set_plan_batch(304) the first 76 windows alone embed to the same bits as inside the 304-window launch
+    (the K cut depends on the layer only; the reduction order is fixed)."""
+    from oracle import encoder as oe
+    from pfann_amd.engine import Engine
+    params = cfg("default")
+    _, _, _, F, T = synth.model_dims(params)
+    sd = synth.make_state_dict(params, seed=123)
+    B = 304
+    x = (synth.normal(83, "t/mid", B * F * T).reshape(B, F, T) * 3.0 - 6.0).astype(np.float32)
+    ref = np.concatenate([oe.encode(x[i:i + 76], sd, params, norm=True) for i in range(0, B, 76)])
+    eng = Engine(params, 0, max_batch=B)
+    eng.load_state_dict(sd)
+    xt = torch_cuda.as_tensor(x).cuda()
+    e1 = eng.encode(xt, norm=True).cpu().numpy()
+    print("mid-batch plan (304 windows) vs oracle %.3e" % np.abs(e1 - ref).max())
+    assert np.abs(e1 - ref).max() < 1e-4
+    assert np.array_equal(e1, eng.encode(xt, norm=True).cpu().numpy())
+    assert eng.set_plan_batch(B) == B
+    e_all = eng.encode(xt, norm=True).cpu().numpy()
+    e_head = eng.encode(xt[:76].contiguous(), norm=True).cpu().numpy()
+    assert np.array_equal(e_all, e1)
+    assert np.array_equal(e_head, e_all[:76]), "a window's bits depend on the batch under a pinned plan"
+    eng.set_plan_batch(0)
+    e76 = eng.encode(xt[:76].contiguous(), norm=True).cpu().numpy()          # its own plan (64x64 tiles everywhere)
+    assert np.abs(e76 - ref[:76]).max() < 1e-4
+
+
 def test_encoder_split_precision_matches_fp32(torch_cuda):
     """Opt-in encoder arithmetic (pfann_set_encoder_precision = 1): conv products as three fp16 MFMA
     terms of two-term operand splits, fp32 accumulation.  Must stay fp32-grade: embeddings within 2e-5
@@ -415,6 +447,22 @@ def test_search_topk_large_batch_sublists(torch_cuda, n, d, nq, k):
     q[::7] = db[(np.arange(len(q[::7])) * 911) % n] + 0.2 * q[::7]
     q /= np.linalg.norm(q, axis=1, keepdims=True)
     _check_topk(torch_cuda, db.astype(np.float32), q.astype(np.float32), k, True)
+
+
+@pytest.mark.parametrize("n,d,nq", [(250007, 128, 33), (250007, 128, 76), (250007, 128, 304), (250007, 128, 1000), (130001, 64, 200)])
+def test_search_topk_mid_batch_takes_the_query_stationary_kernels(torch_cuda, n, d, nq):
+    """Round 6: 33 .. 1023 query rows (one to eight query tiles) run the sampled group-maximum pass + the full pass with
+    sub-lists too -- up to 64 db slices per query tile, three tile buffers where the launch leaves most of the chip empty
+    (csrc/search_f16.hip: qres_min_nq, NBUF) -- instead of the survivor ladder on the generic kernel.  Same exact answer on
+    a db of 'songs' (runs of 40 similar rows), ragged last db tile and query tile."""
+    db = synth.unit_rows(51, "t/mb%d" % n, n, d)
+    heads = np.repeat(db[::40], 40, axis=0)[:n]
+    db = heads + 0.6 * db
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    q = synth.unit_rows(52, "t/mbq%d" % n, nq, d)
+    q[::2] = db[(np.arange(len(q[::2])) * 7919) % n] + 0.5 * q[::2]
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    _check_topk(torch_cuda, db.astype(np.float32), q.astype(np.float32), 100, True)
 
 
 def test_search_topk_sublist_overflow_falls_back(torch_cuda):
