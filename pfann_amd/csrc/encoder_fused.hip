@@ -734,6 +734,18 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParam
     // v = POST((z - mean) * rstd * W + B); out-of-range positions: W = B = 0 -> +-0 -> 0 (as in conv_gemm_ln_kernel)
     auto fx = [&](const f32x4 &z4, const f32x4 &w4, const f32x4 &b4) {
         f32x4 v;
+#ifdef PFANN_FX_SCALAR
+        // (experiment) plain fp32 VALU instead of packed pairs: same operations, same rounding
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = __builtin_fmaf((z4[e] - amu) * ars, w4[e], b4[e]);
+            asm volatile("" : "+v"(t));                    // keep the SLP vectoriser from re-packing the four lanes
+            if (RELU_BN) t = fmaxf(t, 0.f);
+            else t = p.after_bn ? act_fn(t, p.act) : t;
+            v[e] = t;
+        }
+        return v;
+#endif
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const f32x2 z = {z4[2 * h], z4[2 * h + 1]}, w2 = {w4[2 * h], w4[2 * h + 1]}, b2 = {b4[2 * h], b4[2 * h + 1]};
@@ -838,10 +850,12 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParam
             f32x4 a1 = a0;
             if (KIND == 0) a1 = *reinterpret_cast<const f32x4 *>(&Ac[(NP + wm * 32 + l31) * LDK + kk * 8 + lhalf * 4]);
             const f32x4 b4 = *reinterpret_cast<const f32x4 *>(&Bc[bfrag ^ (kk * 8)]);
+#ifdef PFANN_W22_ISSUE_FIRST                    // (rounds 2-5, kept for A/B: the requests in FRONT of the first MFMA group)
             if (kk == 0) {
                 if (more) issue(nextc, cc_next, Bn);
                 __builtin_amdgcn_sched_barrier(0);
             }
+#endif
             if (kk == BK / 8 - 1) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (more) stash(nextc, An);
@@ -855,6 +869,17 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParam
                 else if (KIND == 2) acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[s], a0[s], acc[2], 0, 0, 0);
                 else acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[s], a0[s], acc[1], 0, 0, 0);
             }
+#ifndef PFANN_W22_ISSUE_FIRST
+            // The next sub-step's requests BEHIND the first MFMA group (round 6): issued in front of it, all eight waves spent
+            // their first 200-400 cycles after every barrier on 4-8 memory instructions each while the MFMA pipe waited.
+            // A/B/A/B on one box: all conv GEMMs -0.5 .. -0.9 % (profiles/r6/w22_issue_late_abc.txt); interleaving them
+            // one by one between the MFMAs (sched_group_barrier) measured +0.7 %.  Same MFMA order: bit-identical results.
+            if (kk == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) issue(nextc, cc_next, Bn);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
         }
         if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next weight tile has landed in LDS before anyone reads it
         __syncthreads();

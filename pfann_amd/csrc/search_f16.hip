@@ -271,13 +271,27 @@ __global__ __launch_bounds__(256, 2) void scan_f16_kernel(ScanParams p) {
 // DBR = db rows per tile: 128 (two workgroups per CU), or 64 for the full pass: half the LDS and fewer accumulators per
 // workgroup, THREE workgroups (12 waves) per CU -- more independent barrier domains to cover a workgroup's epilogue and
 // barrier waits with the others' MFMAs, at twice the barriers per MFMA.
+// -DPFANN_SCAN_TRACE (tuning builds only, tools/ubench/scan_trace.py): every wave of the full pass sums the shader cycles of
+// its step phases (tile request | fragment reads + MFMAs | survivor epilogue | wait for the next tile | barrier) and
+// wave 0 / lane 0 of each workgroup leaves the five sums + its step count in a caller-provided buffer.
+#ifdef PFANN_SCAN_TRACE
+__device__ unsigned long long *g_scan_trace = nullptr;
+__device__ unsigned g_scan_trace_cap = 0;
+#define SCAN_STAMP(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); tr_sum[i] += now_ - tr_last; tr_last = now_; } while (0)
+#else
+#define SCAN_STAMP(i)
+#endif
+
 // NBUF = db-tile buffers in LDS: 2 (tile t + S travels during the step of tile t), or 3 for launches that leave most of
 // the chip's workgroup slots empty (the middle of the batch curve: 33 .. ~1000 query rows = 1 .. 8 query tiles): with
 // nobody else on the CU to cover it, a step was one full L2 / HBM round trip long (2400 cycles for 512 cycles of MFMA).
 // With every slot taken (the 9728-row launch groups) the third buffer measured +1.6 % (profiles/r6/scan_v3_abc.txt): there
 // the other two workgroups of the CU already cover the wait, and the pass is bound by its survivor epilogue.
+// (256 query rows per workgroup -- 128 per wave, two waves per SIMD, every 16 KB db tile feeding twice the MFMAs -- measured
+// the same 2.56 ms as this 128-row form in round 6, profiles/r6/scan_bm256_ab.txt: the step is not bound by its per-tile
+// costs but by what it pays per MFMA: the LDS-latency-bound fragment loop and the survivor epilogue.)
 template <int KS, bool GMAX = false, int DBR = 128, int NBUF = 2>
-__global__ __launch_bounds__(256, (DBR == 64 && NBUF == 2) ? 3 : (NBUF == 3 && DBR == 128 ? 1 : 2)) void scan_f16_qres_kernel(ScanParams p) {
+__global__ __launch_bounds__(256, DBR == 64 ? 3 : (NBUF == 3 ? 1 : 2)) void scan_f16_qres_kernel(ScanParams p) {
     constexpr int BM = 128, WM = 64, WN = DBR / 2, TM = 2, TN = WN / 32;
     constexpr int ROWB = KS * 32;                 // bytes of one fp16 row
     constexpr int CPR = ROWB / 16;                // 16-byte chunks per row
@@ -389,16 +403,22 @@ __global__ __launch_bounds__(256, (DBR == 64 && NBUF == 2) ? 3 : (NBUF == 3 && D
     if (t_lo < t_hi) load_tile(t_lo, Bs0);
     if (NBUF == 3 && t_lo + S < t_hi) {
         load_tile(t_lo + S, Bs1);
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLD) : "memory");      // tile t_lo has landed; t_lo + S may still travel
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" :: "n"(NLD) : "memory");      // tile t_lo has landed; t_lo + S may still travel
+        __builtin_amdgcn_s_barrier();                           // (raw: see the end of tile_step)
+        asm volatile("" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the barrier's fence does not wait for an LDS load)
+        __syncthreads();
     }
-    __syncthreads();
     // one db tile: MFMAs on the tile in Bc while the next one (NBUF = 3: the one after the next) travels into Bn
+#ifdef PFANN_SCAN_TRACE
+    unsigned long long tr_sum[5] = {0, 0, 0, 0, 0}, tr_last = __builtin_readcyclecounter(), tr_steps = 0;
+#endif
     auto tile_step = [&](int64_t t, const float *Bc, float *Bn) {
         const bool req = t + (NBUF - 1) * S < t_hi;
         if (req) load_tile(t + (NBUF - 1) * S, Bn);
         __builtin_amdgcn_sched_barrier(0);
+        SCAN_STAMP(0);
         f32x16 acc[TM][TN];
         // db fragments one K step ahead of the MFMAs that use them: with four 32-cycle MFMAs per step a wave that reads
         // its fragments only after issuing the previous step's MFMAs waits out the whole LDS latency every step
@@ -424,6 +444,7 @@ __global__ __launch_bounds__(256, (DBR == 64 && NBUF == 2) ? 3 : (NBUF == 3 && D
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b8[kk % (FA + 1)][j], afr[i][kk], kk == 0 ? zero16 : acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        SCAN_STAMP(1);
         if (NBUF == 3) {
             // tile t + S (requested one step ago) must have landed before the barrier below; vmcnt is ONE in-order counter
             // of loads and stores, so the wait goes HERE, before this step's survivor stores: everything older than the
@@ -473,7 +494,16 @@ __global__ __launch_bounds__(256, (DBR == 64 && NBUF == 2) ? 3 : (NBUF == 3 && D
                         }
                     }
                     int pos = 0;
-                    if (c > 0) pos = atomicAdd(&s_cnt[ml], c);       // one reservation for all of the lane's survivors
+                    if (NBUF == 3) {
+                        // the reservation as a bare ds_add_rtn: in front of an LDS atomic the compiler's wait insertion puts
+                        // `s_waitcnt vmcnt(0)` while an LDS load is outstanding (it cannot tell s_cnt from the tile buffers),
+                        // which would drain the request of tile t + 2S in every step that holds a survivor -- most of them.
+                        // (With two buffers the builtin is kept: the same wait costs nothing there, 2.60 vs 2.62 ms.)
+                        if (c > 0) {
+                            const unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) int *)&s_cnt[ml];
+                            asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(pos) : "v"(a), "v"(c) : "memory");
+                        }
+                    } else if (c > 0) pos = atomicAdd(&s_cnt[ml], c);       // one reservation for all of the lane's survivors
                     const unsigned row0 = (unsigned)((t * DBR + wn * WN + j * 32 + 4 * lhalf) * rstride);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -492,8 +522,28 @@ __global__ __launch_bounds__(256, (DBR == 64 && NBUF == 2) ? 3 : (NBUF == 3 && D
                     }
                 }
             }
-        if (NBUF == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile has landed (and this tile's survivor stores are out)
-        __syncthreads();
+        SCAN_STAMP(2);
+#ifdef PFANN_SCAN_TRACE
+        ++tr_steps;
+        if (NBUF == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            SCAN_STAMP(3);
+            __syncthreads();
+            SCAN_STAMP(4);
+        } else
+#endif
+        if (NBUF == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile has landed (and this tile's survivor stores are out)
+            __syncthreads();
+        } else {
+            // a RAW barrier: __syncthreads() carries a fence, and with an LDS load outstanding the fence is lowered to
+            // `s_waitcnt vmcnt(0)` -- it would drain the request of tile t + 2S issued at the top of this step, i.e. undo the
+            // third buffer.  What the hand-over needs is above (this wave's share of tile t + S has landed: vmcnt(NLD)) and
+            // here (its LDS counter updates and fragment reads are complete: lgkmcnt(0)).
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
     };
     if constexpr (NBUF == 3) {
         int64_t t = t_lo;
@@ -552,7 +602,22 @@ __global__ __launch_bounds__(256, (DBR == 64 && NBUF == 2) ? 3 : (NBUF == 3 && D
         return;
     }
     if (tid < BM && m0 + tid < p.nq) p.cnt[(m0 + tid) * S + seg] = s_cnt[tid];
+#ifdef PFANN_SCAN_TRACE
+    if (!GMAX && lane == 0 && g_scan_trace != nullptr && blockIdx.x < g_scan_trace_cap) {
+        unsigned long long *o = g_scan_trace + ((size_t)blockIdx.x * 4 + wave) * 8;
+        for (int i = 0; i < 5; ++i) o[i] = tr_sum[i];
+        o[5] = tr_steps; o[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4); o[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
 }
+
+#ifdef PFANN_SCAN_TRACE
+extern "C" int pfann_debug_set_scan_trace(void *buf, unsigned cap_blocks) {
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_scan_trace), &buf, sizeof(buf)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_scan_trace_cap), &cap_blocks, sizeof(cap_blocks)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 
 // The query-stationary kernel addresses a db tile with 32-bit chunk offsets against a per-tile descriptor of 0x7FFFFFF0 bytes:
 // the last row of a strided 128-row tile must lie inside it (stride <= ~66 k, i.e. shards below ~268 M rows for the ladder's
@@ -663,7 +728,8 @@ int launch_scan_f16(const void *dbh, int64_t n, int d, int64_t stride, const voi
         // 64-row db tiles, three workgroups per CU (168 VGPRs) for the full pass: 2.97 -> 2.86 ms on the bench's 9728 x 1 M
         // pass, back to back on one box (four per CU would need <= 128 VGPRs: 35 spilled); PFANN_SCAN_DBR128=1: the old tiles
         static const bool dbr64 = getenv("PFANN_SCAN_DBR128") == nullptr;
-        if (d == 128 && dbr64 && stride == 1 && p.n_tiles_m * S < 768)      // less than one round of the resident slots
+        static const bool nbuf3_always = getenv("PFANN_SCAN_NBUF3") != nullptr;       // (A/B aid)
+        if (d == 128 && dbr64 && stride == 1 && (p.n_tiles_m * S < 768 || nbuf3_always))      // less than one round of the resident slots
             PF_LAUNCH((scan_f16_qres_kernel<8, false, 64, 3>), grid, dim3(256), 0, s, p);
         else if (d == 128 && dbr64 && stride == 1) PF_LAUNCH((scan_f16_qres_kernel<8, false, 64>), grid, dim3(256), 0, s, p);
         else
