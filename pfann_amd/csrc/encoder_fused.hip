@@ -690,6 +690,7 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParam
     unsigned va[FIRST ? 1 : 2], vr[2];
     const int ts4 = (int)p.tap_stride * 4;
     float amu, ars;
+    float mlv[2] = {0.f, 0.f};       // FIRST: this thread's two of the pair's 5 x 3 log-mel values, on their way to s_ml
     {
         const int m = m0 + pair_row0(rowq);
         const bool mok = m < p.M;
@@ -716,11 +717,10 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParam
                 const int e = col4 * 2 + h;              // 0 .. 15; 15 is padding
                 const int j = e / 3, t1 = e - j * 3;
                 const bool ok = e < 15 && mok && (a0 + j) < p.in_len && (unsigned)(tq + t1) < (unsigned)p.T0;
-                s_ml[rowq * 16 + e] = buf_load1(srd_a, ok ? (unsigned)(((b - b_first) * p.F + a0 + j) * p.T0 + tq + t1) * 4u : BUF_OOB);
+                mlv[h] = buf_load1(srd_a, ok ? (unsigned)(((b - b_first) * p.F + a0 + j) * p.T0 + tq + t1) * 4u : BUF_OOB);
             }
         }
     }
-    if (FIRST) __syncthreads();
     unsigned vb[2];
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
@@ -734,18 +734,6 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParam
     // v = POST((z - mean) * rstd * W + B); out-of-range positions: W = B = 0 -> +-0 -> 0 (as in conv_gemm_ln_kernel)
     auto fx = [&](const f32x4 &z4, const f32x4 &w4, const f32x4 &b4) {
         f32x4 v;
-#ifdef PFANN_FX_SCALAR
-        // (experiment) plain fp32 VALU instead of packed pairs: same operations, same rounding
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float t = __builtin_fmaf((z4[e] - amu) * ars, w4[e], b4[e]);
-            asm volatile("" : "+v"(t));                    // keep the SLP vectoriser from re-packing the four lanes
-            if (RELU_BN) t = fmaxf(t, 0.f);
-            else t = p.after_bn ? act_fn(t, p.act) : t;
-            v[e] = t;
-        }
-        return v;
-#endif
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const f32x2 z = {z4[2 * h], z4[2 * h + 1]}, w2 = {w4[2 * h], w4[2 * h + 1]}, b2 = {b4[2 * h], b4[2 * h + 1]};
@@ -761,6 +749,7 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParam
     };
     int cc_st = 0;                                       // channel chunk of the sub-step whose operands sit in the registers
     // positions of sub-step KIND's operands: {o0, o1}, {e0, e1}, {e2}
+    bool in_loop = false;
     auto issue = [&](auto kindc, int cc, float *Bd) {    // global loads of sub-step (kind, channel chunk cc)
         constexpr int KIND = decltype(kindc)::value;
         constexpr int J0 = KIND == 0 ? 1 : (KIND == 1 ? 0 : 4), J1 = KIND == 0 ? 3 : 2;
@@ -769,10 +758,17 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParam
         // the weight tile first (the buffer form of the LDS load: one offset register per chunk, and vmcnt stays in order
         // beside the other buffer loads -- the global_load_lds form is a FLAT instruction, after which the compiler waits
         // for vmcnt(0) at every use of a loaded register)
+#ifndef PFANN_ABL
+#define PFANN_ABL 0
+#endif
+        // (PFANN_ABL: timing-only ablation builds, results garbage -- 1: no row requests in the K loop, 2: no weight-tile requests,
+        // 4: no LDS refill; tools/ubench only)
+        if (!((PFANN_ABL & 2) && in_loop))
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_b, (__attribute__((address_space(3))) void *)&Bd[(wave_u * 2 + j) * 256], 16,
                                                      (int)vb[j], (KIND * p.Ci + cc) * 4, 0, 0);
+        if ((PFANN_ABL & 1) && in_loop) return;
         if (KIND <= 2) {
             const int s0 = so + J0 * ts4;
             if (!FIRST) px[0] = buf_load4(srd_a, va[FIRST ? 0 : (J0 == 4)], s0);
@@ -804,6 +800,7 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParam
     };
     auto stash = [&](auto kindc, float *Ad) {             // transform + LDS refill (activation operand) of that sub-step
         constexpr int KIND = decltype(kindc)::value;
+        if ((PFANN_ABL & 4) && in_loop) return;
         if (FIRST) {
             if (KIND == 0) { px[0] = first_z(1); px[1] = first_z(3); }
             else if (KIND == 1) { px[0] = first_z(0); px[1] = first_z(2); }
@@ -832,11 +829,29 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParam
     const int nch = p.Ci / BK;
     const int l31 = lane & 31, lhalf = lane >> 5;
     issue(K0{}, 0, s_b0);
+    if (FIRST) {
+        // the log-mel values reach LDS only now, behind the first sub-step's requests: their round trip and that of the
+        // weight tile / LayerNorm rows overlap (round 6; the tile trace showed the folded-first prologue at 8.4 us against
+        // 4.2 us for the other layers: two memory round trips one after the other)
+        s_ml[rowq * 16 + col4 * 2] = mlv[0];
+        s_ml[rowq * 16 + col4 * 2 + 1] = mlv[1];
+        __syncthreads();
+    }
     stash(K0{}, As);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the weight tile has landed in LDS (the barrier's fence does not wait for it)
     __syncthreads();
     TILE_STAMP(ts_loop);
+    in_loop = PFANN_ABL != 0;
     const int bfrag = (wn * 32 + l31) * BK + ((lhalf ^ ((l31 >> 1) & 7)) * 4);   // this lane's weight chunk of K step 0; step kk: ^ 8 kk
+#ifdef PFANN_TILE_TRACE
+    // K-loop phases of this wave, shader cycles: [0] barrier release -> stash (fragment reads, requests, MFMAs of kk 0..2),
+    // [1] stash (LayerNorm transform + LDS refill, incl. its waits for the requested rows), [2] MFMAs of kk 3,
+    // [3] wait for the weight tile (vmcnt), [4] barrier, [5] wait for the requested rows in front of the stash
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, ph_last = __builtin_readcyclecounter();
+#define PH_STAMP(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); ph[i] += now_ - ph_last; ph_last = now_; } while (0)
+#else
+#define PH_STAMP(i)
+#endif
     // one sub-step: MFMAs on LDS buffer PB while the next sub-step goes global -> registers -> buffer PB ^ 1
     auto substep = [&](int ch, auto kindc, auto nextc) {
         constexpr int KIND = decltype(kindc)::value, PB = KIND & 1;
@@ -858,7 +873,13 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParam
 #endif
             if (kk == BK / 8 - 1) {
                 __builtin_amdgcn_sched_barrier(0);
+                PH_STAMP(0);
+#ifdef PFANN_TILE_TRACE
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (trace builds: the wait for the requested rows on its own)
+                PH_STAMP(5);
+#endif
                 if (more) stash(nextc, An);
+                PH_STAMP(1);
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -881,8 +902,11 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParam
             }
 #endif
         }
+        PH_STAMP(2);
         if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next weight tile has landed in LDS before anyone reads it
+        PH_STAMP(3);
         __syncthreads();
+        PH_STAMP(4);
     };
     for (int ch = 0; ch < nch; ++ch) {
         substep(ch, K0{}, K1{});
@@ -979,10 +1003,11 @@ __global__ __launch_bounds__(512, 4) void conv_gemm_ln_w22_kernel(FusedGemmParam
 #ifdef PFANN_TILE_TRACE
     if (tid == 0 && g_tile_trace != nullptr && blockIdx.x < g_tile_trace_cap && (g_tile_trace_rps == 0 || g_tile_trace_rps == rps)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (this wave's output stores have been acknowledged)
-        unsigned long long *o = g_tile_trace + (size_t)blockIdx.x * 6;
+        unsigned long long *o = g_tile_trace + (size_t)blockIdx.x * 12;
         o[0] = ts_start; o[1] = ts_loop; o[2] = ts_loop_end; o[3] = __builtin_amdgcn_s_memrealtime();
         o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);          // HW_REG_HW_ID
         o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);         // HW_REG_XCC_ID
+        for (int i = 0; i < 6; ++i) o[6 + i] = ph[i];              // (wave 0's K-loop phases)
     }
 #endif
 }
@@ -1163,7 +1188,7 @@ int launch_conv_gemm_ln(const SubLayer &L, const SubLayer &Lin, const float *x, 
         p.w1 = Lfirst->w; p.b1 = Lfirst->bias;
         p.T0 = Lfirst->T; p.s1 = Lfirst->stride; p.pad1 = Lfirst->pad_lo;
     }
-    if (!in_final) {
+    if (!in_final && !(PFANN_ABL & 8)) {        // (PFANN_ABL & 8: timing-only build without the ln_finalize launches)
         ProfScope ps("ln_finalize", s);
         PF_LAUNCH(ln_finalize_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, s, in_part, in_P, 1.0 / (double)p.in_elems,
                   in_stats, (int)B);

@@ -780,7 +780,7 @@ static int ensure_ws(SearchWorkspace &ws, int64_t nq) {
     PF_HIP(hipMalloc(&ws.thr_adj, sizeof(float) * cap));
     PF_HIP(hipMalloc(&ws.eps, sizeof(float) * cap));
     PF_HIP(hipMalloc(&ws.thr, sizeof(float) * cap));
-    PF_HIP(hipMalloc(&ws.cnt, sizeof(int) * cap * 64));      // up to 64 sub-lists per row
+    PF_HIP(hipMalloc(&ws.cnt, sizeof(int) * cap * 256));     // up to 256 sub-lists per row
     PF_HIP(hipMalloc(&ws.cl, sizeof(unsigned long long) * cap * CAP));
     PF_HIP(hipMalloc(&ws.left, sizeof(int) * cap));
     PF_HIP(hipMalloc(&ws.row_ovf, sizeof(int) * cap));

@@ -64,24 +64,28 @@ __device__ inline void bitonic_sort_u64(unsigned long long *s, int P, int tid, i
 template <int ELT, int NT>
 __device__ inline void topk_fallback_body(int64_t m, int *row_ovf, const float *__restrict__ q, const void *__restrict__ dbv,
                                           int64_t n, int d, int k, float *D, int64_t *I, int64_t label_base) {
-    constexpr int FB = 2048, RPP = NT / 2;        // buffer slots; rows per pass (NT / 8 row groups x 4)
+    constexpr int FB = 2048, RPP = NT / 2;        // buffer slots; rows per pass (NT / 4 row groups x 2)
     __shared__ unsigned long long buf[FB];
     __shared__ float qs[1024];
     __shared__ int s_cnt;
     __shared__ unsigned long long s_T;
     if (row_ovf[m] == 0) return;
-    const int tid = threadIdx.x, sub = tid & 7, grp = tid >> 3;
+    // FOUR lanes per row, partial sums over e = 4 sub, 4 sub + 16, ..., combined as (p0 + p1) + (p2 + p3): the summation
+    // order of the select kernels' exact re-scoring (search_f16.hip), so a row's fp32 score has the same bits whether it comes
+    // out of a select or out of this fallback (round 6: with eight lanes per row a list overflow on one path of a sharded
+    // search moved a score by one ulp against the single-shard run)
+    const int tid = threadIdx.x, sub = tid & 3, grp = tid >> 2;
     for (int e = tid; e < d; e += NT) qs[e] = ELT == 4 ? q[m * d + e] : (float)(_Float16)q[m * d + e];
     if (tid == 0) { s_cnt = 0; s_T = ~0ull; }
     __syncthreads();
     for (int64_t base = 0; base < n; base += RPP) {
         const unsigned long long T = s_T;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t row = base + u * (NT / 8) + grp;
+        for (int u = 0; u < 2; ++u) {
+            const int64_t row = base + u * (NT / 4) + grp;
             float part = 0.f;
             if (row < n) {
-                for (int e = sub * 4; e < d; e += 32) {
+                for (int e = sub * 4; e < d; e += 16) {
                     float x0, x1, x2, x3;
                     if (ELT == 4) {
                         const float4 x4 = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(dbv) + row * d + e);
@@ -97,7 +101,6 @@ __device__ inline void topk_fallback_body(int64_t m, int *row_ovf, const float *
             }
             part += __shfl_xor(part, 1, 64);
             part += __shfl_xor(part, 2, 64);
-            part += __shfl_xor(part, 4, 64);
             if (sub == 0 && row < n) {
                 const unsigned long long key = pack_key(part, (unsigned)row);
                 if (key < T) buf[atomicAdd(&s_cnt, 1)] = key;       // s_cnt <= FB - RPP before the pass

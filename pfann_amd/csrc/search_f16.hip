@@ -293,6 +293,7 @@ __device__ unsigned g_scan_trace_cap = 0;
 template <int KS, bool GMAX = false, int DBR = 128, int NBUF = 2>
 __global__ __launch_bounds__(256, DBR == 64 ? 3 : (NBUF == 3 ? 1 : 2)) void scan_f16_qres_kernel(ScanParams p) {
     constexpr int BM = 128, WM = 64, WN = DBR / 2, TM = 2, TN = WN / 32;
+    constexpr bool BAL = !GMAX;                   // balanced row -> owner mapping of the survivor-emitting passes (see `frag`)
     constexpr int ROWB = KS * 32;                 // bytes of one fp16 row
     constexpr int CPR = ROWB / 16;                // 16-byte chunks per row
     constexpr int NLD = DBR * CPR / 256;          // direct-to-LDS loads per thread per db tile
@@ -307,21 +308,24 @@ __global__ __launch_bounds__(256, DBR == 64 ? 3 : (NBUF == 3 ? 1 : 2)) void scan
     // NBUF = 3: tile t + 2S is requested at the top of the step of tile t, so a tile has TWO steps to arrive
     static_assert(NBUF == 2 || NBUF == 3, "two or three db-tile buffers");
     __shared__ __attribute__((aligned(1024))) float Bs2[NBUF == 3 ? TILE_F : 1];
-    __shared__ int s_cnt[BM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lhalf = lane >> 5;
-    const int S = p.nsub, subcap = CAP / S;
+    const int S = p.nsub, subcap = CAP / (4 * S);       // capacity of one PRIVATE list: a quarter of the (row, slice) list
     const int L = xcd_remap(blockIdx.x, gridDim.x);
     const int seg = L / p.n_tiles_m, mt = L - seg * p.n_tiles_m;     // neighbours share the db segment (L2)
     const int64_t m0 = (int64_t)mt * BM;
     // db tiles seg, seg + S, seg + 2S, ...: interleaved, so a run of similar rows (one song) is spread
     // over the sub-lists instead of overflowing one
     const int64_t t_lo = seg, t_hi = (p.nrows + DBR - 1) / DBR;
-    if (tid < BM) s_cnt[tid] = 0;
-    // this workgroup's sub-lists: row ml, slot pos -> keys[(m0 + ml) * CAP + seg * subcap + pos]
-    const __amdgpu_buffer_rsrc_t srd_k = make_srd(p.keys + m0 * CAP + (int64_t)seg * subcap, (unsigned long long)BM * CAP * 8ull);
+    // this lane's private lists: row ml, slot pos -> keys[(m0 + ml) * CAP + own * subcap + pos], own = 4 seg + 2 wn + lhalf
+    const __amdgpu_buffer_rsrc_t srd_k = make_srd(p.keys + m0 * CAP, (unsigned long long)BM * CAP * 8ull);
+    const int own = 4 * seg + 2 * wn + lhalf;
+    const unsigned own_off = (unsigned)(own * subcap) * 8u;
+    int posr[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) posr[i] = 0;
     const char *qb = reinterpret_cast<const char *>(p.q), *dbb = reinterpret_cast<const char *>(p.db);
 
     // ---- query fragments: lane (l31, lhalf) holds k = 16*kk + 8*lhalf .. +7 of query row m0 + wm*64 + i*32 + l31.
@@ -364,7 +368,9 @@ __global__ __launch_bounds__(256, DBR == 64 ? 3 : (NBUF == 3 ? 1 : 2)) void scan
     // the fragment reads apply the same XOR: 16 consecutive rows hit 16 different bank groups.
     //   instruction (wave, u) covers LDS chunks [(wave*NLD + u)*64, +64)
     constexpr int RP = 256 / ROWB;                 // rows per 256 bytes of LDS (1 at d = 128, 2 at d = 64)
-    auto key = [](int r) { return (r / RP) & (CPR - 1); };
+    // BAL: a 16-lane read group holds fragment rows (l31 >> 2) in {0,3,5,6} or {1,2,4,7} x (l31 & 3) = 0..3, i.e. tile rows
+    // 8 a + 4 wn + b: the key is built from a mod 4 and b so that the sixteen hit sixteen different bank groups again
+    auto key = [](int r) { return BAL ? (((r >> 3) & 3) * (4 / RP)) | ((r & 3) / RP) : (r / RP) & (CPR - 1); };
     // the 64-row-tile instantiation is the full pass: launched with stride 1 only (launch_scan_f16), so the row step is a
     // compile-time 1 there and the sixteen (8 g + e) * stride products of the survivor path are immediates, not registers
     const int64_t rstride = DBR == 64 ? 1 : p.row_stride;
@@ -427,7 +433,11 @@ __global__ __launch_bounds__(256, DBR == 64 ? 3 : (NBUF == 3 ? 1 : 2)) void scan
         auto frag = [&](int kk, int set) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int r = wn * WN + j * 32 + l31;
+                // tile row of this lane's fragment row l31.  Full pass (BAL): groups of four tile rows go to the four owners
+                // (lane half, wave) in turn, so that a run of similar consecutive db rows (one song: up to 40 survivors of a
+                // query row in a 64-row tile) fills the four private survivor lists evenly -- with each wave on its own 32-row
+                // half of the tile one owner took 16 of the 40 and its list overflowed at a quarter of the slice's capacity.
+                const int r = BAL ? j * 64 + 8 * (l31 >> 2) + 4 * wn + (l31 & 3) : wn * WN + j * 32 + l31;
                 b8[set][j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(
                                                            &Bc[r * (ROWB / 4) + (((kk * 2 + lhalf) ^ key(r)) * 4)]));
             }
@@ -458,7 +468,7 @@ __global__ __launch_bounds__(256, DBR == 64 ? 3 : (NBUF == 3 ? 1 : 2)) void scan
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (wn * WN + j * 32 + 8 * (r >> 2) + 4 * lhalf + (r & 3) >= nvalid) {
+                    if ((BAL ? j * 64 + 16 * (r >> 2) + 8 * lhalf + 4 * wn + (r & 3) : wn * WN + j * 32 + 8 * (r >> 2) + 4 * lhalf + (r & 3)) >= nvalid) {
 #pragma unroll
                         for (int i = 0; i < TM; ++i) acc[i][j][r] = -INFINITY;
                     }
@@ -482,44 +492,31 @@ __global__ __launch_bounds__(256, DBR == 64 ? 3 : (NBUF == 3 ? 1 : 2)) void scan
                     // for non-survivors (the buffer unit drops them): no per-register exec-mask regions -- the
                     // straightforward `if (survivor) { atomic; store }` per register compiled to 440 instructions per
                     // block and was a third of the pass.
+                    // Each lane appends to a list of ITS OWN (round 6): a query row's survivors in this slice come from four
+                    // owners -- the two waves of its row half x the two lane halves -- which used to share one list behind an
+                    // LDS counter (count pass, ds_add_rtn round trip, and in front of it the compiler's vmcnt(0)).  Now the
+                    // (row, slice) list is cut into four private quarters, the write position is a register, and the count
+                    // is written once at the end of the kernel; the select kernels gather 4 S sub-lists per row.
                     const int ml = wm * WM + i * 32 + l31;
-                    bool anyg[4];
-                    int c = 0;
+                    // (BAL: register 4 g + e of this lane is tile row j * 64 + 16 g + 8 lhalf + 4 wn + e)
+                    const unsigned row0 = (unsigned)((t * DBR + j * 64 + 8 * lhalf + 4 * wn) * rstride);
+                    int pos = posr[i];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        anyg[g] = __any(mg[g] >= th[i]);
-                        if (anyg[g]) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) c += acc[i][j][4 * g + e] >= th[i] ? 1 : 0;
-                        }
-                    }
-                    int pos = 0;
-                    if (NBUF == 3) {
-                        // the reservation as a bare ds_add_rtn: in front of an LDS atomic the compiler's wait insertion puts
-                        // `s_waitcnt vmcnt(0)` while an LDS load is outstanding (it cannot tell s_cnt from the tile buffers),
-                        // which would drain the request of tile t + 2S in every step that holds a survivor -- most of them.
-                        // (With two buffers the builtin is kept: the same wait costs nothing there, 2.60 vs 2.62 ms.)
-                        if (c > 0) {
-                            const unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) int *)&s_cnt[ml];
-                            asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(pos) : "v"(a), "v"(c) : "memory");
-                        }
-                    } else if (c > 0) pos = atomicAdd(&s_cnt[ml], c);       // one reservation for all of the lane's survivors
-                    const unsigned row0 = (unsigned)((t * DBR + wn * WN + j * 32 + 4 * lhalf) * rstride);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        if (anyg[g]) {
+                        if (__any(mg[g] >= th[i])) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const float v = acc[i][j][4 * g + e];
                                 const bool sv = v >= th[i];
-                                const unsigned long long key = pack_key(v, row0 + (unsigned)((8 * g + e) * rstride));
+                                const unsigned long long key = pack_key(v, row0 + (unsigned)((16 * g + e) * rstride));
                                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, key), srd_k,
-                                                                      (sv && pos < subcap) ? (unsigned)(ml * CAP + pos) * 8u : BUF_OOB, 0, 0);
+                                                                      (sv && pos < subcap) ? (unsigned)(ml * CAP + pos) * 8u + own_off : BUF_OOB, 0, 0);
                                 pos += sv ? 1 : 0;
                             }
                         }
                     }
+                    posr[i] = pos;
                 }
             }
         SCAN_STAMP(2);
@@ -601,7 +598,11 @@ __global__ __launch_bounds__(256, DBR == 64 ? 3 : (NBUF == 3 ? 1 : 2)) void scan
         }
         return;
     }
-    if (tid < BM && m0 + tid < p.nq) p.cnt[(m0 + tid) * S + seg] = s_cnt[tid];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int64_t m = m0 + wm * WM + i * 32 + l31;
+        if (m < p.nq) p.cnt[m * (4 * S) + own] = posr[i];
+    }
 #ifdef PFANN_SCAN_TRACE
     if (!GMAX && lane == 0 && g_scan_trace != nullptr && blockIdx.x < g_scan_trace_cap) {
         unsigned long long *o = g_scan_trace + ((size_t)blockIdx.x * 4 + wave) * 8;
@@ -704,7 +705,9 @@ int launch_scan_f16(const void *dbh, int64_t n, int d, int64_t stride, const voi
     p.n_tiles_m = cdiv(nq, 128);
     const int64_t db_tiles = cdiv(p.nrows, 128);
     static const bool no_qres = getenv("PFANN_NO_QRES") != nullptr;
+    bool qres_lists = false;
     if (thr_adj != nullptr && allow_sublists && !no_qres && (d == 128 || d == 64) && nq >= qres_min_nq() && db_tiles >= 16 && qres_stride_ok(stride, d)) {
+        qres_lists = true;
         // S interleaved db slices: about four rounds of the 512 resident workgroups, sub-lists of >= 256; with few query
         // tiles up to 64 slices (sub-lists of 128: a row's ~330 survivors spread over them), so that one query tile still
         // becomes 64 workgroups
@@ -723,7 +726,7 @@ int launch_scan_f16(const void *dbh, int64_t n, int d, int64_t stride, const voi
         if (s_env > 0) S = s_env;
         if (S > db_tiles) S = (int)db_tiles;
         p.nsub = S;
-        PF_HIP(hipMemsetAsync(ws.cnt, 0, sizeof(int) * nq * S, s));
+        // (no counter reset: every (row, private list) count is written by the lane that owns it, cnt[nq][4 S])
         const dim3 grid((unsigned)(p.n_tiles_m * S));
         // 64-row db tiles, three workgroups per CU (168 VGPRs) for the full pass: 2.97 -> 2.86 ms on the bench's 9728 x 1 M
         // pass, back to back on one box (four per CU would need <= 128 VGPRs: 35 spilled); PFANN_SCAN_DBR128=1: the old tiles
@@ -740,7 +743,7 @@ int launch_scan_f16(const void *dbh, int64_t n, int d, int64_t stride, const voi
     else
         PF_LAUNCH((scan_f16_kernel<1>), dim3((unsigned)(db_tiles * p.n_tiles_m)), dim3(256), 0, s, p);
     PF_HIP(hipGetLastError());
-    *nsub_out = p.nsub;
+    *nsub_out = qres_lists ? 4 * p.nsub : p.nsub;       // the query-stationary kernel: four private lists per (row, slice)
     return 0;
 }
 
@@ -750,6 +753,44 @@ int launch_scan_f16(const void *dbh, int64_t n, int d, int64_t stride, const voi
 // round trips (count / key gather / candidate rows) overlap.  Same steps and results as
 // select_rescore_kernel below, which keeps the rows with more survivors.
 // ------------------------------------------------------------------------------------
+// Offsets of a row's sub-lists (at most NSUB_MAX = 256 since round 6: the query-stationary scan keeps FOUR private lists
+// per (row, db slice) -- one per owner lane -- instead of one list with an LDS counter): s_off[g] = keys of sub-lists
+// 0 .. g-1 (counts clamped to the sub-list capacity), s_off[nsub] = n, s_off[NSUB_MAX + 1] = some list overflowed.
+// Called by every thread of the workgroup (NT >= 256 threads); contains barriers.
+constexpr int NSUB_MAX = 256;
+template <int NT>
+__device__ __forceinline__ void sublist_offsets(const int *__restrict__ cnt_row, int nsub, int subcap, int *s_off, int *s_wt) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int incl = 0;
+    bool ov = false;
+    if (tid < NSUB_MAX) {
+        int c = tid < nsub ? cnt_row[tid] : 0;
+        ov = c > subcap;
+        c = ov ? subcap : c;
+        incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) s_wt[wave] = incl;
+        const bool any_ov = __any(ov);
+        if (lane == 0) s_wt[4 + wave] = any_ov ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid < NSUB_MAX) {
+        int base = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) base += w < wave ? s_wt[w] : 0;
+        s_off[tid + 1] = base + incl;
+        if (tid == 0) {
+            s_off[0] = 0;
+            s_off[NSUB_MAX + 1] = s_wt[4] | s_wt[5] | s_wt[6] | s_wt[7];
+        }
+    }
+    __syncthreads();
+}
+
 constexpr int SMALL_N = 4096;
 __device__ __forceinline__ void select_rescore_small_row(const int64_t m, const unsigned long long *__restrict__ keys,
                                                 const int *__restrict__ cnt, int k, int mode,
@@ -763,32 +804,17 @@ __device__ __forceinline__ void select_rescore_small_row(const int64_t m, const 
     constexpr int NT = 256, KPT = SMALL_N / NT;
     __shared__ __attribute__((aligned(16))) unsigned long long skeys[SMALL_N];
     __shared__ int s_n2, s_bin, s_kk;
-    __shared__ int s_off[66];
+    __shared__ int s_off[NSUB_MAX + 2], s_wt[8];
     __shared__ int hist[256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int subcap = CAP / nsub;
-    if (tid < 64) {
-        int c = tid < nsub ? cnt[m * nsub + tid] : 0;
-        const bool ov = c > subcap;
-        c = ov ? subcap : c;
-        int incl = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o, 64);
-            if (tid >= o) incl += v;
-        }
-        s_off[tid + 1] = incl;
-        if (tid == 0) s_off[0] = 0;
-        const bool any_ov = __any(ov);
-        if (tid == 0) s_off[65] = any_ov ? 1 : 0;
-    }
-    __syncthreads();
+    sublist_offsets<NT>(cnt + m * nsub, nsub, subcap, s_off, s_wt);
     const int n = s_off[nsub];
     if (n > SMALL_N) {                                // select_rescore_kernel's job
         if (tid == 0) atomicAdd(overflow + 1, 1);
         return;
     }
-    const bool over = s_off[65] != 0;
+    const bool over = s_off[NSUB_MAX + 1] != 0;
     if (over && mode == 1 && tid == 0) row_ovf[m] = 1;           // topk_fallback_kernel recomputes this row
     if (nsub == 1) {
         for (int i = tid; i < n; i += NT) skeys[i] = keys[m * CAP + i];
@@ -981,24 +1007,36 @@ __global__ __launch_bounds__(256) void select_rescore_wave_kernel(const unsigned
     if (m >= nq) return;
     unsigned long long *sk = wk[w];
     const int subcap = CAP / nsub;
-    int c = lane < nsub ? cnt[m * nsub + lane] : 0;
-    const bool ov = c > subcap;
-    int incl = c;
+    // up to 256 sub-lists, four per lane (sub-list lane + 64 j in chunk j); offsets by a wave scan per chunk + carry
+    int c[4], og[4], n = 0;
+    bool ov = false;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += v;
+    for (int j = 0; j < 4; ++j) {
+        c[j] = lane + 64 * j < nsub ? cnt[m * nsub + lane + 64 * j] : 0;
+        ov = ov || c[j] > subcap;
+        int incl = c[j];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        og[j] = n + incl - c[j];
+        n += __shfl(incl, 63, 64);
     }
-    const int n = __shfl(incl, 63, 64);
     if (__any(ov) || n > WAVE_N) {
         if (lane == 0) left[atomicAdd(overflow + 2, 1)] = (int)m;
         return;
     }
-    // gather the sub-lists (sub-list g holds its keys at keys[m*CAP + g*subcap])
-    for (int g = 0; g < nsub; ++g) {
-        const int cg = __shfl(c, g, 64), og = __shfl(incl, g, 64) - cg;
-        if (lane < cg) sk[og + lane] = keys[m * CAP + (int64_t)g * subcap + lane];
-        for (int i = 64 + lane; i < cg; i += 64) sk[og + i] = keys[m * CAP + (int64_t)g * subcap + i];
+    // gather: every lane copies its own (short: a handful of keys) sub-lists, sub-list g at keys[m*CAP + g*subcap]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (64 * j >= nsub) break;
+        int cmax = c[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o, 64));
+        const unsigned long long *src = keys + m * CAP + (int64_t)(lane + 64 * j) * subcap;
+        for (int i = 0; i < cmax; ++i)
+            if (i < c[j]) sk[og[j] + i] = src[i];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const float e2 = rescore ? 2.0f * eps[m] : 0.f;
@@ -1104,39 +1142,24 @@ __device__ __forceinline__ void select_rescore_body(const unsigned long long *__
                                            int skip_small, int rescore, int64_t m = -1) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
     __shared__ int s_n2;
-    __shared__ int s_off[66];
+    __shared__ int s_off[NSUB_MAX + 2], s_wt[8];
     if (m < 0) m = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (skip_small && overflow[1] == 0) return;       // every row was handled by select_rescore_small_kernel
     // gather the row's nsub sub-lists (sub-list g holds cnt[m*nsub+g] keys at keys[m*CAP + g*subcap])
     const int subcap = CAP / nsub;
-    if (tid < 64) {
-        int c = tid < nsub ? cnt[m * nsub + tid] : 0;
-        const bool ov = c > subcap;
-        c = ov ? subcap : c;
-        int incl = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o, 64);
-            if (tid >= o) incl += v;
-        }
-        s_off[tid + 1] = incl;
-        if (tid == 0) s_off[0] = 0;
-        const bool any_ov = __any(ov);
-        if (tid == 0) s_off[65] = any_ov ? 1 : 0;
-    }
-    __syncthreads();
+    sublist_offsets<1024>(cnt + m * nsub, nsub, subcap, s_off, s_wt);
     const int n = s_off[nsub];
     if (skip_small && n <= SMALL_N) return;          // done by select_rescore_small_kernel
-    const bool over = s_off[65] != 0;
+    const bool over = s_off[NSUB_MAX + 1] != 0;
     if (over && mode == 1 && tid == 0) row_ovf[m] = 1;           // topk_fallback_kernel recomputes this row
     int P = 1;
     while (P < n) P <<= 1;
     if (nsub == 1) {
         for (int i = tid; i < n; i += 1024) skeys[i] = keys[m * CAP + i];
     } else {
-        const int g = tid >> 4, l = tid & 15;      // 16 threads per sub-list
-        if (g < nsub) {
+        const int l = tid & 15;                    // 16 threads per sub-list, 64 sub-lists per pass
+        for (int g = tid >> 4; g < nsub; g += 64) {
             const int o = s_off[g], c = s_off[g + 1] - o;
             for (int i = l; i < c; i += 16) skeys[o + i] = keys[m * CAP + g * subcap + i];
         }
@@ -1351,7 +1374,7 @@ int launch_select_rescore(SearchWorkspace &ws, int64_t nq, int k, int mode, floa
     ProfScope ps(rescore ? "topk_select_rescore" : "topk_select_radix", s);
     PF_HIP(hipMemsetAsync(ws.overflow + 1, 0, 2 * sizeof(int), s));
     static const bool no_wave = getenv("PFANN_NO_WAVE_SELECT") != nullptr;       // A/B aid
-    const bool wave_tier = few_survivors && mode == 1 && nsub <= 64 && k <= WAVE_N && !no_wave;
+    const bool wave_tier = few_survivors && mode == 1 && nsub <= NSUB_MAX && k <= WAVE_N && !no_wave;
     const unsigned long long *keys = reinterpret_cast<const unsigned long long *>(ws.cl);
     if (wave_tier) {
         if (ensure_dyn_lds((const void *)select_rescore_list_kernel, CAP * 8)) return -1;

@@ -465,6 +465,25 @@ def test_search_topk_mid_batch_takes_the_query_stationary_kernels(torch_cuda, n,
     _check_topk(torch_cuda, db.astype(np.float32), q.astype(np.float32), 100, True)
 
 
+@pytest.mark.parametrize("nq", [130, 2100])
+def test_search_topk_private_lists_take_whole_songs(torch_cuda, nq):
+    """Round 6: the query-stationary scan keeps four PRIVATE survivor lists per (query row, db slice) -- one per owner lane --
+    instead of one list behind an LDS counter, and hands groups of four consecutive db rows to the four owners in turn.  A db
+    made of runs of 40 nearly identical rows whose query sits in the middle of a run puts 40 survivors of one query row into one
+    64-row tile: they must spread over the private lists (no list overflow -> no exact fallback -> the fp32 scores come from
+    the select's own re-scoring) and the answer is the exact top-k, for one query tile (64 slices, lists of 32) and for
+    seventeen."""
+    d, n, k = 128, 150000, 100
+    db = synth.unit_rows(61, "t/pl", n, d)
+    for s0 in range(0, n, 40):
+        db[s0:s0 + 40] = db[s0] + 0.05 * db[s0:s0 + 40]
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    q = synth.unit_rows(62, "t/plq", nq, d)
+    q[::2] = db[(np.arange(len(q[::2])) * 7919 + 20) % n] + 0.3 * q[::2]
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    _check_topk(torch_cuda, db.astype(np.float32), q.astype(np.float32), k, True)
+
+
 def test_search_topk_sublist_overflow_falls_back(torch_cuda):
     """More near-identical rows inside ONE interleaved db slice than a sub-list holds (256 at 32
     slices): the rows that lost survivors are recomputed exactly by the device-side fallback kernel."""

@@ -33,7 +33,7 @@ starts = (torch.arange(B, device="cuda") * 1571) % (wav.shape[0] - 8000)
 for _ in range(2):
     eng.embed_windows(wav, starts)
 cap = 1 << 19
-buf = torch.zeros((cap, 6), dtype=torch.int64, device="cuda")
+buf = torch.zeros((cap, 12), dtype=torch.int64, device="cuda")
 assert lib.pfann_debug_set_tile_trace(buf.data_ptr(), cap, RPS) == 0
 eng.embed_windows(wav, starts)
 torch.cuda.synchronize()
@@ -49,6 +49,11 @@ t0 = t[:, 0].min()
 st, lb, le, en = [(t[:, i] - t0).astype(np.float64) * 10.0 for i in range(4)]     # ns
 print("traced %d workgroups of the rows=%d layer on %d CUs (%d windows); launch span %.3f ms" % (n, RPS, len(np.unique(cu)), B, (en.max()) / 1e6))
 print("wave slots of thread 0's wave:", dict(zip(*np.unique(wave_id, return_counts=True))))
+PH = ["kk 0..2: fragment reads, requests, MFMAs", "stash: LayerNorm transform + LDS refill (+ its waits)", "kk 3 MFMAs", "wait for the weight tile (vmcnt)", "barrier", "wait for the requested rows (vmcnt) in front of the stash"]
+ph = t[:, 6:12].astype(np.float64)
+print("K-loop phases of wave 0, shader cycles per tile (mean):")
+for i, nm in enumerate(PH):
+    print("   %-56s %9.0f  (%.1f %%)" % (nm, ph[:, i].mean(), 100 * ph[:, i].mean() / ph.sum(axis=1).mean()))
 print("phase means (ns): prologue %.0f  K loop %.0f  epilogue %.0f  whole %.0f" % ((lb - st).mean(), (le - lb).mean(), (en - le).mean(), (en - st).mean()))
 # steady state window: between the 10th and 90th percentile of start times
 w0, w1 = np.percentile(st, 10), np.percentile(st, 90)
@@ -84,6 +89,7 @@ tot = res["resident"].sum()
 out = {"windows": B, "rows_per_sample": RPS, "workgroups": int(n), "cus": int(len(np.unique(cu))),
        "phase_ns": {"prologue": float((lb - st).mean()), "k_loop": float((le - lb).mean()), "epilogue": float((en - le).mean()),
                     "whole": float((en - st).mean())},
+       "k_loop_phase_cycles_wave0": {nm: float(ph[:, i].mean()) for i, nm in enumerate(PH)},
        "resident_fraction": {str(i): float(res["resident"][i] / tot) for i in range(4)},
        "in_loop_fraction": {str(i): float(res["in_loop"][i] / tot) for i in range(4)},
        "successor_gap_ns": {"median": float(np.median(gaps)), "mean": float(np.mean(gaps)), "p90": float(np.percentile(gaps, 90))},
