@@ -50,6 +50,14 @@ def test_bench_json_contract_small():
     assert len(out["alt_modes"]["encoder_only"]) == 3 and all(v["segments_per_s"] > 0 for v in out["alt_modes"]["encoder_only"].values())
     assert out["seq_score_seam"]["same_best_song"] is True and out["seq_score_seam"]["calls"] == 200
     assert out["seq_score_seam"]["gpu_call_us_median"] <= out["seq_score_seam"]["gpu_call_us_p95"]
+    # round 6: the whole step per launch group of 1 / 4 / 16 queries (19 / 76 / 304 windows: the one-query plan, the
+    # middle-of-the-curve plan with its split-K layers, and the query-stationary search at 76 and 304 rows) decides like the timed step
+    bc = out["batch_curve"]["points"]
+    assert [pt["queries"] for pt in bc] == [1, 4, 16], bc
+    for pt in bc:
+        same, of = pt["decisions_identical_to_the_timed_step"].split("/")
+        assert same == of and pt["segments_per_s"] > 0 and set(pt["kernel_ms_by_stage"]) == {"encoder", "scan", "matcher"}, pt
+    assert bc[-1]["fraction_of_largest_group_rate"] == 1.0
 
 
 def test_live_traffic_of_the_conv_gemms_is_measured_under_rocprofv3(tmp_path):
