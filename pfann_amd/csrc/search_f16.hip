@@ -259,9 +259,10 @@ __global__ __launch_bounds__(256, 2) void scan_f16_kernel(ScanParams p) {
 //   * only the 32 KB db tile goes through LDS per step (double buffered, one barrier): half the
 //     LDS traffic and staging instructions per MFMA of the generic kernel above, which matters
 //     because with d this small the loop is bound by LDS and issue slots, not by the fp16 MFMA rate;
-//   * survivors go to the workgroup's OWN sub-list (query row, segment) with LDS counters; the
-//     15 million device-scope atomics of a db-stationary split cost 5 ms per pass on MI355X
-//     (measured) and are gone.  The select kernels gather the S sub-lists of a row.
+//   * survivors go to lists of the LANE's own: four private lists per (query row, db slice), one per owner (the two waves
+//     of the row half x the two lane halves), write position in a register, count written once at the end (round 6; up to
+//     round 5 one list per (row, slice) behind an LDS counter; the 15 million device-scope atomics of a db-stationary
+//     split cost 5 ms per pass on MI355X, measured).  The select kernels gather the 4 S sub-lists of a row.
 // ------------------------------------------------------------------------------------
 // GMAX = true (sampled pass, no thresholds): no survivor lists at all -- every (lane, register) keeps the running maximum
 // of ITS row position over all db tiles of the slice and the kernel writes 64 group maxima per (query row, slice); the
@@ -536,7 +537,7 @@ __global__ __launch_bounds__(256, DBR == 64 ? 3 : (NBUF == 3 ? 1 : 2)) void scan
             // a RAW barrier: __syncthreads() carries a fence, and with an LDS load outstanding the fence is lowered to
             // `s_waitcnt vmcnt(0)` -- it would drain the request of tile t + 2S issued at the top of this step, i.e. undo the
             // third buffer.  What the hand-over needs is above (this wave's share of tile t + S has landed: vmcnt(NLD)) and
-            // here (its LDS counter updates and fragment reads are complete: lgkmcnt(0)).
+            // here (its fragment reads are complete: lgkmcnt(0)).
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
