@@ -838,7 +838,12 @@ int pfann_match(pfann_db *db, const float *q, const int64_t *labels, int k, cons
     while (P < (int64_t)max_qlen * k) P <<= 1;
     a.pmax = P;
     a.gkeys = nullptr; a.gscore = nullptr; a.ncand = nullptr; a.phase = 0;
-    const bool phased = nQ <= 16;      // a handful of queries: spread each one's candidate scoring over the GPU
+    // a handful of queries: spread each one's candidate scoring over the GPU (three launches: candidates, scores on all CUs,
+    // argmax).  One workgroup per query -- the single-launch form -- leaves most of the chip idle below ~128 queries.
+    // (round 6, tools/ubench/match_mid.py: 32 queries 0.54 -> 0.21 ms, 64 queries 0.54 -> 0.33, same decisions and scores; at
+    // 128 queries the single launch is level, 0.52 vs 0.56; up to round 5 the limit was 16)
+    static const int64_t phased_max = getenv("PFANN_MATCH_PHASED_MAX") ? atoll(getenv("PFANN_MATCH_PHASED_MAX")) : 64;
+    const bool phased = nQ <= phased_max;
     if (P > 8192 || phased) {     // longer than the LDS candidate buffer, or phased: per-query slabs in HBM
         if ((int64_t)max_qlen * k > (1 << 22)) { set_error("match: query of %d rows x top_k %d is too long", max_qlen, k); return -1; }
         const size_t need = (size_t)nQ * P * 12 + (size_t)nQ * sizeof(int);
