@@ -1143,6 +1143,35 @@ def test_owned_songs_follow_the_callers_cut_at_a_rowless_boundary_song(torch_cud
         shards[0][0].load(z[0:10], pos, 0, song_range=(0, 3))
 
 
+def test_match_phased_and_single_launch_forms_agree(torch_cuda):
+    """The sequence matcher has two launch plans: up to 64 queries the three-launch form (candidates | scores spread over all
+    CUs | argmax; round 6 raised its limit from 16), above it one workgroup per query.  The same 48 queries alone (phased) and
+    as the head of a batch of 200 (single launch) must give the same (song, offset, shift) and bit-identical scores, and the
+    same per-song score block."""
+    torch = torch_cuda
+    from pfann_amd.database import DeviceIndex
+    g = torch.Generator(device="cuda")
+    g.manual_seed(9)
+    n_songs, seg, d, ql = 3000, 40, 128, 19
+    db = torch.nn.functional.normalize(torch.randn((n_songs * seg, d), device="cuda", generator=g), dim=1)
+    pos = np.arange(n_songs + 1, dtype=np.int64) * seg
+    nQ = 200
+    src = (torch.arange(nQ, device="cuda") * 577 + 3) % (n_songs * seg - 40)
+    rows = (src[:, None] + torch.arange(ql, device="cuda")[None, :]).reshape(-1)
+    q = torch.nn.functional.normalize(db[rows] + 0.6 * torch.randn((nQ * ql, d), device="cuda", generator=g), dim=1).contiguous()
+    ix = DeviceIndex(d, 0)
+    ix.load(db, pos, 0)
+    _, I = ix.search(q, 100)
+    qs, qn = np.arange(nQ, dtype=np.int64) * ql, np.full(nQ, ql, np.int32)
+    res_all, ss_all = ix.match(q, I, qs, qn, 1, 0.0, 0, False, True, to_host=False)
+    res_all, ss_all = res_all.clone(), ss_all.clone()
+    for n_head in (17, 48, 64):
+        res_h, ss_h = ix.match(q[: n_head * ql].contiguous(), I[: n_head * ql].contiguous(), qs[:n_head], qn[:n_head], 1, 0.0, 0,
+                               False, True, to_host=False)
+        assert torch.equal(res_h, res_all[:n_head]), "decisions of the phased form differ at %d queries" % n_head
+        assert torch.equal(ss_h, ss_all[:n_head]), "per-song scores of the phased form differ at %d queries" % n_head
+
+
 def test_melspec_is_bit_stable_beside_a_batched_search(torch_cuda):
     """Round 5 finding (profiles/r5/NOTES.md): with packed-fp32 VALU instructions in it, melspec_kernel returned wrong FFT
     bins for a few windows per launch whenever the batched fp16 scan ran on ANOTHER stream at the same time (found through
