@@ -308,9 +308,11 @@ def test_matcher_cli_variants_vs_oracle(tmp_path, variant):
     assert worst_emb < 1e-4
 
 
-def test_oracle_builds_its_own_database_from_the_same_files():
+@pytest.mark.parametrize("config", ["default", "seg", "n640d64"])
+def test_oracle_builds_its_own_database_from_the_same_files(config):
     """The fully independent form of end-to-end parity (the 2,000- and 10,000-song records of the same
-    tool are under profiles/r5/): `builder.py` + `matcher.py` as subprocesses on 96 songs / 48 ten-second SNR-0 queries,
+    tool are under profiles/r5/ and -- round 6: the two depthwise models `seg.json` / `n640d64.json` and `default` at -6 dB --
+    profiles/r6/): `builder.py` + `matcher.py` as subprocesses on 96 songs / 48 ten-second SNR-0 queries,
     against an oracle that reads the same WAV files with its own reader, embeds every song ON THE HOST into its own
     database, and answers the queries against THAT -- nothing shared but the files and the weights.  The product's files
     must agree: `landmarkKey` exactly, `embeddings` within 1e-4 (3e-5 expected: both sides build the mel bank the way
@@ -318,10 +320,10 @@ def test_oracle_builds_its_own_database_from_the_same_files():
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import decision_parity_oracle_db as dp
     workers = max(4, min(32, (os.cpu_count() or 8) // 8))
-    out = dp.run(96, 48, 0.0, workers=workers, log=lambda *a: print(*a, file=sys.stderr, flush=True))
+    out = dp.run(96, 48, 0.0, workers=workers, log=lambda *a: print(*a, file=sys.stderr, flush=True), config=config)
     assert "skipped" not in out, out
-    os.makedirs(os.path.join(REPO, "gpurun_out", "r5"), exist_ok=True)
-    json.dump(out, open(os.path.join(REPO, "gpurun_out", "r5", "decision_parity_oracle_db_test.json"), "w"), indent=1)
+    os.makedirs(os.path.join(REPO, "gpurun_out", "r6"), exist_ok=True)
+    json.dump(out, open(os.path.join(REPO, "gpurun_out", "r6", "decision_parity_oracle_db_test_%s.json" % config), "w"), indent=1)
     assert out["landmarkKey_equal"] and out["embeddings_rows"] == 96 * 59 and out["tsv_and_detail_csv_agree"]
     assert out["embeddings_max_abs_diff"] < 1e-4, out["embeddings_max_abs_diff"]
     assert out["bugs"] == 0, out["flips"]
