@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/ubench/abc_layers.sh "A L C" REPS : per-layer conv GEMM times of the encoder at 9728 windows under each library build
-cd $GRAFT_REPO_ROOT
+cd ${GRAFT_REPO_ROOT:-/root/repo}
 vs=$1; reps=$2
 for i in $(seq 1 $reps); do for v in $vs; do
   cp gpurun_ab/lib$v.so pfann_amd/libpfann_amd.so
